@@ -1,0 +1,106 @@
+// dgs_common.h -- shared device helpers for the gfx950 kernels (wave64 everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <stdint.h>
+
+#include "dgsparse_hip.h"
+
+namespace dgs {
+
+constexpr int kWave = 64;    // CDNA wavefront
+constexpr int kBlock = 256;  // 4 waves per workgroup, one per SIMD
+
+// Identities of include/gspmm.h:133-146: (float)INT_MIN / (float)INT_MAX, not +-inf.
+template <int OP>
+__device__ __forceinline__ float reduce_init() {
+  if constexpr (OP == DGS_MAX) return (float)INT_MIN;
+  if constexpr (OP == DGS_MIN) return (float)INT_MAX;
+  return 0.0f;
+}
+
+// One reduction step of algorithm 0 (include/cuda/spmm_cuda.cuh:37-43 + gspmm.h:16-17 macros, taken
+// literally so that NaN/tie behaviour is identical): t = w*x is ONE fp32 rounding; E takes the column
+// id on a strict improvement, so the first occurrence in CSR order wins ties.
+template <int OP>
+__device__ __forceinline__ void reduce_step(float &res, int &eidx, float w, float x, int c) {
+  if constexpr (OP == DGS_MAX) {
+    const float t = w * x;
+    if (res < t) eidx = c;
+    res = (res < t) ? t : res;
+  } else if constexpr (OP == DGS_MIN) {
+    const float t = w * x;
+    if (res > t) eidx = c;
+    res = (res < t) ? res : t;
+  } else {
+    res = __builtin_fmaf(w, x, res);  // v_fmac_f32: the contraction nvcc applies to res + val*x
+  }
+}
+
+// V consecutive floats / ints at p (p is 4*V-byte aligned by construction of the dispatch).
+template <int V>
+__device__ __forceinline__ void load_vec(const float *p, float (&o)[V]) {
+  if constexpr (V == 4) {
+    const float4 t = *reinterpret_cast<const float4 *>(p);
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+  } else if constexpr (V == 2) {
+    const float2 t = *reinterpret_cast<const float2 *>(p);
+    o[0] = t.x; o[1] = t.y;
+  } else {
+    o[0] = *p;
+  }
+}
+template <int V>
+__device__ __forceinline__ void load_vec(const int *p, int (&o)[V]) {
+  if constexpr (V == 4) {
+    const int4 t = *reinterpret_cast<const int4 *>(p);
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+  } else if constexpr (V == 2) {
+    const int2 t = *reinterpret_cast<const int2 *>(p);
+    o[0] = t.x; o[1] = t.y;
+  } else {
+    o[0] = *p;
+  }
+}
+template <int V>
+__device__ __forceinline__ void store_vec(float *p, const float (&o)[V]) {
+  if constexpr (V == 4) {
+    *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  } else if constexpr (V == 2) {
+    *reinterpret_cast<float2 *>(p) = make_float2(o[0], o[1]);
+  } else {
+    *p = o[0];
+  }
+}
+template <int V>
+__device__ __forceinline__ void store_vec(int *p, const int (&o)[V]) {
+  if constexpr (V == 4) {
+    *reinterpret_cast<int4 *>(p) = make_int4(o[0], o[1], o[2], o[3]);
+  } else if constexpr (V == 2) {
+    *reinterpret_cast<int2 *>(p) = make_int2(o[0], o[1]);
+  } else {
+    *p = o[0];
+  }
+}
+
+// Feature-dimension mapping shared by all row-group kernels: a row is covered by G lanes x V floats.
+struct FeatMap {
+  int G;      // lanes per row group (power of two, <= 64)
+  int V;      // floats per lane (4 when N % 4 == 0 and bases are 16-B aligned, else 1)
+  int tiles;  // ceil(N / (G*V)) -> gridDim.y
+};
+inline FeatMap feat_map(int64_t N, bool aligned16) {
+  FeatMap m;
+  m.V = (N % 4 == 0 && aligned16) ? 4 : 1;
+  int64_t lanes = (N + m.V - 1) / m.V;
+  int G = 1;
+  while (G < lanes && G < 64) G <<= 1;
+  m.G = G;
+  m.tiles = (int)((lanes + G - 1) / G);
+  return m;
+}
+inline bool is_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ELAUNCH; }
+
+}  // namespace dgs

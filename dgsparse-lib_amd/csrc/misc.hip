@@ -1,0 +1,117 @@
+// misc.hip -- row gather / scatter-add (halo pack / unpack for the multi-GPU path), version/info entry
+// points, and the GE-SpMM / SDDMM compatibility shims (reference src/ge-spmm/gespmm.h:32-41,
+// src/sddmm/sddmm.h:10) over the dgs_* entry points.
+#include "dgs_common.h"
+
+namespace dgs {
+
+// One row per G-lane group, V floats per lane: dst[i,:] = src[ids[i],:]
+template <int V>
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(int64_t n_ids, int N, const int *__restrict__ ids,
+                                                             const float *__restrict__ src,
+                                                             float *__restrict__ dst) {
+  const int lanes = (N + V - 1) / V;  // lanes needed per row
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = t / lanes;
+  const int f = (int)(t % lanes) * V;
+  if (i >= n_ids) return;
+  float x[V];
+  load_vec<V>(src + (int64_t)ids[i] * N + f, x);
+  store_vec<V>(dst + i * N + f, x);
+}
+
+template <int V>
+__global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(int64_t n_ids, int N, const int *__restrict__ ids,
+                                                                  const float *__restrict__ src,
+                                                                  float *__restrict__ dst) {
+  const int lanes = (N + V - 1) / V;
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = t / lanes;
+  const int f = (int)(t % lanes) * V;
+  if (i >= n_ids) return;
+  float x[V], y[V];
+  float *d = dst + (int64_t)ids[i] * N + f;
+  load_vec<V>(src + i * N + f, x);
+  load_vec<V>(d, y);
+#pragma unroll
+  for (int v = 0; v < V; v++) y[v] += x[v];
+  store_vec<V>(d, y);
+}
+
+}  // namespace dgs
+
+using namespace dgs;
+
+extern "C" int dgs_version(void) { return 1000; }
+extern "C" const char *dgs_arch(void) { return "gfx950"; }
+extern "C" const char *dgs_strerror(int code) {
+  switch (code) {
+    case DGS_OK: return "ok";
+    case DGS_EINVAL: return "invalid argument";
+    case DGS_EWORKSPACE: return "workspace too small";
+    case DGS_ELAUNCH: return "kernel launch failed";
+    case DGS_ERANGE: return "size exceeds int32 CSR indexing";
+  }
+  return "unknown error";
+}
+
+extern "C" int dgs_gather_rows_f32(int64_t n_ids, int64_t N, const int32_t *ids, const float *src, float *dst,
+                                   dgsStream_t stream) {
+  if (n_ids < 0 || N < 0 || N >= INT32_MAX) return DGS_EINVAL;
+  if (n_ids == 0 || N == 0) return DGS_OK;
+  if (!ids || !src || !dst) return DGS_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool v4 = (N % 4 == 0) && is_aligned16(src) && is_aligned16(dst);
+  const int64_t lanes = v4 ? N / 4 : N;
+  const dim3 grid((unsigned)((n_ids * lanes + kBlock - 1) / kBlock));
+  if (v4)
+    hipLaunchKernelGGL((gather_rows_kernel<4>), grid, dim3(kBlock), 0, st, n_ids, (int)N, ids, src, dst);
+  else
+    hipLaunchKernelGGL((gather_rows_kernel<1>), grid, dim3(kBlock), 0, st, n_ids, (int)N, ids, src, dst);
+  return check_launch();
+}
+
+extern "C" int dgs_scatter_add_rows_f32(int64_t n_ids, int64_t N, const int32_t *ids, const float *src, float *dst,
+                                        dgsStream_t stream) {
+  if (n_ids < 0 || N < 0 || N >= INT32_MAX) return DGS_EINVAL;
+  if (n_ids == 0 || N == 0) return DGS_OK;
+  if (!ids || !src || !dst) return DGS_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool v4 = (N % 4 == 0) && is_aligned16(src) && is_aligned16(dst);
+  const int64_t lanes = v4 ? N / 4 : N;
+  const dim3 grid((unsigned)((n_ids * lanes + kBlock - 1) / kBlock));
+  if (v4)
+    hipLaunchKernelGGL((scatter_add_rows_kernel<4>), grid, dim3(kBlock), 0, st, n_ids, (int)N, ids, src, dst);
+  else
+    hipLaunchKernelGGL((scatter_add_rows_kernel<1>), grid, dim3(kBlock), 0, st, n_ids, (int)N, ids, src, dst);
+  return check_launch();
+}
+
+// ---- compatibility shims: same signatures as the reference's standalone C libraries, default stream ----
+extern "C" void gespmmCsrSpMM(const struct SpMatCsrDescr_t A, float *B, const int N, float *C, bool transpose_BC,
+                              enum gespmmAlg_t alg) {
+  (void)alg;  // all algorithm ids share the algorithm-0 numerics here
+  if (!transpose_BC) return;  // column-major B/C is out of scope
+  int64_t nnz = A.nnz;
+  if (nnz < 0) {  // gespmm.h semantics: nnz < 0 means "read indptr[nrow]"
+    int last = 0;
+    if (hipMemcpy(&last, A.indptr + A.nrow, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return;
+    nnz = last;
+  }
+  dgs_spmm_csr_f32(DGS_SUM, A.nrow, A.ncol, N, nnz, A.indptr, A.indices, A.data, B, C, nullptr, 0, nullptr, 0,
+                   nullptr);
+}
+extern "C" void spmm_cuda(int nrowA, int ncolB, int *rowptr, int *colind, float *values, float *dense, float *out) {
+  struct SpMatCsrDescr_t A = {nrowA, 0, -1, rowptr, colind, values};
+  A.ncol = INT32_MAX - 1;
+  gespmmCsrSpMM(A, dense, ncolB, out, true, GESPMM_ALG_DEFAULT);
+}
+extern "C" void spmm_cuda_no_edge_value(int nrowA, int ncolB, int *rowptr, int *colind, float *values, float *dense,
+                                        float *out) {
+  (void)values;
+  struct SpMatCsrDescr_t A = {nrowA, INT32_MAX - 1, -1, rowptr, colind, nullptr};
+  gespmmCsrSpMM(A, dense, ncolB, out, true, GESPMM_ALG_DEFAULT);
+}
+extern "C" void sddmm_cuda_csr(int m, int k, int nnz, int *rowptr, int *colind, float *D1, float *D2, float *out) {
+  dgs_sddmm_csr_f32(DGS_SUM, m, INT32_MAX - 1, k, nnz, rowptr, colind, D1, D2, out, nullptr);
+}

@@ -1,0 +1,19 @@
+"""dgsparse on MI355X: the reference's Python operator surface (dgsparse/__init__.py:1-49) over hand-written
+gfx950 HIP kernels reached through the C ABI of ``libdgsparse_hip.so`` (include/dgsparse_hip.h).
+
+``import dgsparse`` fails with ImportError when the HIP library has not been built - there is no fallback.
+"""
+from . import _C  # noqa: F401  (reference: pybind module with cuda_version())
+from . import _capi  # noqa: F401  (raises ImportError if libdgsparse_hip.so is missing)
+from . import _ops  # noqa: F401  (registers torch.ops.dgsparse_spmm.*)
+from .ftransform import csr2csc
+from .sddmm import sddmm
+from .spmm import spmm_max, spmm_mean, spmm_min, spmm_sum
+from .storage import Storage
+from .tensor import SparseTensor
+
+__version__ = '0.1'
+
+cuda_version = _C.cuda_version()  # -1 on ROCm: the reference's CUDA-major check is skipped (__init__.py:29)
+
+__all__ = ['spmm_sum', 'spmm_max', 'spmm_min', 'spmm_mean', 'sddmm', 'Storage', 'SparseTensor', 'csr2csc']

@@ -1,0 +1,218 @@
+"""ctypes binding of the C-ABI library ``libdgsparse_hip.so`` (declared in include/dgsparse_hip.h).
+
+This is the ONLY compute back end of the package: there is no CPU or eager-PyTorch fallback.  Importing
+fails loudly when the library is missing, and every call on a non-GPU tensor raises.  PyTorch is used for
+device memory, the current HIP stream and ``torch.distributed`` only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdgsparse_hip.so')
+
+SUM, MAX, MIN, MEAN = 0, 1, 2, 3  # include/gspmm.h:13 in the reference
+
+if not os.path.exists(LIB_PATH):  # mirrors dgsparse/__init__.py:25 in the reference (ImportError, no fallback)
+    raise ImportError(f"Could not find the HIP kernel library '{LIB_PATH}'. Build it with "
+                      f"`make -C dgsparse-lib_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`).")
+
+_lib = ctypes.CDLL(LIB_PATH)
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_sz = ctypes.c_size_t
+
+_lib.dgs_version.restype = _int
+_lib.dgs_arch.restype = ctypes.c_char_p
+_lib.dgs_strerror.restype = ctypes.c_char_p
+_lib.dgs_strerror.argtypes = [_int]
+_lib.dgs_spmm_csr_workspace_bytes.restype = _sz
+_lib.dgs_spmm_csr_workspace_bytes.argtypes = [_int, _i64, _i64, _i64]
+_lib.dgs_spmm_csr_f32.restype = _int
+_lib.dgs_spmm_csr_f32.argtypes = [_int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _sz, _vp]
+_lib.dgs_spmm_csr_mask_f32.restype = _int
+_lib.dgs_spmm_csr_mask_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+_lib.dgs_sddmm_csr_f32.restype = _int
+_lib.dgs_sddmm_csr_f32.argtypes = [_int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]
+_lib.dgs_sddmm_csr_mask_f32.restype = _int
+_lib.dgs_sddmm_csr_mask_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+_lib.dgs_csr2csc_workspace_bytes.restype = _sz
+_lib.dgs_csr2csc_workspace_bytes.argtypes = [_i64, _i64, _i64]
+_lib.dgs_csr2csc_i32.restype = _int
+_lib.dgs_csr2csc_i32.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
+_lib.dgs_gather_rows_f32.restype = _int
+_lib.dgs_gather_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
+_lib.dgs_scatter_add_rows_f32.restype = _int
+_lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
+
+EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
+           'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
+           'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'gespmmCsrSpMM', 'spmm_cuda',
+           'spmm_cuda_no_edge_value', 'sddmm_cuda_csr']
+
+
+def version() -> int:
+    return int(_lib.dgs_version())
+
+
+def arch() -> str:
+    return _lib.dgs_arch().decode()
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f'dgsparse: {what} failed: {_lib.dgs_strerror(rc).decode()} ({rc})')
+
+
+def _need_gpu(*ts) -> torch.device:
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('dgsparse: this build has only the HIP (gfx950) back end - tensors must live on a GPU '
+                               f'(got a {t.device} tensor); there is no CPU fallback')
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f'dgsparse: tensors on different devices ({dev} vs {t.device})')
+    return dev
+
+
+def _i32(t, name):
+    if t.dtype != torch.int32 or t.dim() != 1:
+        raise TypeError(f'dgsparse: {name} must be a 1-D int32 tensor (got {t.dtype}, dim {t.dim()})')
+    return t.contiguous()
+
+
+def _f32mat(t, name):
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise TypeError(f'dgsparse: {name} must be a 2-D float32 tensor (got {t.dtype}, dim {t.dim()})')
+    return t.contiguous()
+
+
+def _f32vec(t, name, n):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise TypeError(f'dgsparse: {name} must be float32 (got {t.dtype})')
+    t = t.contiguous().view(-1)
+    if t.numel() != n:
+        raise ValueError(f'dgsparse: {name} has {t.numel()} elements, expected {n}')
+    return t
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def spmm(reduce_op, rowptr, col, values, dense, algorithm=0, want_E=None):
+    """C = reduce(A (*) dense).  Returns (C, E) with E=None unless max/min (or want_E)."""
+    dev = _need_gpu(rowptr, col, values, dense)
+    rowptr = _i32(rowptr, 'rowptr')
+    col = _i32(col, 'col')
+    dense = _f32mat(dense, 'dense')
+    M, nnz, (K, N) = rowptr.numel() - 1, col.numel(), dense.shape
+    if M < 0:
+        raise ValueError('dgsparse: rowptr must have at least one element')
+    values = _f32vec(values, 'values', nnz)
+    arg = reduce_op in (MAX, MIN) if want_E is None else want_E
+    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    E = torch.empty((M, N), dtype=torch.int32, device=dev) if arg else None
+    with torch.cuda.device(dev):
+        wsb = _lib.dgs_spmm_csr_workspace_bytes(reduce_op, M, N, nnz)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        _check(_lib.dgs_spmm_csr_f32(reduce_op, M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(dense), _p(out),
+                                     _p(E), int(algorithm), _p(ws), wsb, _stream(dev)), 'spmm')
+    return out, E
+
+
+def spmm_mask(ptr, idx, values, grad, E, n_out=None):
+    """out[j,:] = sum_p [E[idx[p],:]==j] * values[p] * grad[idx[p],:] over the CSC arrays (ptr, idx)."""
+    dev = _need_gpu(ptr, idx, values, grad, E)
+    ptr = _i32(ptr, 'ptr')
+    idx = _i32(idx, 'idx')
+    grad = _f32mat(grad, 'grad')
+    if E.dtype != torch.int32 or E.shape != grad.shape:
+        raise TypeError('dgsparse: E must be int32 with the shape of grad')
+    E = E.contiguous()
+    Mo, nnz, (Mi, N) = ptr.numel() - 1, idx.numel(), grad.shape
+    values = _f32vec(values, 'values', nnz)
+    rows = Mo if n_out is None else max(int(n_out), Mo)
+    out = torch.empty((rows, N), dtype=torch.float32, device=dev)
+    if rows > Mo:
+        out[Mo:].zero_()
+    with torch.cuda.device(dev):
+        _check(_lib.dgs_spmm_csr_mask_f32(Mo, Mi, N, nnz, _p(ptr), _p(idx), _p(values), _p(grad), _p(E), _p(out),
+                                          _stream(dev)), 'spmm_mask')
+    return out
+
+
+def sddmm(rowptr, col, D1, D2, reduce_op=SUM, E=None):
+    """out[e] = <D1[row(e)], D2[col(e)]> (mean-scaled / arg-masked variants)."""
+    dev = _need_gpu(rowptr, col, D1, D2, E)
+    rowptr = _i32(rowptr, 'rowptr')
+    col = _i32(col, 'col')
+    D1 = _f32mat(D1, 'D1')
+    D2 = _f32mat(D2, 'D2')
+    M, nnz, F = rowptr.numel() - 1, col.numel(), D1.shape[1]
+    if D2.shape[1] != F or D1.shape[0] < M:
+        raise ValueError(f'dgsparse: sddmm shape mismatch D1 {tuple(D1.shape)} D2 {tuple(D2.shape)} rows {M}')
+    out = torch.empty(nnz, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        if E is not None:
+            if E.dtype != torch.int32 or E.shape != D1.shape:
+                raise TypeError('dgsparse: E must be int32 with the shape of D1')
+            _check(_lib.dgs_sddmm_csr_mask_f32(M, D2.shape[0], F, nnz, _p(rowptr), _p(col), _p(D1), _p(D2),
+                                               _p(E.contiguous()), _p(out), _stream(dev)), 'sddmm_mask')
+        else:
+            _check(_lib.dgs_sddmm_csr_f32(reduce_op, M, D2.shape[0], F, nnz, _p(rowptr), _p(col), _p(D1), _p(D2),
+                                          _p(out), _stream(dev)), 'sddmm')
+    return out
+
+
+def csr2csc(rowptr, col, values, n_cols, want_perm=True):
+    """Stable transpose.  Returns (colptr[n_cols+1], row[nnz], cscval[nnz] | None, perm[nnz] | None)."""
+    dev = _need_gpu(rowptr, col, values)
+    rowptr = _i32(rowptr, 'rowptr')
+    col = _i32(col, 'col')
+    M, nnz = rowptr.numel() - 1, col.numel()
+    values = _f32vec(values, 'values', nnz)
+    colptr = torch.empty(n_cols + 1, dtype=torch.int32, device=dev)
+    row = torch.empty(nnz, dtype=torch.int32, device=dev)
+    cscval = torch.empty(nnz, dtype=torch.float32, device=dev) if values is not None else None
+    perm = torch.empty(nnz, dtype=torch.int32, device=dev) if want_perm else None
+    with torch.cuda.device(dev):
+        wsb = _lib.dgs_csr2csc_workspace_bytes(M, n_cols, nnz)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _check(_lib.dgs_csr2csc_i32(M, n_cols, nnz, _p(rowptr), _p(col), _p(values), _p(colptr), _p(row), _p(cscval),
+                                    _p(perm), _p(ws), wsb, _stream(dev)), 'csr2csc')
+    return colptr, row, cscval, perm
+
+
+def gather_rows(src, ids):
+    dev = _need_gpu(src, ids)
+    src = _f32mat(src, 'src')
+    ids = _i32(ids, 'ids')
+    out = torch.empty((ids.numel(), src.shape[1]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(_lib.dgs_gather_rows_f32(ids.numel(), src.shape[1], _p(ids), _p(src), _p(out), _stream(dev)), 'gather')
+    return out
+
+
+def scatter_add_rows(dst, ids, src):
+    dev = _need_gpu(dst, ids, src)
+    assert dst.is_contiguous() and dst.dtype == torch.float32
+    src = _f32mat(src, 'src')
+    ids = _i32(ids, 'ids')
+    with torch.cuda.device(dev):
+        _check(_lib.dgs_scatter_add_rows_f32(ids.numel(), src.shape[1], _p(ids), _p(src), _p(dst), _stream(dev)),
+               'scatter_add')
+    return dst

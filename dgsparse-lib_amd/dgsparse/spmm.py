@@ -1,0 +1,35 @@
+"""``spmm_sum / spmm_mean / spmm_max / spmm_min`` -- the reference's public operators
+(dgsparse/spmm.py:5,31,57,83): same names, same ``(sparse, dense, algorithm)`` arguments, same unpacking of
+the SparseTensor into the nine-argument ``torch.ops.dgsparse_spmm.*`` call."""
+import torch
+
+from .tensor import SparseTensor
+
+
+def _call(op, sparse: SparseTensor, dense: torch.Tensor, algorithm) -> torch.Tensor:
+    st = sparse.storage
+    if dense.dim() != 2 or dense.shape[0] < st.sparse_sizes[1]:
+        raise ValueError(f'dgsparse: dense has shape {tuple(dense.shape)} but the sparse tensor references '
+                         f'{st.sparse_sizes[1]} columns')
+    return op(st.rowptr(), st.col(), st.values(), st.colptr(), st.row(), st.csr2csc(), dense, sparse.has_value,
+              algorithm)
+
+
+def spmm_sum(sparse: SparseTensor, dense: torch.Tensor, algorithm=0) -> torch.Tensor:
+    r"""Sparse @ dense with sum reduction (algorithm is a tuning hint; all values give the same result)."""
+    return _call(torch.ops.dgsparse_spmm.spmm_sum, sparse, dense, algorithm)
+
+
+def spmm_mean(sparse: SparseTensor, dense: torch.Tensor, algorithm=0) -> torch.Tensor:
+    r"""Sparse @ dense with mean reduction over each row's stored entries."""
+    return _call(torch.ops.dgsparse_spmm.spmm_mean, sparse, dense, algorithm)
+
+
+def spmm_max(sparse: SparseTensor, dense: torch.Tensor, algorithm=0) -> torch.Tensor:
+    r"""Row-wise max of val * dense[col]; empty rows give 0."""
+    return _call(torch.ops.dgsparse_spmm.spmm_max, sparse, dense, algorithm)
+
+
+def spmm_min(sparse: SparseTensor, dense: torch.Tensor, algorithm=0) -> torch.Tensor:
+    r"""Row-wise min of val * dense[col]; empty rows give 0."""
+    return _call(torch.ops.dgsparse_spmm.spmm_min, sparse, dense, algorithm)

@@ -1,0 +1,157 @@
+/*
+ * dgsparse_hip.h -- C ABI of the MI355X (gfx950) CSR SpMM / SDDMM / csr2csc hot path.
+ *
+ * This is the drop-in boundary: plain pointers + sizes + a hipStream_t, no torch types, no allocation,
+ * no host synchronisation, no global state.  All pointers are DEVICE pointers on the device that owns
+ * `stream`.  Every entry point returns 0 on success or a negative DGS_E* code (never exit()s, unlike
+ * the reference's checkCudaError, include/cuda/cuda_util.cuh:116-134).  Launches are asynchronous on
+ * `stream` (the reference launches on the legacy default stream, src/cuda/spmm_cuda.cu:57).
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the dgSPARSE-Lib tree).
+ * Index type int32, value type float32, dense operands row-major - as the reference.
+ */
+#ifndef DGSPARSE_HIP_H
+#define DGSPARSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* hipStream_t without dragging hip headers into C callers (cgo / JNI / ctypes). */
+typedef void *dgsStream_t;
+
+/* include/gspmm.h:13  enum REDUCEOP { SUM, MAX, MIN, MEAN } */
+enum { DGS_SUM = 0, DGS_MAX = 1, DGS_MIN = 2, DGS_MEAN = 3 };
+
+enum {
+  DGS_OK = 0,
+  DGS_EINVAL = -1,    /* bad enum / negative size / null required pointer */
+  DGS_EWORKSPACE = -2,/* workspace too small (query dgs_*_workspace_bytes) */
+  DGS_ELAUNCH = -3,   /* hipGetLastError() after a launch was not hipSuccess */
+  DGS_ERANGE = -4     /* sizes exceed int32 indexing of the CSR arrays */
+};
+
+/* ABI version (major*1000+minor) and the gfx target the kernels were compiled for. */
+int dgs_version(void);
+const char *dgs_arch(void);
+const char *dgs_strerror(int code);
+
+/*
+ * CSR SpMM with reduce:  C[r,:] = reduce_{p in row r} val[p] * B[col[p],:]
+ * Replaces: spmm_cuda() host launcher, src/cuda/spmm_cuda.cu:14-253, i.e. kernel
+ *           csrspmm_seqreduce_rowbalance_kernel, include/cuda/spmm_cuda.cuh:10-55 ("algorithm 0",
+ *           the numerical contract; algorithms 1/2 are other schedules of the same maths, and every
+ *           `algorithm` value returns the algorithm-0 result here - it is kept as a tuning hint).
+ *   rowptr[M+1], col[nnz] int32; val[nnz] or NULL (= weight 1, cuda_util.cuh:140-146);
+ *   B[K,N], C[M,N] row-major fp32;
+ *   E[M,N] int32 arg COLUMN ids (-1 for empty rows), REQUIRED for MAX/MIN, optional (may be NULL) else.
+ *   MAX/MIN: values and E bit-exact vs algorithm 0 (first occurrence in CSR order wins ties; identities
+ *   (float)INT_MIN / (float)INT_MAX; empty row -> 0 / -1).  SUM/MEAN: sequential CSR order for rows up
+ *   to the split threshold (bit-exact vs an fmaf chain), fixed-tree split above it (<=1e-5 rel).
+ *   workspace: dgs_spmm_csr_workspace_bytes() bytes, 256-B aligned; contents undefined on entry/exit.
+ */
+size_t dgs_spmm_csr_workspace_bytes(int reduce_op, int64_t M, int64_t N, int64_t nnz);
+int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz,
+                     const int32_t *rowptr, const int32_t *col, const float *val, const float *B,
+                     float *C, int32_t *E, int algorithm, void *workspace, size_t workspace_bytes,
+                     dgsStream_t stream);
+
+/*
+ * Masked SpMM = backward of max/min w.r.t. the dense operand, run on the CSC arrays of A:
+ *   out[j,:] = sum_{p in [ptr[j],ptr[j+1])} [E[idx[p],:] == j] * val[p] * G[idx[p],:]
+ * Replaces: spmm_cuda_with_mask(), src/cuda/spmm_cuda.cu:255-303 /
+ *           csrspmm_seqreduce_rowbalance_with_mask_kernel, include/cuda/spmm_cuda.cuh:400-433
+ *           (the formula, not that kernel's stale-variable bug).
+ *   ptr[Mout+1], idx[nnz] = colptr,row of A; val = values permuted to CSC order or NULL;
+ *   G[Min,N] grad of the SpMM output; E[Min,N] saved arg ids; out[Mout,N].
+ */
+int dgs_spmm_csr_mask_f32(int64_t Mout, int64_t Min, int64_t N, int64_t nnz, const int32_t *ptr,
+                          const int32_t *idx, const float *val, const float *G, const int32_t *E,
+                          float *out, dgsStream_t stream);
+
+/*
+ * CSR SDDMM:  out[e] = sum_k D1[row(e),k] * D2[col(e),k]   (/ deg(row(e)) when reduce_op==DGS_MEAN)
+ * Replaces: sddmm_cuda_csr(), src/cuda/spmm_cuda.cu:331-361 / sddmmCSR{2,1}Scale<REDUCE>,
+ *           include/cuda/sddmm_cuda.cuh:222-401; and the standalone C entry sddmm_cuda_csr,
+ *           src/sddmm/sddmm.h:10.   D1[M,F], D2[K,F], out[nnz].  reduce_op in {DGS_SUM, DGS_MEAN}.
+ */
+int dgs_sddmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t F, int64_t nnz,
+                      const int32_t *rowptr, const int32_t *col, const float *D1, const float *D2,
+                      float *out, dgsStream_t stream);
+
+/*
+ * Masked SDDMM = backward of max/min w.r.t. the sparse values:
+ *   out[e] = sum_k [E[row(e),k] == col(e)] * D1[row(e),k] * D2[col(e),k]
+ * Replaces: sddmm_cuda_csr_with_mask(), src/cuda/spmm_cuda.cu:363-382 / sddmmCSR1Scale_with_mask,
+ *           include/cuda/sddmm_cuda.cuh:403-507.
+ */
+int dgs_sddmm_csr_mask_f32(int64_t M, int64_t K, int64_t F, int64_t nnz, const int32_t *rowptr,
+                           const int32_t *col, const float *D1, const float *D2, const int32_t *E,
+                           float *out, dgsStream_t stream);
+
+/*
+ * Stable CSR -> CSC transpose (integer permutation; exact for any nnz < 2^31, unlike the reference's
+ * float-encoded permutation, dgsparse/storage.py:164-169, which breaks at nnz >= 2^24).
+ * Replaces: csr2csc_cuda(), src/cuda/spmm_cuda.cu:384-414 / csr2cscKernel (cusparseCsr2cscEx2),
+ *           include/cuda/csr2csc.cuh:8-26.
+ *   colptr[Kcols+1], row[nnz] outputs; cscval[nnz] (needs val) and perm[nnz] (CSC slot -> CSR slot)
+ *   are optional outputs (NULL to skip).  Rectangular matrices supported (reference: square only).
+ */
+size_t dgs_csr2csc_workspace_bytes(int64_t M, int64_t Kcols, int64_t nnz);
+int dgs_csr2csc_i32(int64_t M, int64_t Kcols, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                    const float *val, int32_t *colptr, int32_t *row, float *cscval, int32_t *perm,
+                    void *workspace, size_t workspace_bytes, dgsStream_t stream);
+
+/* Row gather / scatter-add used by the multi-GPU halo exchange (new; no reference counterpart):
+ *   gather:      dst[i,:] = src[ids[i],:]          scatter_add: dst[ids[i],:] += src[i,:] (ids unique) */
+int dgs_gather_rows_f32(int64_t n_ids, int64_t N, const int32_t *ids, const float *src, float *dst,
+                        dgsStream_t stream);
+int dgs_scatter_add_rows_f32(int64_t n_ids, int64_t N, const int32_t *ids, const float *src, float *dst,
+                             dgsStream_t stream);
+
+/* ---- GE-SpMM / SDDMM compatibility entry points (same names and argument order as the reference's
+ *      standalone C libraries; default stream, void return) ------------------------------------- */
+
+/* src/ge-spmm/gespmm.h:9-16 */
+struct SpMatCsrDescr_t {
+  int nrow;
+  int ncol;
+  int nnz;
+  int *indptr;
+  int *indices;
+  float *data;
+};
+/* src/ge-spmm/gespmm.h:18-30 (only row-major "transpose_BC=true" layouts exist here) */
+enum gespmmAlg_t {
+  GESPMM_ALG_SEQREDUCE_ROWBALANCE = 0,
+  GESPMM_ALG_PARREDUCE_ROWBALANCE,
+  GESPMM_ALG_SEQREDUCE_NNZBALANCE,
+  GESPMM_ALG_PARREDUCE_NNZBALANCE,
+  GESPMM_ALG_SEQREDUCE_ROWBALANCE_NON_TRANSPOSE,
+  GESPMM_ALG_PARREDUCE_ROWBALANCE_NON_TRANSPOSE,
+  GESPMM_ALG_SEQREDUCE_NNZBALANCE_NON_TRANSPOSE,
+  GESPMM_ALG_PARREDUCE_NNZBALANCE_NON_TRANSPOSE,
+  GESPMM_ALG_ROWCACHING_ROWBALANCE,
+  GESPMM_ALG_ROWCACHING_NNZBALANCE,
+  GESPMM_ALG_DEFAULT
+};
+/* src/ge-spmm/gespmm.h:32 */
+void gespmmCsrSpMM(const struct SpMatCsrDescr_t spmatA, float *B, const int N, float *C,
+                   bool transpose_BC, enum gespmmAlg_t alg);
+/* src/ge-spmm/gespmm.h:38-41 */
+void spmm_cuda(int nrowA, int ncolB, int *rowptr, int *colind, float *values, float *dense, float *out);
+void spmm_cuda_no_edge_value(int nrowA, int ncolB, int *rowptr, int *colind, float *values, float *dense,
+                             float *out);
+/* src/sddmm/sddmm.h:10 */
+void sddmm_cuda_csr(int m, int k, int nnz, int *rowptr, int *colind, float *D1, float *D2, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGSPARSE_HIP_H */

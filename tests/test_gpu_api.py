@@ -1,0 +1,97 @@
+"""GPU tests of the drop-in Python surface (dgsparse.spmm_* / SparseTensor / torch.ops.dgsparse_spmm.*),
+written the way the reference's own tests are (test/test_spmm.py: forward_check / backward_check against
+torch.sparse.mm, here via the committed golden vectors generated from exactly that call)."""
+import numpy as np
+import pytest
+import torch
+
+from util import assert_bitexact, assert_close, load_golden
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-5, 2e-6
+
+
+def make(g, requires_grad=True, has_value=True):
+    import dgsparse
+    M, K = g['rowptr'].shape[0] - 1, int(g['K'])
+    tcsr = torch.sparse_csr_tensor(torch.from_numpy(g['rowptr']), torch.from_numpy(g['col']),
+                                   torch.from_numpy(g['val']), size=(M, K), device='cuda')
+    dcsr = dgsparse.SparseTensor.from_torch_sparse_csr_tensor(tcsr.clone().detach(), has_value,
+                                                              requires_grad=requires_grad)
+    X = torch.from_numpy(g['X']).cuda().requires_grad_(requires_grad)
+    return dcsr, X
+
+
+GRAD_CASES = ['tiny_nodup_grad_N3', 'tiny_nodup_grad_N32', 'cora_shaped_N32', 'small_weighted_N64',
+              'powerlaw4k_signed_grad_N8']
+
+
+@pytest.mark.parametrize('name', GRAD_CASES)
+@pytest.mark.parametrize('reduce', ['sum', 'mean', 'max'])
+def test_forward_backward_like_reference_tests(name, reduce):
+    import dgsparse
+    g = load_golden(name)
+    if f'{reduce}_dX' not in g:
+        pytest.skip('no golden grads for this reduce')
+    dcsr, X = make(g)
+    fn = {'sum': dgsparse.spmm_sum, 'mean': dgsparse.spmm_mean, 'max': dgsparse.spmm_max}[reduce]
+    out = fn(dcsr, X, 0)
+    if reduce == 'max':
+        assert_bitexact(out.detach().cpu().numpy(), g['max_out'])
+    else:
+        assert_close(out.detach().cpu().numpy(), g[f'{reduce}_out'], RTOL, ATOL)
+    out.backward(torch.from_numpy(g['G']).cuda())
+    assert_close(X.grad.cpu().numpy(), g[f'{reduce}_dX'], RTOL, ATOL, 'dX')
+    assert_close(dcsr.storage._values.grad.cpu().numpy(), g[f'{reduce}_dA'], RTOL, ATOL, 'dA')
+
+
+def test_algorithm_is_a_hint_and_has_value_false():
+    import dgsparse
+    g = load_golden('cora_shaped_N32')
+    dcsr, X = make(g, requires_grad=False)
+    ref = dgsparse.spmm_sum(dcsr, X, 0)
+    for alg in (1, 2, 3, 7):
+        assert torch.equal(dgsparse.spmm_sum(dcsr, X, alg), ref)
+    d2, _ = make(g, requires_grad=False, has_value=False)  # weights are ones in this fixture
+    assert torch.equal(dgsparse.spmm_sum(d2, X, 0), ref)
+    out = torch.ops.dgsparse_spmm.spmm_min(dcsr.storage.rowptr(), dcsr.storage.col(), dcsr.storage.values(),
+                                           dcsr.storage.colptr(), dcsr.storage.row(), dcsr.storage.csr2csc(), X,
+                                           True, 0)
+    assert_bitexact(out.cpu().numpy(), g['min_out'])
+
+
+def test_storage_csc_and_csr2csc_entry():
+    import dgsparse
+    g = load_golden('small_weighted_N64')
+    dcsr, _ = make(g, requires_grad=False)
+    st = dcsr.storage
+    assert st.sparse_sizes == (g['rowptr'].shape[0] - 1, int(g['col'].max()) + 1)
+    ncol = st.sparse_sizes[1]
+    assert_bitexact(st.colptr().cpu().numpy(), g['csc_colptr'][:ncol + 1])
+    assert_bitexact(st.row().cpu().numpy(), g['csc_row'])
+    assert_bitexact(st.csr2csc().cpu().numpy(), g['csc_perm'])
+    colptr, row, vals = dgsparse.csr2csc(dcsr)  # reference test/test_csr2csr.py:40-49
+    assert_bitexact(row.cpu().numpy(), g['csc_row'])
+    assert_bitexact(vals.cpu().numpy(), g['csc_val'])
+
+
+def test_sddmm_public_entry():
+    import dgsparse
+    g = load_golden('cora_shaped_N32')
+    dcsr, X = make(g, requires_grad=False)
+    out = dgsparse.sddmm(dcsr, torch.from_numpy(g['D1']).cuda(), X)
+    assert_close(out.cpu().numpy(), g['ref_sddmm_out'], RTOL, ATOL)
+
+
+def test_errors_are_loud():
+    import dgsparse
+    g = load_golden('tiny_N32')
+    dcsr, X = make(g, requires_grad=False)
+    with pytest.raises(ValueError):
+        dgsparse.spmm_sum(dcsr, X[:2], 0)  # fewer dense rows than referenced columns
+    with pytest.raises(TypeError):
+        dgsparse.spmm_sum(dcsr, X.double(), 0)
+    with pytest.raises(RuntimeError):
+        dgsparse.spmm_sum(dcsr, X.cpu(), 0)  # no CPU fallback
+    with pytest.raises(AssertionError):
+        dgsparse.SparseTensor(rowptr=dcsr.storage.rowptr().long(), col=dcsr.storage.col())

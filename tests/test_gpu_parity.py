@@ -1,0 +1,179 @@
+"""GPU parity tests proper: the HIP path, called THROUGH THE C ABI (dgsparse._capi -> libdgsparse_hip.so),
+against the CPU oracle on the same seeded inputs and against the committed golden vectors.
+
+Bars (north_star): max/min values AND arg column ids E bit-exact; sum/mean within 1e-5 relative (and, for
+rows processed sequentially, bit-exact against the oracle's fmaf chain); csr2csc exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from bench import graphgen
+from util import assert_bitexact, assert_close, golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 2e-6  # sum/mean tolerance of north_star (atol covers cancellation in signed cases)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope='module')
+def capi():
+    from dgsparse import _capi
+    return _capi
+
+
+def run_spmm(capi, reduce, rp, col, val, X):
+    op = oracle.REDUCE[reduce]
+    C, E = capi.spmm(op, dev(rp), dev(col), None if val is None else dev(val), dev(X))
+    torch.cuda.synchronize()
+    return C.cpu().numpy(), None if E is None else E.cpu().numpy()
+
+
+CASES = golden_names()
+
+
+@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('reduce', ['sum', 'mean', 'max', 'min'])
+def test_spmm_golden(capi, name, reduce):
+    g = load_golden(name)
+    C, E = run_spmm(capi, reduce, g['rowptr'], g['col'], g['val'], g['X'])
+    Co, Eo = oracle.spmm(reduce, g['rowptr'], g['col'], g['val'], g['X'], fma=True)
+    if reduce in ('max', 'min'):
+        assert_bitexact(C, g[f'{reduce}_out'], 'values vs torch golden')
+        assert_bitexact(E, g[f'{reduce}_E'], 'E vs torch golden')
+        assert_bitexact(C, Co, 'values vs oracle')
+        assert_bitexact(E, Eo, 'E vs oracle')
+    else:
+        assert_close(C, g[f'{reduce}_out'], RTOL, ATOL, 'vs torch golden')
+        assert_close(C, Co, RTOL, ATOL, 'vs oracle')
+        if reduce == 'sum':
+            assert_close(C, g['ref_sum_out'], RTOL, ATOL, 'vs spmm_reference_host')
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_sddmm_and_csr2csc_golden(capi, name):
+    g = load_golden(name)
+    rp, col, val = dev(g['rowptr']), dev(g['col']), dev(g['val'])
+    out = capi.sddmm(rp, col, dev(g['D1']), dev(g['X'])).cpu().numpy()
+    assert_close(out, g['ref_sddmm_out'], RTOL, ATOL, 'sddmm vs sddmm_reference_host')
+    outm = capi.sddmm(rp, col, dev(g['D1']), dev(g['X']), oracle.MEAN).cpu().numpy()
+    assert_close(outm, oracle.sddmm(g['rowptr'], g['col'], g['D1'], g['X'], 'mean'), RTOL, ATOL, 'sddmm mean')
+    colptr, row, cscval, perm = capi.csr2csc(rp, col, val, int(g['K']))
+    assert_bitexact(colptr.cpu().numpy(), g['csc_colptr'])
+    assert_bitexact(row.cpu().numpy(), g['csc_row'])
+    assert_bitexact(cscval.cpu().numpy(), g['csc_val'])
+    assert_bitexact(perm.cpu().numpy(), g['csc_perm'])
+
+
+def test_csr2csc_reference_fixture(capi):
+    g = load_golden('p2p_gnutella31_csr2csc')
+    colptr, row, cscval, _ = capi.csr2csc(dev(g['rowptr']), dev(g['col']), dev(g['val']), int(g['shape'][1]))
+    assert_bitexact(colptr.cpu().numpy(), g['csc_colptr'])
+    assert_bitexact(row.cpu().numpy(), g['csc_row'])
+    assert_bitexact(cscval.cpu().numpy(), g['csc_val'])
+
+
+def rand_graph(M, K, nnz, seed, dup=False, unsorted=False):
+    rp, col, _ = graphgen.powerlaw_csr(M, nnz, K=K, alpha=2.2, dmax=max(2, min(K, M // 2)), seed=seed, dedup=not dup)
+    if unsorted:
+        rng = np.random.default_rng(seed)
+        col = col.copy()
+        for r in range(0, M, 3):
+            rng.shuffle(col[rp[r]:rp[r + 1]])
+    return rp, col
+
+
+@pytest.mark.parametrize('N', [1, 2, 3, 4, 7, 16, 31, 32, 33, 64, 100, 128, 129, 256, 260, 512, 516])
+@pytest.mark.parametrize('has_value', [True, False])
+def test_spmm_shapes_vs_oracle(capi, N, has_value):
+    M, K = 517, 389
+    rp, col = rand_graph(M, K, 6000, seed=N, dup=(N % 2 == 0), unsorted=(N % 3 == 0))
+    val = graphgen.weights(col.shape[0], 'tied' if N % 2 else 'signed', N) if has_value else None
+    X = (np.random.default_rng(N).integers(-2, 3, (K, N)) / 4).astype(np.float32)  # ties + signs
+    for reduce in ('sum', 'mean', 'max', 'min'):
+        C, E = run_spmm(capi, reduce, rp, col, val, X)
+        Co, Eo = oracle.spmm(reduce, rp, col, val, X, fma=True)
+        if reduce in ('max', 'min'):
+            assert_bitexact(C, Co, f'{reduce} values N={N}')
+            assert_bitexact(E, Eo, f'{reduce} E N={N}')
+        else:
+            assert_close(C, Co, RTOL, ATOL, f'{reduce} N={N}')
+
+
+@pytest.mark.parametrize('N', [3, 32, 64, 132])
+def test_backward_kernels_vs_oracle(capi, N):
+    M, K = 300, 411
+    rp, col = rand_graph(M, K, 5000, seed=100 + N)
+    val = graphgen.weights(col.shape[0], 'signed', N)
+    X = graphgen.features(K, N, N) - np.float32(0.5)
+    G = graphgen.features(M, N, N + 1) - np.float32(0.5)
+    colptr, row, tval, perm = oracle.csr2csc(rp, col, val, K)
+    for reduce in ('max', 'min'):
+        _, E = oracle.spmm(reduce, rp, col, val, X)
+        gX = capi.spmm_mask(dev(colptr), dev(row), dev(tval), dev(G), dev(E)).cpu().numpy()
+        assert_close(gX, oracle.spmm_mask(colptr, row, tval, G, E, fma=True), RTOL, ATOL, 'spmm_mask')
+        gW = capi.sddmm(dev(rp), dev(col), dev(G), dev(X), E=dev(E)).cpu().numpy()
+        assert_close(gW, oracle.sddmm_mask(rp, col, G, X, E, fma=True), RTOL, ATOL, 'sddmm_mask')
+
+
+def test_unaligned_views_and_scalar_path(capi):
+    """A dense operand whose base is not 16-B aligned must take the scalar (V=1) path and stay correct."""
+    M, K, N = 200, 150, 64
+    rp, col = rand_graph(M, K, 2500, seed=5)
+    X = graphgen.features(K, N, 5)
+    flat = torch.zeros(K * N + 1, dtype=torch.float32, device='cuda')
+    flat[1:] = dev(X).view(-1)
+    Xd = flat[1:].view(K, N)
+    assert Xd.data_ptr() % 16 != 0
+    C, E = capi.spmm(oracle.MAX, dev(rp), dev(col), None, Xd)
+    Co, Eo = oracle.spmm('max', rp, col, None, X)
+    assert_bitexact(C.cpu().numpy(), Co)
+    assert_bitexact(E.cpu().numpy(), Eo)
+
+
+def test_empty_and_degenerate(capi):
+    rp0 = torch.zeros(1, dtype=torch.int32, device='cuda')
+    c0 = torch.zeros(0, dtype=torch.int32, device='cuda')
+    X = torch.rand(5, 8, device='cuda')
+    C, _ = capi.spmm(oracle.SUM, rp0, c0, None, X)
+    assert C.shape == (0, 8)
+    rp = torch.zeros(4, dtype=torch.int32, device='cuda')  # 3 rows, all empty
+    for op in (oracle.SUM, oracle.MEAN, oracle.MAX, oracle.MIN):
+        C, E = capi.spmm(op, rp, c0, None, X)
+        assert torch.count_nonzero(C) == 0
+        if E is not None:
+            assert bool((E == -1).all())
+    assert capi.sddmm(rp, c0, torch.rand(3, 8, device='cuda'), X).numel() == 0
+    colptr, row, _, perm = capi.csr2csc(rp, c0, None, 5)
+    assert colptr.tolist() == [0] * 6 and row.numel() == 0
+
+
+def test_nan_identity_semantics(capi):
+    rp = np.array([0, 3, 4], np.int32)
+    col = np.array([0, 1, 2, 0], np.int32)
+    X = np.array([[1.0] * 4, [np.nan] * 4, [5.0] * 4], np.float32)
+    for reduce in ('max', 'min'):
+        C, E = run_spmm(capi, reduce, rp, col, None, X)
+        Co, Eo = oracle.spmm(reduce, rp, col, None, X)
+        assert_bitexact(C, Co, reduce)
+        assert_bitexact(E, Eo, reduce)
+    X2 = np.full((3, 4), -3e9, np.float32)
+    C, E = run_spmm(capi, 'max', rp, col, None, X2)
+    assert C[0, 0] == np.float32(-2147483648.0) and E[0, 0] == -1
+
+
+def test_gather_scatter_rows(capi):
+    src = torch.rand(1000, 64, device='cuda')
+    ids = torch.randperm(1000, device='cuda')[:300].int()
+    g = capi.gather_rows(src, ids)
+    assert torch.equal(g, src[ids.long()])
+    dst = torch.rand(1000, 64, device='cuda')
+    ref = dst.clone()
+    ref[ids.long()] += g
+    capi.scatter_add_rows(dst, ids, g)
+    assert torch.equal(dst, ref)
