@@ -1,19 +1,407 @@
-// spmm.hip -- CSR SpMM (sum / max / min / mean + arg ids) for gfx950, row-group schedule.
+// spmm.hip -- CSR SpMM (sum / max / min / mean + arg ids) for gfx950.
 //
-// Replaces csrspmm_seqreduce_rowbalance_kernel (reference include/cuda/spmm_cuda.cuh:10-55), which maps
-// ONE THREAD to one (row, feature) and re-reads col/val through L1 once per feature.  Here a row is owned
-// by a group of G lanes of a wave64, each lane holding V=4 consecutive features, so one B row is fetched
-// by G coalesced dwordx4 loads (N=64: 16 lanes x 16 B = one 256-B row; a wave gathers 4 rows per load
-// instruction) and every accumulator still sees its products in CSR order - i.e. the result is the
-// algorithm-0 result bit for bit (fmaf chain for sum/mean, single-rounded products for max/min).
+// Replaces csrspmm_seqreduce_rowbalance_kernel (reference include/cuda/spmm_cuda.cuh:10-55), which maps ONE
+// THREAD to one (row, feature), re-reads col/val through L1 once per feature and walks every row - however
+// long - sequentially in one thread.  Power-law graphs (a few rows with 10^4..10^5 nnz) stall that schedule,
+// and short rows pay three dependent memory latencies (rowptr -> col -> B) per handful of nnz.
 //
-// Kernel in this file:
-//   spmm_rowgroup_seq<G,V,OP,HAS_VAL>   one group per row, sequential over the row's nnz, 4-deep unroll so
-//                                       that 4 independent B-row gathers are in flight per group.
+// Schedule used here (all wave64, plan-free: the only state is a caller-provided scratch workspace):
+//
+//   feature mapping   a row of the output is owned by a GROUP of G lanes, each lane holding V=4 consecutive
+//                     features: one B row = G coalesced dwordx4 loads (N=64: 16 lanes x 16 B = one 256-B row,
+//                     so a single wave-level load instruction gathers 4 different B rows = 1 KiB).
+//
+//   K1 spmm_rows      one wave per block of 64 consecutive rows.  rowptr for the block is read with one
+//                     coalesced load, the (col,val) pairs of runs of SHORT rows (len <= T1) are staged into a
+//                     per-wave LDS tile with coalesced loads, then each group walks its rows reading (col,val)
+//                     by LDS broadcast and issuing up to U independent B-row gathers at a time.  Accumulation
+//                     per feature is sequential in CSR order => bit-identical to algorithm 0 (fmaf chain for
+//                     sum/mean, single-rounded products + first-wins ties for max/min).
+//                     LONG rows (len > T1) are not processed here: they are cut into units of <= CH nnz that
+//                     are appended to a unit table in the workspace (one atomicAdd per long row).
+//
+//   K2 spmm_units     one wave per unit: 64 (col,val) pairs at a time through LDS, the NG=64/G groups take
+//                     interleaved nnz (G lanes still read one coalesced B row), partial results are combined
+//                     across groups with a fixed xor-butterfly (ds_bpermute / DPP).  Single-unit rows write C
+//                     directly; multi-unit rows write a partial row to the workspace.
+//
+//   K3 spmm_combine   one wave per multi-unit row: folds its partials in unit order (fixed tree).
+//
+//   Determinism: atomics only allocate table slots; every value is produced by a fixed reduction tree, so
+//   results are run-to-run identical.  max/min carry (value, column id, position) so that the first occurrence
+//   in CSR order wins ties under any split => values and E bit-exact vs algorithm 0 for every row length.
+//   sum/mean: sequential (bit-exact) for rows <= T1, fixed-tree (<= 1e-5 rel) above.
+//
+//   spmm_rowgroup_seq (the first, plan-free single-kernel version) is kept for tiny problems.
 #include "dgs_common.h"
 
 namespace dgs {
 
+// ---------------------------------------------------------------------------------------------------------
+// tuning constants
+constexpr int kT1 = 32;        // rows up to this many nnz are handled sequentially by one group in K1
+constexpr int kCap = 512;      // (col,val) pairs per wave LDS tile in K1  (4 KiB per wave, 16 KiB per block)
+constexpr int kRowsPerWave = 64;
+constexpr int kU1 = 4;         // independent B-row gathers in flight per lane, K1 (short rows)
+constexpr int kU = 8;          // same for K2 (units)
+
+struct SpmmWs {       // workspace header (zeroed every call with one 16-byte memset)
+  int n_units;        // K1 -> K2: number of unit descriptors
+  int n_multi;        // K1 -> K3: number of multi-unit rows
+  int n_pslots;       // partial-row slots handed out
+  int pad;
+};
+
+struct WsLayout {
+  size_t off_units, off_multi, off_part, off_parte, total;
+  int64_t max_units, max_multi, max_pslots;
+  int ch;
+};
+
+// Unit length CH: 256 nnz by default, grown for huge inputs so that the partial-row scratch stays bounded.
+static inline int unit_len(int64_t nnz) {
+  int ch = 256;
+  while ((nnz / ch) > 65536 && ch < (1 << 20)) ch <<= 1;
+  return ch;
+}
+
+static inline WsLayout ws_layout(int reduce_op, int64_t N, int64_t nnz) {
+  auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+  WsLayout L;
+  L.ch = unit_len(nnz);
+  L.max_multi = nnz / L.ch + 1;                      // rows longer than CH
+  L.max_pslots = 2 * (nnz / L.ch) + 2;               // sum over those rows of ceil(len/CH) <= nnz/CH + #rows
+  L.max_units = nnz / kT1 + nnz / L.ch + 2;          // #long rows < nnz/T1, plus the extra units
+  L.off_units = up(sizeof(SpmmWs));
+  L.off_multi = L.off_units + up((size_t)L.max_units * sizeof(int4));
+  L.off_part = L.off_multi + up((size_t)L.max_multi * sizeof(int4));
+  const size_t prow = up((size_t)L.max_pslots * N * sizeof(float));
+  L.off_parte = L.off_part + prow;
+  const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
+  L.total = L.off_parte + (arg ? prow : 0) + 256;
+  return L;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// cross-group combine helpers (all 64 lanes active)
+template <int OP>
+__device__ __forceinline__ bool arg_better(float mine, int mypos, float other, int opos) {
+  // "other" replaces "mine" iff it wins under first-occurrence-wins semantics of algorithm 0
+  if constexpr (OP == DGS_MAX) return (mine < other) || (mine == other && opos < mypos);
+  return (mine > other) || (mine == other && opos < mypos);
+}
+
+template <int G, int V, int OP>
+__device__ __forceinline__ void cross_group_reduce(float (&acc)[V], int (&ei)[V], int (&ep)[V]) {
+  constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
+#pragma unroll
+  for (int m = G; m < 64; m <<= 1) {
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+      const float o = __shfl_xor(acc[v], m, 64);
+      if constexpr (ARG) {
+        const int oi = __shfl_xor(ei[v], m, 64);
+        const int op = __shfl_xor(ep[v], m, 64);
+        if (arg_better<OP>(acc[v], ep[v], o, op)) {
+          acc[v] = o;
+          ei[v] = oi;
+          ep[v] = op;
+        }
+      } else {
+        acc[v] += o;  // IEEE addition is commutative: both partners compute the same sum => fixed tree
+      }
+    }
+  }
+}
+
+// position-tracking reduction step for the split path (pos = CSR position, or unit index in K3)
+template <int OP>
+__device__ __forceinline__ void reduce_step_pos(float &res, int &eidx, int &epos, float w, float x, int c, int pos) {
+  if constexpr (OP == DGS_MAX) {
+    const float t = w * x;
+    if (res < t) {
+      eidx = c;
+      epos = pos;
+    }
+    res = (res < t) ? t : res;
+  } else if constexpr (OP == DGS_MIN) {
+    const float t = w * x;
+    if (res > t) {
+      eidx = c;
+      epos = pos;
+    }
+    res = (res < t) ? res : t;
+  } else {
+    res = __builtin_fmaf(w, x, res);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K1: short rows, LDS-staged (col,val), sequential per group.  Also builds the unit table for long rows.
+template <int G, int V, int OP, bool HAS_VAL>
+__global__ __launch_bounds__(kBlock) void spmm_rows(int M, int N, int ch, const int *__restrict__ rowptr,
+                                                    const int *__restrict__ col, const float *__restrict__ val,
+                                                    const float *__restrict__ B, float *__restrict__ C,
+                                                    int *__restrict__ E, SpmmWs *__restrict__ hdr,
+                                                    int4 *__restrict__ units, int4 *__restrict__ multi) {
+  constexpr int NG = kWave / G;
+  constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
+  __shared__ int2 s_tile[kBlock / kWave][kCap];
+  __shared__ int2 s_rows[kBlock / kWave][kRowsPerWave];
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane / G, l = lane % G;
+  const int r0 = (blockIdx.x * (kBlock / kWave) + wave) * kRowsPerWave;
+  if (r0 >= M) return;  // wave-uniform
+  int2 *tile = s_tile[wave];
+  int2 *rows = s_rows[wave];
+  const int nrows = min(kRowsPerWave, M - r0);
+  const int f0 = (blockIdx.y * G + l) * V;
+  const bool fl = f0 < N;
+
+  int s_i = 0, e_i = 0;
+  if (lane < nrows) {
+    s_i = rowptr[r0 + lane];
+    e_i = rowptr[r0 + lane + 1];
+  }
+  const int len_i = e_i - s_i;
+  const bool long_i = len_i > kT1;
+  rows[lane] = make_int2(s_i, e_i);
+
+  // long rows -> unit table (feature tile 0 only; slots come from atomics, values never do)
+  if (long_i && blockIdx.y == 0) {
+    const int nch = (len_i + ch - 1) / ch;
+    const int ubase = atomicAdd(&hdr->n_units, nch);
+    int pbase = -1;
+    if (nch > 1) {
+      pbase = atomicAdd(&hdr->n_pslots, nch);
+      const int mi = atomicAdd(&hdr->n_multi, 1);
+      multi[mi] = make_int4(r0 + lane, pbase, nch, 0);
+    }
+    for (int k = 0; k < nch; k++) units[ubase + k] = make_int4(r0 + lane, k, pbase, nch);
+  }
+
+  int a = 0;
+  while (a < nrows) {
+    const int s_a = __shfl(s_i, a, 64);
+    // first row >= a that cannot join the batch: long, or it would overflow the LDS tile, or past the end
+    const unsigned long long brk =
+        __ballot(lane >= a && (long_i || (e_i - s_a) > kCap || lane >= nrows));
+    const int b = brk ? (__ffsll((long long)brk) - 1) : kRowsPerWave;
+    if (b == a) {  // row a itself is long: skipped here
+      a++;
+      continue;
+    }
+    const int e_b = __shfl(e_i, b - 1, 64);
+    const int cnt = e_b - s_a;
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < cnt; t += kWave) {
+      const int c = col[s_a + t];
+      const float w = HAS_VAL ? val[s_a + t] : 1.0f;
+      tile[t] = make_int2(c, __float_as_int(w));
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    for (int r = a + g; r < b; r += NG) {
+      const int2 se = rows[r];
+      float acc[V];
+      int ei[V];
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        acc[v] = reduce_init<OP>();
+        ei[v] = -1;
+      }
+      const int rs = se.x - s_a, re = se.y - s_a;  // tile-relative
+      for (int p = rs; p < re; p += kU1) {
+        int c[kU1];
+        float w[kU1];
+        float x[kU1][V];
+#pragma unroll
+        for (int u = 0; u < kU1; u++) {
+          if (p + u < re) {
+            const int2 cv = tile[p + u];
+            c[u] = cv.x;
+            w[u] = __int_as_float(cv.y);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kU1; u++)
+          if (p + u < re && fl) load_vec<V>(B + (int64_t)c[u] * N + f0, x[u]);
+#pragma unroll
+        for (int u = 0; u < kU1; u++)
+          if (p + u < re && fl) {
+#pragma unroll
+            for (int v = 0; v < V; v++) reduce_step<OP>(acc[v], ei[v], w[u], x[u][v], c[u]);
+          }
+      }
+      if (re > rs) {
+        if constexpr (OP == DGS_MEAN) {
+          const float d = (float)(re - rs);
+#pragma unroll
+          for (int v = 0; v < V; v++) acc[v] /= d;
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < V; v++) acc[v] = 0.0f;
+      }
+      if (fl) {
+        store_vec<V>(C + (int64_t)(r0 + r) * N + f0, acc);
+        if constexpr (ARG) store_vec<V>(E + (int64_t)(r0 + r) * N + f0, ei);
+      }
+    }
+    a = b;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2: one wave per unit (<= ch nnz of a long row).
+template <int G, int V, int OP, bool HAS_VAL>
+__global__ __launch_bounds__(kBlock) void spmm_units(int N, int ch, const int *__restrict__ rowptr,
+                                                     const int *__restrict__ col, const float *__restrict__ val,
+                                                     const float *__restrict__ B, float *__restrict__ C,
+                                                     int *__restrict__ E, const SpmmWs *__restrict__ hdr,
+                                                     const int4 *__restrict__ units, float *__restrict__ part,
+                                                     int *__restrict__ parte) {
+  constexpr int NG = kWave / G;
+  constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
+  __shared__ int2 s_tile[kBlock / kWave][kWave];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane / G, l = lane % G;
+  int2 *tile = s_tile[wave];
+  const int f0 = (blockIdx.y * G + l) * V;
+  const bool fl = f0 < N;
+  const int n_units = hdr->n_units;
+  const int wstride = gridDim.x * (kBlock / kWave);
+
+  for (int u = blockIdx.x * (kBlock / kWave) + wave; u < n_units; u += wstride) {
+    const int4 d = units[u];  // {row, unit index in row, partial slot base, units in row}
+    const int rs = rowptr[d.x], re = rowptr[d.x + 1];
+    const int p0 = rs + d.y * ch;
+    const int p1 = min(p0 + ch, re);
+    float acc[V];
+    int ei[V], ep[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+      acc[v] = reduce_init<OP>();
+      ei[v] = -1;
+      ep[v] = INT_MAX;
+    }
+    for (int t0 = p0; t0 < p1; t0 += kWave) {
+      const int cnt = min(kWave, p1 - t0);
+      __builtin_amdgcn_wave_barrier();
+      if (lane < cnt) {
+        const int c = col[t0 + lane];
+        const float w = HAS_VAL ? val[t0 + lane] : 1.0f;
+        tile[lane] = make_int2(c, __float_as_int(w));
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int j = g; j < cnt; j += NG * kU) {
+        int c[kU];
+        float w[kU];
+        float x[kU][V];
+#pragma unroll
+        for (int q = 0; q < kU; q++) {
+          if (j + q * NG < cnt) {
+            const int2 cv = tile[j + q * NG];
+            c[q] = cv.x;
+            w[q] = __int_as_float(cv.y);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < kU; q++)
+          if (j + q * NG < cnt && fl) load_vec<V>(B + (int64_t)c[q] * N + f0, x[q]);
+#pragma unroll
+        for (int q = 0; q < kU; q++)
+          if (j + q * NG < cnt && fl) {
+#pragma unroll
+            for (int v = 0; v < V; v++)
+              reduce_step_pos<OP>(acc[v], ei[v], ep[v], w[q], x[q][v], c[q], t0 + j + q * NG);
+          }
+      }
+    }
+    cross_group_reduce<G, V, OP>(acc, ei, ep);
+    if (g == 0 && fl) {
+      if (d.w == 1) {  // the whole row was this unit: final result
+        if constexpr (OP == DGS_MEAN) {
+          const float dg = (float)(re - rs);
+#pragma unroll
+          for (int v = 0; v < V; v++) acc[v] /= dg;
+        }
+        store_vec<V>(C + (int64_t)d.x * N + f0, acc);
+        if constexpr (ARG) store_vec<V>(E + (int64_t)d.x * N + f0, ei);
+      } else {
+        const int64_t slot = (int64_t)(d.z + d.y) * N + f0;
+        store_vec<V>(part + slot, acc);
+        if constexpr (ARG) store_vec<V>(parte + slot, ei);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K3: one wave per multi-unit row, folds the partial rows in unit order.
+template <int G, int V, int OP>
+__global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restrict__ rowptr,
+                                                       float *__restrict__ C, int *__restrict__ E,
+                                                       const SpmmWs *__restrict__ hdr, const int4 *__restrict__ multi,
+                                                       const float *__restrict__ part,
+                                                       const int *__restrict__ parte) {
+  constexpr int NG = kWave / G;
+  constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane / G, l = lane % G;
+  const int f0 = (blockIdx.y * G + l) * V;
+  const bool fl = f0 < N;
+  const int n_multi = hdr->n_multi;
+  const int wstride = gridDim.x * (kBlock / kWave);
+  for (int i = blockIdx.x * (kBlock / kWave) + wave; i < n_multi; i += wstride) {
+    const int4 d = multi[i];  // {row, partial slot base, units, -}
+    float acc[V];
+    int ei[V], ep[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+      acc[v] = reduce_init<OP>();
+      ei[v] = -1;
+      ep[v] = INT_MAX;
+    }
+    for (int k = g; k < d.z; k += NG) {
+      if (fl) {
+        float x[V];
+        const int64_t slot = (int64_t)(d.y + k) * N + f0;
+        load_vec<V>(part + slot, x);
+        if constexpr (ARG) {
+          int xe[V];
+          load_vec<V>(parte + slot, xe);
+#pragma unroll
+          for (int v = 0; v < V; v++) {
+            // a partial that never improved on the identity carries E=-1 and must not win
+            if (xe[v] != -1 && arg_better<OP>(acc[v], ep[v], x[v], k)) {
+              acc[v] = x[v];
+              ei[v] = xe[v];
+              ep[v] = k;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int v = 0; v < V; v++) acc[v] += x[v];
+        }
+      }
+    }
+    cross_group_reduce<G, V, OP>(acc, ei, ep);
+    if (g == 0 && fl) {
+      if constexpr (OP == DGS_MEAN) {
+        const float dg = (float)(rowptr[d.x + 1] - rowptr[d.x]);
+#pragma unroll
+        for (int v = 0; v < V; v++) acc[v] /= dg;
+      }
+      store_vec<V>(C + (int64_t)d.x * N + f0, acc);
+      if constexpr (ARG) store_vec<V>(E + (int64_t)d.x * N + f0, ei);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Single-kernel version (no workspace): one group per row, sequential, 4-deep unroll.  Used for tiny inputs.
 template <int G, int V, int OP, bool HAS_VAL>
 __global__ __launch_bounds__(kBlock) void spmm_rowgroup_seq(int M, int N, const int *__restrict__ rowptr,
                                                             const int *__restrict__ col,
@@ -76,75 +464,97 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup_seq(int M, int N, const 
   if constexpr (ARG) store_vec<V>(E + row * N + f0, ei);
 }
 
-template <int G, int V, int OP>
-static int launch_seq(int64_t M, int64_t N, const int *rowptr, const int *col, const float *val, const float *B,
-                      float *C, int *E, int tiles, hipStream_t st) {
-  const dim3 grid((unsigned)((M + (kBlock / G) - 1) / (kBlock / G)), (unsigned)tiles);
-  if (val)
-    hipLaunchKernelGGL((spmm_rowgroup_seq<G, V, OP, true>), grid, dim3(kBlock), 0, st, (int)M, (int)N, rowptr, col,
-                       val, B, C, E);
-  else
-    hipLaunchKernelGGL((spmm_rowgroup_seq<G, V, OP, false>), grid, dim3(kBlock), 0, st, (int)M, (int)N, rowptr, col,
-                       val, B, C, E);
+// ---------------------------------------------------------------------------------------------------------
+struct SpmmArgs {
+  int64_t M, N, nnz;
+  const int *rowptr, *col;
+  const float *val, *B;
+  float *C;
+  int *E;
+  int tiles;
+  void *ws;  // nullptr => single-kernel path
+  hipStream_t st;
+  int reduce_op;
+};
+
+template <int G, int V, int OP, bool HAS_VAL>
+static int launch_all(const SpmmArgs &a) {
+  if (!a.ws) {
+    const dim3 grid((unsigned)((a.M + (kBlock / G) - 1) / (kBlock / G)), (unsigned)a.tiles);
+    hipLaunchKernelGGL((spmm_rowgroup_seq<G, V, OP, HAS_VAL>), grid, dim3(kBlock), 0, a.st, (int)a.M, (int)a.N,
+                       a.rowptr, a.col, a.val, a.B, a.C, a.E);
+    return check_launch();
+  }
+  const WsLayout L = ws_layout(a.reduce_op, a.N, a.nnz);
+  char *w = static_cast<char *>(a.ws);
+  SpmmWs *hdr = reinterpret_cast<SpmmWs *>(w);
+  int4 *units = reinterpret_cast<int4 *>(w + L.off_units);
+  int4 *multi = reinterpret_cast<int4 *>(w + L.off_multi);
+  float *part = reinterpret_cast<float *>(w + L.off_part);
+  int *parte = reinterpret_cast<int *>(w + L.off_parte);
+  if (hipMemsetAsync(hdr, 0, sizeof(SpmmWs), a.st) != hipSuccess) return DGS_ELAUNCH;
+  const int rows_per_block = (kBlock / kWave) * kRowsPerWave;
+  const dim3 g1((unsigned)((a.M + rows_per_block - 1) / rows_per_block), (unsigned)a.tiles);
+  hipLaunchKernelGGL((spmm_rows<G, V, OP, HAS_VAL>), g1, dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, L.ch, a.rowptr,
+                     a.col, a.val, a.B, a.C, a.E, hdr, units, multi);
+  // unit / multi counts live on the device: launch a bounded persistent grid, waves stride over the tables
+  const int64_t ub = (L.max_units + 3) / 4;
+  const dim3 g2((unsigned)(ub < 4096 ? (ub < 1 ? 1 : ub) : 4096), (unsigned)a.tiles);
+  hipLaunchKernelGGL((spmm_units<G, V, OP, HAS_VAL>), g2, dim3(kBlock), 0, a.st, (int)a.N, L.ch, a.rowptr, a.col,
+                     a.val, a.B, a.C, a.E, hdr, units, part, parte);
+  const int64_t mb = (L.max_multi + 3) / 4;
+  const dim3 g3((unsigned)(mb < 1024 ? (mb < 1 ? 1 : mb) : 1024), (unsigned)a.tiles);
+  hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.C, a.E, hdr, multi,
+                     part, parte);
   return check_launch();
 }
 
+template <int G, int V, int OP>
+static int dispatch_val(const SpmmArgs &a) {
+  return a.val ? launch_all<G, V, OP, true>(a) : launch_all<G, V, OP, false>(a);
+}
+
 template <int G, int V>
-static int dispatch_op(int op, int64_t M, int64_t N, const int *rowptr, const int *col, const float *val,
-                       const float *B, float *C, int *E, int tiles, hipStream_t st) {
-  switch (op) {
-    case DGS_SUM:
-      return launch_seq<G, V, DGS_SUM>(M, N, rowptr, col, val, B, C, E, tiles, st);
-    case DGS_MAX:
-      return launch_seq<G, V, DGS_MAX>(M, N, rowptr, col, val, B, C, E, tiles, st);
-    case DGS_MIN:
-      return launch_seq<G, V, DGS_MIN>(M, N, rowptr, col, val, B, C, E, tiles, st);
-    case DGS_MEAN:
-      return launch_seq<G, V, DGS_MEAN>(M, N, rowptr, col, val, B, C, E, tiles, st);
+static int dispatch_op(const SpmmArgs &a) {
+  switch (a.reduce_op) {
+    case DGS_SUM: return dispatch_val<G, V, DGS_SUM>(a);
+    case DGS_MAX: return dispatch_val<G, V, DGS_MAX>(a);
+    case DGS_MIN: return dispatch_val<G, V, DGS_MIN>(a);
+    case DGS_MEAN: return dispatch_val<G, V, DGS_MEAN>(a);
   }
   return DGS_EINVAL;
 }
 
 template <int V>
-static int dispatch_g(int G, int op, int64_t M, int64_t N, const int *rowptr, const int *col, const float *val,
-                      const float *B, float *C, int *E, int tiles, hipStream_t st) {
+static int dispatch_g(int G, const SpmmArgs &a) {
   switch (G) {
-    case 1:
-      return dispatch_op<1, V>(op, M, N, rowptr, col, val, B, C, E, tiles, st);
-    case 2:
-      return dispatch_op<2, V>(op, M, N, rowptr, col, val, B, C, E, tiles, st);
-    case 4:
-      return dispatch_op<4, V>(op, M, N, rowptr, col, val, B, C, E, tiles, st);
-    case 8:
-      return dispatch_op<8, V>(op, M, N, rowptr, col, val, B, C, E, tiles, st);
-    case 16:
-      return dispatch_op<16, V>(op, M, N, rowptr, col, val, B, C, E, tiles, st);
-    case 32:
-      return dispatch_op<32, V>(op, M, N, rowptr, col, val, B, C, E, tiles, st);
-    case 64:
-      return dispatch_op<64, V>(op, M, N, rowptr, col, val, B, C, E, tiles, st);
+    case 1: return dispatch_op<1, V>(a);
+    case 2: return dispatch_op<2, V>(a);
+    case 4: return dispatch_op<4, V>(a);
+    case 8: return dispatch_op<8, V>(a);
+    case 16: return dispatch_op<16, V>(a);
+    case 32: return dispatch_op<32, V>(a);
+    case 64: return dispatch_op<64, V>(a);
   }
   return DGS_EINVAL;
 }
+
+// Inputs this small finish in a few microseconds in the single kernel; three launches would only add latency.
+static inline bool tiny_problem(int64_t M, int64_t nnz) { return nnz <= 4096 && M <= 4096; }
 
 }  // namespace dgs
 
 using namespace dgs;
 
 extern "C" size_t dgs_spmm_csr_workspace_bytes(int reduce_op, int64_t M, int64_t N, int64_t nnz) {
-  (void)reduce_op;
-  (void)M;
-  (void)N;
-  (void)nnz;
-  return 0;
+  if (M <= 0 || N <= 0 || nnz <= 0 || tiny_problem(M, nnz)) return 0;
+  return ws_layout(reduce_op, N, nnz).total;
 }
 
 extern "C" int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,
                                 const int32_t *col, const float *val, const float *B, float *C, int32_t *E,
                                 int algorithm, void *workspace, size_t workspace_bytes, dgsStream_t stream) {
   (void)algorithm;  // every algorithm id returns the algorithm-0 result
-  (void)workspace;
-  (void)workspace_bytes;
   if (reduce_op < DGS_SUM || reduce_op > DGS_MEAN || M < 0 || K < 0 || N < 0 || nnz < 0) return DGS_EINVAL;
   if (M >= INT32_MAX || K >= INT32_MAX || N >= INT32_MAX || nnz >= INT32_MAX) return DGS_ERANGE;
   const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
@@ -154,8 +564,12 @@ extern "C" int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, 
   if (E && !arg) {  // the reference leaves E = -1 for sum/mean (Eidx is never updated)
     if (hipMemsetAsync(E, 0xFF, (size_t)M * N * sizeof(int32_t), st) != hipSuccess) return DGS_ELAUNCH;
   }
-  const bool al = is_aligned16(B) && is_aligned16(C) && (!arg || is_aligned16(E));
+  const size_t need = dgs_spmm_csr_workspace_bytes(reduce_op, M, N, nnz);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return DGS_EWORKSPACE;
+  const bool al = is_aligned16(B) && is_aligned16(C) && (!arg || is_aligned16(E)) &&
+                  (need == 0 || is_aligned16(workspace));
   const FeatMap fm = feat_map(N, al);
-  if (fm.V == 4) return dispatch_g<4>(fm.G, reduce_op, M, N, rowptr, col, val, B, C, E, fm.tiles, st);
-  return dispatch_g<1>(fm.G, reduce_op, M, N, rowptr, col, val, B, C, E, fm.tiles, st);
+  SpmmArgs a{M, N, nnz, rowptr, col, val, B, C, arg ? E : nullptr, fm.tiles, need ? workspace : nullptr, st, reduce_op};
+  if (fm.V == 4) return dispatch_g<4>(fm.G, a);
+  return dispatch_g<1>(fm.G, a);
 }

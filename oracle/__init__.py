@@ -102,6 +102,21 @@ def spmm(reduce, rowptr, col, val, B, K=None, fma=False, threads=1):
     return C, E
 
 
+def spmm_sum_f64(rowptr, col, val, B, mean=False, absval=False):
+    """Exact-arithmetic yardstick (double accumulation) for sum/mean - see dgs_oracle.c."""
+    rowptr, prp = _i(rowptr)
+    col, pc = _i(col)
+    val, pv = _f(val)
+    B, pb = _f(B)
+    M, N = rowptr.shape[0] - 1, B.shape[1]
+    C = np.empty((M, N), np.float64)
+    f = lib().orc_spmm_sum_f64
+    f.argtypes = [ctypes.c_int, ctypes.c_int, _i64, _i64, _i32p, _i32p, _f32p, _f32p, ctypes.POINTER(ctypes.c_double)]
+    rc = f(int(mean), int(absval), M, N, prp, pc, pv, pb, C.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    assert rc == 0
+    return C
+
+
 def spmm_mask(colptr, row, tval, G, E, fma=False):
     """max/min backward w.r.t. dense, on the CSC arrays.  Returns gX[Kcols,N]."""
     colptr, p0 = _i(colptr)

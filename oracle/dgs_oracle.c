@@ -221,3 +221,27 @@ int orc_max_threads(void) {
   return 1;
 #endif
 }
+
+/*
+ * Exact-arithmetic yardstick for sum/mean (NOT a restatement of the reference): products and the running
+ * sum are carried in double (a float*float product is exact in double), result left in double.  Used by
+ * the tests to judge long rows, where the reference's own sequential fp32 chain (spmm_cuda.cuh:27-44) is
+ * itself more than 1e-5 away from the exact sum: a split (tree) summation must then be at least as close
+ * to the exact value as the sequential chain is.
+ */
+int orc_spmm_sum_f64(int mean, int absval, int64_t M, int64_t N, const int32_t *rowptr, const int32_t *col,
+                     const float *val, const float *B, double *C) {
+  for (int64_t r = 0; r < M; r++) {
+    const int64_t s = rowptr[r], e = rowptr[r + 1];
+    for (int64_t f = 0; f < N; f++) {
+      double acc = 0.0;
+      for (int64_t p = s; p < e; p++) {
+        const double t = (double)(val ? val[p] : 1.0f) * (double)B[(int64_t)col[p] * N + f];
+        acc += absval ? fabs(t) : t; /* absval: the condition scale sum|t| of the row */
+      }
+      if (mean && e > s) acc /= (double)(e - s);
+      C[r * N + f] = acc;
+    }
+  }
+  return 0;
+}
