@@ -83,6 +83,79 @@ __device__ __forceinline__ void store_vec(int *p, const int (&o)[V]) {
   }
 }
 
+// Stores the compiler does not count.  hipcc's s_waitcnt pass treats a wave with BOTH loads and stores pending
+// on vmcnt as "out of order" and drains with vmcnt(0), which collapses a rolling window of gathers as soon as a
+// row result is stored inside the loop.  An inline-asm store is invisible to that bookkeeping, so the loads keep
+// their counted vmcnt(N) waits.  Safe: the hardware counter then only over-counts (loads still retire in order
+// among themselves, so "counter <= N" still implies the needed load has landed), nothing ever reads these
+// addresses again in the kernel, and outstanding stores complete on their own at s_endpgm.
+// The trailing s_nop 1 keeps hipcc's next instruction from overwriting the data registers before the store
+// has read them (cdna_hip_programming.md 5.7 item 1).
+typedef float dgs_f4 __attribute__((ext_vector_type(4)));
+typedef int dgs_i4 __attribute__((ext_vector_type(4)));
+#ifndef DGS_NT
+#define DGS_NT 1
+#endif
+#if DGS_NT
+#define DGS_NT_SUFFIX " nt"
+#else
+#define DGS_NT_SUFFIX ""
+#endif
+// Streaming accesses (col/val/rowptr reads, C/E writes are touched once): non-temporal so that they do not
+// displace rows of the dense operand from the 4 MiB XCD L2, which is the only reuse the kernel has.
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T *p) {
+#if DGS_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <int V>
+__device__ __forceinline__ void store_vec_stream(float *p, const float (&o)[V]) {
+#if DGS_NT
+  if constexpr (V == 4) {
+    dgs_f4 d = {o[0], o[1], o[2], o[3]};
+    __builtin_nontemporal_store(d, reinterpret_cast<dgs_f4 *>(p));
+  } else {
+    __builtin_nontemporal_store(o[0], p);
+  }
+#else
+  store_vec<V>(p, o);
+#endif
+}
+template <int V>
+__device__ __forceinline__ void store_vec_stream(int *p, const int (&o)[V]) {
+#if DGS_NT
+  if constexpr (V == 4) {
+    dgs_i4 d = {o[0], o[1], o[2], o[3]};
+    __builtin_nontemporal_store(d, reinterpret_cast<dgs_i4 *>(p));
+  } else {
+    __builtin_nontemporal_store(o[0], p);
+  }
+#else
+  store_vec<V>(p, o);
+#endif
+}
+template <int V>
+__device__ __forceinline__ void store_vec_hidden(float *p, const float (&o)[V]) {
+  if constexpr (V == 4) {
+    dgs_f4 d = {o[0], o[1], o[2], o[3]};
+    asm volatile("global_store_dwordx4 %0, %1, off" DGS_NT_SUFFIX "\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+  } else {
+    asm volatile("global_store_dword %0, %1, off" DGS_NT_SUFFIX "\n\ts_nop 1" ::"v"(p), "v"(o[0]) : "memory");
+  }
+}
+template <int V>
+__device__ __forceinline__ void store_vec_hidden(int *p, const int (&o)[V]) {
+  if constexpr (V == 4) {
+    dgs_i4 d = {o[0], o[1], o[2], o[3]};
+    asm volatile("global_store_dwordx4 %0, %1, off" DGS_NT_SUFFIX "\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+  } else {
+    asm volatile("global_store_dword %0, %1, off" DGS_NT_SUFFIX "\n\ts_nop 1" ::"v"(p), "v"(o[0]) : "memory");
+  }
+}
+
 // Feature-dimension mapping shared by all row-group kernels: a row is covered by G lanes x V floats.
 struct FeatMap {
   int G;      // lanes per row group (power of two, <= 64)

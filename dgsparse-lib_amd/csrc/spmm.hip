@@ -39,10 +39,15 @@ namespace dgs {
 
 // ---------------------------------------------------------------------------------------------------------
 // tuning constants
-constexpr int kT1 = 32;        // rows up to this many nnz are handled sequentially by one group in K1
+constexpr int kT1 = 32;        // rows up to this many nnz are streamed sequentially by one group in K1
+constexpr int kT2 = 1024;      // rows up to this many nnz are reduced by one whole wave inside K1; longer rows are
+                               // cut into units for K2/K3 (few rows, so their table atomics do not serialise K1)
 constexpr int kCap = 512;      // (col,val) pairs per wave LDS tile in K1  (4 KiB per wave, 16 KiB per block)
 constexpr int kRowsPerWave = 64;
-constexpr int kU1 = 4;         // independent B-row gathers in flight per lane, K1 (short rows)
+#ifndef DGS_KU1
+#define DGS_KU1 4
+#endif
+constexpr int kU1 = DGS_KU1;   // independent B-row gathers in flight per lane, K1 (short rows)
 constexpr int kU = 8;          // same for K2 (units)
 
 struct SpmmWs {       // workspace header (zeroed every call with one 16-byte memset)
@@ -71,7 +76,7 @@ static inline WsLayout ws_layout(int reduce_op, int64_t N, int64_t nnz) {
   L.ch = unit_len(nnz);
   L.max_multi = nnz / L.ch + 1;                      // rows longer than CH
   L.max_pslots = 2 * (nnz / L.ch) + 2;               // sum over those rows of ceil(len/CH) <= nnz/CH + #rows
-  L.max_units = nnz / kT1 + nnz / L.ch + 2;          // #long rows < nnz/T1, plus the extra units
+  L.max_units = nnz / kT2 + nnz / L.ch + 2;          // #huge rows < nnz/T2, plus the extra units
   L.off_units = up(sizeof(SpmmWs));
   L.off_multi = L.off_units + up((size_t)L.max_units * sizeof(int4));
   L.off_part = L.off_multi + up((size_t)L.max_multi * sizeof(int4));
@@ -137,7 +142,56 @@ __device__ __forceinline__ void reduce_step_pos(float &res, int &eidx, int &epos
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K1: short rows, LDS-staged (col,val), sequential per group.  Also builds the unit table for long rows.
+// Wave-cooperative reduction of the nnz range [p0,p1) of one row: 64 (col,val) pairs at a time through the
+// wave's LDS tile, the NG groups take interleaved nnz (each B row is still one coalesced G-lane read), up to kU
+// gathers in flight per lane.  Leaves per-group partials in acc/ei/ep (combine with cross_group_reduce).
+template <int G, int V, int OP, bool HAS_VAL>
+__device__ __forceinline__ void coop_accumulate(int p0, int p1, int lane, int g, int f0, bool fl, int N,
+                                                const int *__restrict__ col, const float *__restrict__ val,
+                                                const float *__restrict__ B, int2 *tile, float (&acc)[V],
+                                                int (&ei)[V], int (&ep)[V]) {
+  constexpr int NG = kWave / G;
+  for (int t0 = p0; t0 < p1; t0 += kWave) {
+    const int cnt = min(kWave, p1 - t0);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < cnt) {
+      const int c = ld_stream(col + t0 + lane);
+      const float w = HAS_VAL ? ld_stream(val + t0 + lane) : 1.0f;
+      tile[lane] = make_int2(c, __float_as_int(w));
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int j = g; j < cnt; j += NG * kU) {
+      int c[kU];
+      float w[kU];
+      float x[kU][V];
+#pragma unroll
+      for (int q = 0; q < kU; q++) {
+        if (j + q * NG < cnt) {
+          const int2 cv = tile[j + q * NG];
+          c[q] = cv.x;
+          w[q] = __int_as_float(cv.y);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kU; q++)
+        if (j + q * NG < cnt && fl) load_vec<V>(B + (int64_t)c[q] * N + f0, x[q]);
+#pragma unroll
+      for (int q = 0; q < kU; q++)
+        if (j + q * NG < cnt && fl) {
+#pragma unroll
+          for (int v = 0; v < V; v++)
+            reduce_step_pos<OP>(acc[v], ei[v], ep[v], w[q], x[q][v], c[q], t0 + j + q * NG);
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K1: short rows.  Per wave: 64 consecutive rows; runs of short rows are staged into LDS as (col | row-end flag,
+// val) pairs; the run's nnz stream is cut into NG nnz-balanced, row-aligned pieces, one per group; each group
+// streams its piece U nnz at a time (U independent B-row gathers in flight, no per-row wait) and stores a row
+// of C whenever it meets a row-end flag.  Per-feature accumulation order = CSR order (bit-exact vs algorithm 0).
+// Also builds the unit table for long rows.
 template <int G, int V, int OP, bool HAS_VAL>
 __global__ __launch_bounds__(kBlock) void spmm_rows(int M, int N, int ch, const int *__restrict__ rowptr,
                                                     const int *__restrict__ col, const float *__restrict__ val,
@@ -147,14 +201,14 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(int M, int N, int ch, const 
   constexpr int NG = kWave / G;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
   __shared__ int2 s_tile[kBlock / kWave][kCap];
-  __shared__ int2 s_rows[kBlock / kWave][kRowsPerWave];
+  __shared__ int4 s_rows[kBlock / kWave][kRowsPerWave + 1];  // {start, end, next non-empty short row, -}
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane / G, l = lane % G;
   const int r0 = (blockIdx.x * (kBlock / kWave) + wave) * kRowsPerWave;
   if (r0 >= M) return;  // wave-uniform
   int2 *tile = s_tile[wave];
-  int2 *rows = s_rows[wave];
+  int4 *rows = s_rows[wave];
   const int nrows = min(kRowsPerWave, M - r0);
   const int f0 = (blockIdx.y * G + l) * V;
   const bool fl = f0 < N;
@@ -165,11 +219,42 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(int M, int N, int ch, const 
     e_i = rowptr[r0 + lane + 1];
   }
   const int len_i = e_i - s_i;
-  const bool long_i = len_i > kT1;
-  rows[lane] = make_int2(s_i, e_i);
+  const bool long_i = len_i > kT1;   // not streamed: medium (whole wave, below) or huge (unit table)
+  const bool huge_i = len_i > kT2;
+  const bool live_i = lane < nrows && len_i > 0 && !long_i;  // non-empty short row: produces output in the stream
+  {
+    // index of the next live row after this lane's row (64 = none)
+    const unsigned long long livemask = __ballot(live_i);
+    const unsigned long long above = (lane >= 63) ? 0ull : (livemask >> (lane + 1));
+    const int nxt = above ? (lane + 1 + (__ffsll((long long)above) - 1)) : kRowsPerWave;
+    rows[lane] = make_int4(s_i, e_i, nxt, 0);
+    // empty rows: 0 / E = -1 (spmm_cuda.cuh:49-51); NG rows per pass, one per group
+    unsigned long long em = __ballot(lane < nrows && len_i == 0);
+    while (em) {
+      int r = -1;
+      unsigned long long t = em;
+      for (int k = 0; k <= g && t; k++) {  // g-th set bit
+        r = __ffsll((long long)t) - 1;
+        t &= t - 1;
+        if (k < g) r = -1;
+      }
+      if (r >= 0 && fl) {
+        float z[V];
+        int m1[V];
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+          z[v] = 0.0f;
+          m1[v] = -1;
+        }
+        store_vec_stream<V>(C + (int64_t)(r0 + r) * N + f0, z);
+        if constexpr (ARG) store_vec_stream<V>(E + (int64_t)(r0 + r) * N + f0, m1);
+      }
+      for (int k = 0; k < NG && em; k++) em &= em - 1;  // drop the NG rows just written
+    }
+  }
 
-  // long rows -> unit table (feature tile 0 only; slots come from atomics, values never do)
-  if (long_i && blockIdx.y == 0) {
+  // huge rows -> unit table (feature tile 0 only; slots come from atomics, values never do)
+  if (huge_i && blockIdx.y == 0) {
     const int nch = (len_i + ch - 1) / ch;
     const int ubase = atomicAdd(&hdr->n_units, nch);
     int pbase = -1;
@@ -185,8 +270,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(int M, int N, int ch, const 
   while (a < nrows) {
     const int s_a = __shfl(s_i, a, 64);
     // first row >= a that cannot join the batch: long, or it would overflow the LDS tile, or past the end
-    const unsigned long long brk =
-        __ballot(lane >= a && (long_i || (e_i - s_a) > kCap || lane >= nrows));
+    const unsigned long long brk = __ballot(lane >= a && (long_i || (e_i - s_a) > kCap || lane >= nrows));
     const int b = brk ? (__ffsll((long long)brk) - 1) : kRowsPerWave;
     if (b == a) {  // row a itself is long: skipped here
       a++;
@@ -194,16 +278,50 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(int M, int N, int ch, const 
     }
     const int e_b = __shfl(e_i, b - 1, 64);
     const int cnt = e_b - s_a;
+    if (cnt == 0) {  // only empty rows in this run
+      a = b;
+      continue;
+    }
     __builtin_amdgcn_wave_barrier();
     for (int t = lane; t < cnt; t += kWave) {
-      const int c = col[s_a + t];
-      const float w = HAS_VAL ? val[s_a + t] : 1.0f;
+      const int c = ld_stream(col + s_a + t);
+      const float w = HAS_VAL ? ld_stream(val + s_a + t) : 1.0f;
       tile[t] = make_int2(c, __float_as_int(w));
     }
     __builtin_amdgcn_wave_barrier();
+    // row-end flag = sign bit of the column id of each live row's last nnz (column ids are < 2^31)
+    if (live_i && lane >= a && lane < b) tile[e_i - 1 - s_a].x |= (int)0x80000000;
+    __builtin_amdgcn_wave_barrier();
 
-    for (int r = a + g; r < b; r += NG) {
-      const int2 se = rows[r];
+    // piece of group g: rows [ra, rb) where boundary(k) = first row r in [a,b] with start_r - s_a >= k*cnt/NG
+    int ra, rb;
+    {
+      const int tgt0 = (int)(((long long)g * cnt) / NG), tgt1 = (int)(((long long)(g + 1) * cnt) / NG);
+      int lo = a, hi = b;  // first r in [a,b] with rows[r].x - s_a >= tgt0   (rows[b].x >= e_b by CSR monotonicity)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int sm = (mid < b) ? rows[mid].x : e_b;
+        if (sm - s_a < tgt0) lo = mid + 1; else hi = mid;
+      }
+      ra = lo;
+      lo = ra;
+      hi = b;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int sm = (mid < b) ? rows[mid].x : e_b;
+        if (sm - s_a < tgt1) lo = mid + 1; else hi = mid;
+      }
+      rb = (g == NG - 1) ? b : lo;
+    }
+    if (ra < rb) {
+      const int ps = rows[ra].x - s_a;
+      const int pe = ((rb < b) ? rows[rb].x : e_b) - s_a;
+      // first live row of the piece
+      int cur = ra;
+      {
+        const int4 q = rows[ra];
+        if (!(q.y > q.x)) cur = q.z;
+      }
       float acc[V];
       int ei[V];
 #pragma unroll
@@ -211,45 +329,80 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(int M, int N, int ch, const 
         acc[v] = reduce_init<OP>();
         ei[v] = -1;
       }
-      const int rs = se.x - s_a, re = se.y - s_a;  // tile-relative
-      for (int p = rs; p < re; p += kU1) {
-        int c[kU1];
-        float w[kU1];
-        float x[kU1][V];
+      // Rolling window of kU1 gathers: slot i always holds nnz (p+i); after it is consumed the slot is refilled
+      // with nnz (p+i+kU1).  Loads are unconditional (index clamped to the last nnz of the piece, feature lanes
+      // beyond N read feature 0) so the compiler emits counted s_waitcnt vmcnt(kU1-1) instead of draining.
+      const float *Bl = B + (fl ? f0 : 0);
+      const int last = pe - 1;
+      int2 cv[kU1];
+      float x[kU1][V];
+#pragma unroll
+      for (int u = 0; u < kU1; u++) {
+        cv[u] = tile[min(ps + u, last)];
+        load_vec<V>(Bl + (int64_t)(cv[u].x & 0x7fffffff) * N, x[u]);
+      }
+      for (int p = ps; p < pe; p += kU1) {
 #pragma unroll
         for (int u = 0; u < kU1; u++) {
-          if (p + u < re) {
-            const int2 cv = tile[p + u];
-            c[u] = cv.x;
-            w[u] = __int_as_float(cv.y);
+          const int2 cvu = cv[u];
+          if (p + u < pe) {
+            const int c = cvu.x & 0x7fffffff;
+            const float w = __int_as_float(cvu.y);
+#pragma unroll
+            for (int v = 0; v < V; v++) reduce_step<OP>(acc[v], ei[v], w, x[u][v], c);
+            if (cvu.x < 0) {  // last nnz of row `cur` (group-uniform)
+              const int4 q = rows[cur];
+              if constexpr (OP == DGS_MEAN) {
+                const float d = (float)(q.y - q.x);
+#pragma unroll
+                for (int v = 0; v < V; v++) acc[v] /= d;
+              }
+              if (fl) {
+                store_vec_hidden<V>(C + (int64_t)(r0 + cur) * N + f0, acc);
+                if constexpr (ARG) store_vec_hidden<V>(E + (int64_t)(r0 + cur) * N + f0, ei);
+              }
+#pragma unroll
+              for (int v = 0; v < V; v++) {
+                acc[v] = reduce_init<OP>();
+                ei[v] = -1;
+              }
+              cur = q.z;
+            }
           }
+          // refill the slot just consumed (same registers: no copies, so the waits stay counted)
+          cv[u] = tile[min(p + u + kU1, last)];
+          load_vec<V>(Bl + (int64_t)(cv[u].x & 0x7fffffff) * N, x[u]);
         }
-#pragma unroll
-        for (int u = 0; u < kU1; u++)
-          if (p + u < re && fl) load_vec<V>(B + (int64_t)c[u] * N + f0, x[u]);
-#pragma unroll
-        for (int u = 0; u < kU1; u++)
-          if (p + u < re && fl) {
-#pragma unroll
-            for (int v = 0; v < V; v++) reduce_step<OP>(acc[v], ei[v], w[u], x[u][v], c[u]);
-          }
-      }
-      if (re > rs) {
-        if constexpr (OP == DGS_MEAN) {
-          const float d = (float)(re - rs);
-#pragma unroll
-          for (int v = 0; v < V; v++) acc[v] /= d;
-        }
-      } else {
-#pragma unroll
-        for (int v = 0; v < V; v++) acc[v] = 0.0f;
-      }
-      if (fl) {
-        store_vec<V>(C + (int64_t)(r0 + r) * N + f0, acc);
-        if constexpr (ARG) store_vec<V>(E + (int64_t)(r0 + r) * N + f0, ei);
       }
     }
     a = b;
+  }
+
+  // medium rows (T1 < len <= T2): the whole wave reduces one row at a time, result written directly
+  unsigned long long med = __ballot(long_i && !huge_i);
+  while (med) {
+    const int r = __ffsll((long long)med) - 1;
+    med &= med - 1;
+    const int rs = __shfl(s_i, r, 64), re = __shfl(e_i, r, 64);
+    float acc[V];
+    int ei[V], ep[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+      acc[v] = reduce_init<OP>();
+      ei[v] = -1;
+      ep[v] = INT_MAX;
+    }
+    coop_accumulate<G, V, OP, HAS_VAL>(rs, re, lane, g, f0, fl, N, col, val, B, tile, acc, ei, ep);
+    cross_group_reduce<G, V, OP>(acc, ei, ep);
+    if (g == 0 && fl) {
+      if constexpr (OP == DGS_MEAN) {
+        const float dg = (float)(re - rs);
+#pragma unroll
+        for (int v = 0; v < V; v++) acc[v] /= dg;
+      }
+      store_vec_stream<V>(C + (int64_t)(r0 + r) * N + f0, acc);
+      if constexpr (ARG) store_vec_stream<V>(E + (int64_t)(r0 + r) * N + f0, ei);
+    }
   }
 }
 
@@ -262,7 +415,7 @@ __global__ __launch_bounds__(kBlock) void spmm_units(int N, int ch, const int *_
                                                      int *__restrict__ E, const SpmmWs *__restrict__ hdr,
                                                      const int4 *__restrict__ units, float *__restrict__ part,
                                                      int *__restrict__ parte) {
-  constexpr int NG = kWave / G;
+
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
   __shared__ int2 s_tile[kBlock / kWave][kWave];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -286,39 +439,7 @@ __global__ __launch_bounds__(kBlock) void spmm_units(int N, int ch, const int *_
       ei[v] = -1;
       ep[v] = INT_MAX;
     }
-    for (int t0 = p0; t0 < p1; t0 += kWave) {
-      const int cnt = min(kWave, p1 - t0);
-      __builtin_amdgcn_wave_barrier();
-      if (lane < cnt) {
-        const int c = col[t0 + lane];
-        const float w = HAS_VAL ? val[t0 + lane] : 1.0f;
-        tile[lane] = make_int2(c, __float_as_int(w));
-      }
-      __builtin_amdgcn_wave_barrier();
-      for (int j = g; j < cnt; j += NG * kU) {
-        int c[kU];
-        float w[kU];
-        float x[kU][V];
-#pragma unroll
-        for (int q = 0; q < kU; q++) {
-          if (j + q * NG < cnt) {
-            const int2 cv = tile[j + q * NG];
-            c[q] = cv.x;
-            w[q] = __int_as_float(cv.y);
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < kU; q++)
-          if (j + q * NG < cnt && fl) load_vec<V>(B + (int64_t)c[q] * N + f0, x[q]);
-#pragma unroll
-        for (int q = 0; q < kU; q++)
-          if (j + q * NG < cnt && fl) {
-#pragma unroll
-            for (int v = 0; v < V; v++)
-              reduce_step_pos<OP>(acc[v], ei[v], ep[v], w[q], x[q][v], c[q], t0 + j + q * NG);
-          }
-      }
-    }
+    coop_accumulate<G, V, OP, HAS_VAL>(p0, p1, lane, g, f0, fl, N, col, val, B, tile, acc, ei, ep);
     cross_group_reduce<G, V, OP>(acc, ei, ep);
     if (g == 0 && fl) {
       if (d.w == 1) {  // the whole row was this unit: final result
@@ -327,8 +448,8 @@ __global__ __launch_bounds__(kBlock) void spmm_units(int N, int ch, const int *_
 #pragma unroll
           for (int v = 0; v < V; v++) acc[v] /= dg;
         }
-        store_vec<V>(C + (int64_t)d.x * N + f0, acc);
-        if constexpr (ARG) store_vec<V>(E + (int64_t)d.x * N + f0, ei);
+        store_vec_stream<V>(C + (int64_t)d.x * N + f0, acc);
+        if constexpr (ARG) store_vec_stream<V>(E + (int64_t)d.x * N + f0, ei);
       } else {
         const int64_t slot = (int64_t)(d.z + d.y) * N + f0;
         store_vec<V>(part + slot, acc);
@@ -394,8 +515,8 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
 #pragma unroll
         for (int v = 0; v < V; v++) acc[v] /= dg;
       }
-      store_vec<V>(C + (int64_t)d.x * N + f0, acc);
-      if constexpr (ARG) store_vec<V>(E + (int64_t)d.x * N + f0, ei);
+      store_vec_stream<V>(C + (int64_t)d.x * N + f0, acc);
+      if constexpr (ARG) store_vec_stream<V>(E + (int64_t)d.x * N + f0, ei);
     }
   }
 }
