@@ -11,55 +11,68 @@
 //                     features: one B row = G coalesced dwordx4 loads (N=64: 16 lanes x 16 B = one 256-B row,
 //                     so a single wave-level load instruction gathers 4 different B rows = 1 KiB).
 //
-//   K1 spmm_rows      one wave per block of 64 consecutive rows.  rowptr for the block is read with one
-//                     coalesced load, the (col,val) pairs of runs of SHORT rows (len <= T1) are staged into a
-//                     per-wave LDS tile with coalesced loads, then each group walks its rows reading (col,val)
-//                     by LDS broadcast and issuing up to U independent B-row gathers at a time.  Accumulation
-//                     per feature is sequential in CSR order => bit-identical to algorithm 0 (fmaf chain for
-//                     sum/mean, single-rounded products + first-wins ties for max/min).
-//                     LONG rows (len > T1) are not processed here: they are cut into units of <= CH nnz that
-//                     are appended to a unit table in the workspace (one atomicAdd per long row).
+//   K0 spmm_classify  one pass over rowptr: every LONG row (len > T1) is cut into units of <= CH nnz, appended
+//                     to a unit table in the workspace (block-level scan + ONE atomicAdd per block).
 //
-//   K2 spmm_units     one wave per unit: 64 (col,val) pairs at a time through LDS, the NG=64/G groups take
-//                     interleaved nnz (G lanes still read one coalesced B row), partial results are combined
-//                     across groups with a fixed xor-butterfly (ds_bpermute / DPP).  Single-unit rows write C
-//                     directly; multi-unit rows write a partial row to the workspace.
+//   K1 spmm_fused     one launch, two kinds of blocks:
+//        unit blocks  persistent, stride over the unit table, one wave per unit: 64 (col,val) pairs at a time
+//                     through LDS, the NG=64/G groups take interleaved nnz (G lanes still read one coalesced B
+//                     row), up to 8 gathers in flight per lane, partials combined across groups by a fixed
+//                     xor-butterfly (ds_bpermute/DPP).  Single-unit rows write C directly, multi-unit rows write
+//                     a partial row (slot = unit id) to the workspace.
+//        row blocks   one wave per 64 consecutive rows.  rowptr comes in with one coalesced load, the (col,val)
+//                     pairs of runs of SHORT rows (len <= T1) are staged into a per-wave LDS tile with coalesced
+//                     non-temporal loads, the run's nnz stream is cut into NG nnz-balanced row-aligned pieces
+//                     and each group streams its piece through a rolling window of independent B-row gathers,
+//                     storing a row of C whenever it meets a row-end flag.  Per-feature accumulation order is
+//                     CSR order => bit-identical to algorithm 0 (fmaf chain for sum/mean, single-rounded
+//                     products + first-wins ties for max/min).
 //
-//   K3 spmm_combine   one wave per multi-unit row: folds its partials in unit order (fixed tree).
+//   K2 spmm_combine   folds the partial rows of every multi-unit row in unit order (fixed tree).
 //
 //   Determinism: atomics only allocate table slots; every value is produced by a fixed reduction tree, so
 //   results are run-to-run identical.  max/min carry (value, column id, position) so that the first occurrence
 //   in CSR order wins ties under any split => values and E bit-exact vs algorithm 0 for every row length.
 //   sum/mean: sequential (bit-exact) for rows <= T1, fixed-tree (<= 1e-5 rel) above.
 //
-//   spmm_rowgroup_seq (the first, plan-free single-kernel version) is kept for tiny problems.
+//   Measured on MI355X (profiles/): the fused kernel is bound by the L2-miss path (~6.5 TB/s of 128-B fabric
+//   reads at a ~30% L2 hit rate on the 1M x 1M power-law graph); see DESIGN.md for the ladder that led here.
+//
+//   spmm_rowgroup_seq (the first, single-kernel version) is kept for tiny problems.
 #include "dgs_common.h"
 
 namespace dgs {
 
 // ---------------------------------------------------------------------------------------------------------
 // tuning constants
-constexpr int kT1 = 32;        // rows up to this many nnz are streamed sequentially by one group in K1
-constexpr int kT2 = 1024;      // rows up to this many nnz are reduced by one whole wave inside K1; longer rows are
+#ifndef DGS_T1
+#define DGS_T1 64
+#endif
+#ifndef DGS_T2
+#define DGS_T2 DGS_T1
+#endif
+#ifndef DGS_CAP
+#define DGS_CAP 512
+#endif
+constexpr int kT1 = DGS_T1;        // rows up to this many nnz are streamed sequentially by one group in K1
+constexpr int kT2 = DGS_T2;      // rows up to this many nnz are reduced by one whole wave inside K1; longer rows are
                                // cut into units for K2/K3 (few rows, so their table atomics do not serialise K1)
-constexpr int kCap = 512;      // (col,val) pairs per wave LDS tile in K1  (4 KiB per wave, 16 KiB per block)
+constexpr int kCap = DGS_CAP;      // (col,val) pairs per wave LDS tile in K1  (4 KiB per wave, 16 KiB per block)
 constexpr int kRowsPerWave = 64;
 #ifndef DGS_KU1
-#define DGS_KU1 4
+#define DGS_KU1 6
 #endif
 constexpr int kU1 = DGS_KU1;   // independent B-row gathers in flight per lane, K1 (short rows)
 constexpr int kU = 8;          // same for K2 (units)
 
 struct SpmmWs {       // workspace header (zeroed every call with one 16-byte memset)
-  int n_units;        // K1 -> K2: number of unit descriptors
-  int n_multi;        // K1 -> K3: number of multi-unit rows
-  int n_pslots;       // partial-row slots handed out
-  int pad;
+  int n_units;        // K0 -> fused/K3: number of unit descriptors
+  int pad[3];
 };
 
 struct WsLayout {
-  size_t off_units, off_multi, off_part, off_parte, total;
-  int64_t max_units, max_multi, max_pslots;
+  size_t off_units, off_part, off_parte, total;
+  int64_t max_units;
   int ch;
 };
 
@@ -74,13 +87,10 @@ static inline WsLayout ws_layout(int reduce_op, int64_t N, int64_t nnz) {
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
   WsLayout L;
   L.ch = unit_len(nnz);
-  L.max_multi = nnz / L.ch + 1;                      // rows longer than CH
-  L.max_pslots = 2 * (nnz / L.ch) + 2;               // sum over those rows of ceil(len/CH) <= nnz/CH + #rows
-  L.max_units = nnz / kT2 + nnz / L.ch + 2;          // #huge rows < nnz/T2, plus the extra units
+  L.max_units = nnz / kT2 + nnz / L.ch + 2;          // sum over huge rows of ceil(len/ch) <= nnz/ch + #huge rows
   L.off_units = up(sizeof(SpmmWs));
-  L.off_multi = L.off_units + up((size_t)L.max_units * sizeof(int4));
-  L.off_part = L.off_multi + up((size_t)L.max_multi * sizeof(int4));
-  const size_t prow = up((size_t)L.max_pslots * N * sizeof(float));
+  L.off_part = L.off_units + up((size_t)L.max_units * sizeof(int4));
+  const size_t prow = up((size_t)L.max_units * N * sizeof(float));  // one partial row per unit (slot = unit id)
   L.off_parte = L.off_part + prow;
   const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
   L.total = L.off_parte + (arg ? prow : 0) + 256;
@@ -142,6 +152,62 @@ __device__ __forceinline__ void reduce_step_pos(float &res, int &eidx, int &epos
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// K0: scan rowptr once and cut every huge row (len > T2) into units of <= ch nnz: unit = {row, k, first unit of
+// the row, units in the row}.  Each thread looks at kK0Rows rows, a block-level exclusive scan turns the per-thread
+// unit counts into offsets, and ONE atomicAdd per block reserves the block's range of the table (same-address
+// atomics cost ~12 ns each when they serialise at L2; per-row atomics made this kernel 44 us, per-block ones ~5).
+// Only the position of a row's units in the table depends on the atomics, never a value.
+constexpr int kK0Rows = 16;
+__global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, const int *__restrict__ rowptr,
+                                                        SpmmWs *__restrict__ hdr, int4 *__restrict__ units) {
+  __shared__ int s_wsum[kBlock / kWave];
+  __shared__ int s_base;
+  const int nthreads = gridDim.x * kBlock;
+  const int tid = blockIdx.x * kBlock + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int mine = 0;
+  unsigned hugemask = 0;
+#pragma unroll
+  for (int i = 0; i < kK0Rows; i++) {
+    const int r = i * nthreads + tid;
+    if (r < M) {
+      const int len = rowptr[r + 1] - rowptr[r];
+      if (len > kT2) {
+        mine += (len + ch - 1) / ch;
+        hugemask |= 1u << i;
+      }
+    }
+  }
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const int t = __shfl_up(incl, d, kWave);
+    if (lane >= d) incl += t;
+  }
+  if (lane == kWave - 1) s_wsum[wave] = incl;
+  __syncthreads();
+  int woff = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / kWave; w++) {
+    if (w < wave) woff += s_wsum[w];
+    total += s_wsum[w];
+  }
+  if (threadIdx.x == 0) s_base = total ? atomicAdd(&hdr->n_units, total) : 0;
+  __syncthreads();
+  if (!mine) return;
+  int off = s_base + woff + incl - mine;
+  while (hugemask) {
+    const int i = __ffs((int)hugemask) - 1;
+    hugemask &= hugemask - 1;
+    const int r = i * nthreads + tid;
+    const int len = rowptr[r + 1] - rowptr[r];
+    const int nch = (len + ch - 1) / ch;
+    for (int k = 0; k < nch; k++) units[off + k] = make_int4(r, k, off, nch);
+    off += nch;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Wave-cooperative reduction of the nnz range [p0,p1) of one row: 64 (col,val) pairs at a time through the
 // wave's LDS tile, the NG groups take interleaved nnz (each B row is still one coalesced G-lane read), up to kU
 // gathers in flight per lane.  Leaves per-group partials in acc/ei/ep (combine with cross_group_reduce).
@@ -192,23 +258,24 @@ __device__ __forceinline__ void coop_accumulate(int p0, int p1, int lane, int g,
 // streams its piece U nnz at a time (U independent B-row gathers in flight, no per-row wait) and stores a row
 // of C whenever it meets a row-end flag.  Per-feature accumulation order = CSR order (bit-exact vs algorithm 0).
 // Also builds the unit table for long rows.
+struct RowsLds {
+  int2 tile[kBlock / kWave][kCap];
+  int4 rows[kBlock / kWave][kRowsPerWave + 1];  // {start, end, next non-empty short row, -}
+};
+
 template <int G, int V, int OP, bool HAS_VAL>
-__global__ __launch_bounds__(kBlock) void spmm_rows(int M, int N, int ch, const int *__restrict__ rowptr,
-                                                    const int *__restrict__ col, const float *__restrict__ val,
-                                                    const float *__restrict__ B, float *__restrict__ C,
-                                                    int *__restrict__ E, SpmmWs *__restrict__ hdr,
-                                                    int4 *__restrict__ units, int4 *__restrict__ multi) {
+__device__ __forceinline__ void spmm_rows_body(int bid, RowsLds &lds, int M, int N, const int *__restrict__ rowptr,
+                                               const int *__restrict__ col, const float *__restrict__ val,
+                                               const float *__restrict__ B, float *__restrict__ C,
+                                               int *__restrict__ E) {
   constexpr int NG = kWave / G;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
-  __shared__ int2 s_tile[kBlock / kWave][kCap];
-  __shared__ int4 s_rows[kBlock / kWave][kRowsPerWave + 1];  // {start, end, next non-empty short row, -}
-
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane / G, l = lane % G;
-  const int r0 = (blockIdx.x * (kBlock / kWave) + wave) * kRowsPerWave;
+  const int r0 = (bid * (kBlock / kWave) + wave) * kRowsPerWave;
   if (r0 >= M) return;  // wave-uniform
-  int2 *tile = s_tile[wave];
-  int4 *rows = s_rows[wave];
+  int2 *tile = lds.tile[wave];
+  int4 *rows = lds.rows[wave];
   const int nrows = min(kRowsPerWave, M - r0);
   const int f0 = (blockIdx.y * G + l) * V;
   const bool fl = f0 < N;
@@ -251,19 +318,6 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(int M, int N, int ch, const 
       }
       for (int k = 0; k < NG && em; k++) em &= em - 1;  // drop the NG rows just written
     }
-  }
-
-  // huge rows -> unit table (feature tile 0 only; slots come from atomics, values never do)
-  if (huge_i && blockIdx.y == 0) {
-    const int nch = (len_i + ch - 1) / ch;
-    const int ubase = atomicAdd(&hdr->n_units, nch);
-    int pbase = -1;
-    if (nch > 1) {
-      pbase = atomicAdd(&hdr->n_pslots, nch);
-      const int mi = atomicAdd(&hdr->n_multi, 1);
-      multi[mi] = make_int4(r0 + lane, pbase, nch, 0);
-    }
-    for (int k = 0; k < nch; k++) units[ubase + k] = make_int4(r0 + lane, k, pbase, nch);
   }
 
   int a = 0;
@@ -409,24 +463,22 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(int M, int N, int ch, const 
 // ---------------------------------------------------------------------------------------------------------
 // K2: one wave per unit (<= ch nnz of a long row).
 template <int G, int V, int OP, bool HAS_VAL>
-__global__ __launch_bounds__(kBlock) void spmm_units(int N, int ch, const int *__restrict__ rowptr,
-                                                     const int *__restrict__ col, const float *__restrict__ val,
-                                                     const float *__restrict__ B, float *__restrict__ C,
-                                                     int *__restrict__ E, const SpmmWs *__restrict__ hdr,
-                                                     const int4 *__restrict__ units, float *__restrict__ part,
-                                                     int *__restrict__ parte) {
-
+__device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &lds, int N, int ch,
+                                                const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                const float *__restrict__ val, const float *__restrict__ B,
+                                                float *__restrict__ C, int *__restrict__ E,
+                                                const SpmmWs *__restrict__ hdr, const int4 *__restrict__ units,
+                                                float *__restrict__ part, int *__restrict__ parte) {
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
-  __shared__ int2 s_tile[kBlock / kWave][kWave];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane / G, l = lane % G;
-  int2 *tile = s_tile[wave];
+  int2 *tile = lds.tile[wave];
   const int f0 = (blockIdx.y * G + l) * V;
   const bool fl = f0 < N;
   const int n_units = hdr->n_units;
-  const int wstride = gridDim.x * (kBlock / kWave);
+  const int wstride = nblocks * (kBlock / kWave);
 
-  for (int u = blockIdx.x * (kBlock / kWave) + wave; u < n_units; u += wstride) {
+  for (int u = bid * (kBlock / kWave) + wave; u < n_units; u += wstride) {
     const int4 d = units[u];  // {row, unit index in row, partial slot base, units in row}
     const int rs = rowptr[d.x], re = rowptr[d.x + 1];
     const int p0 = rs + d.y * ch;
@@ -460,23 +512,55 @@ __global__ __launch_bounds__(kBlock) void spmm_units(int N, int ch, const int *_
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K3: one wave per multi-unit row, folds the partial rows in unit order.
+// Fused launch: blocks [0, nbu) walk the unit table of the huge rows (persistent, strided), the remaining blocks
+// each own 4 x 64 consecutive rows.  Unit blocks come first so that the longest-running work starts first; the
+// two kinds of work share the CUs, so the fabric-bound unit gathers overlap the row kernel's latency phases.
+template <int G, int V, int OP, bool HAS_VAL>
+__global__ __launch_bounds__(kBlock) void spmm_fused(int M, int N, int ch, int nbu, const int *__restrict__ rowptr,
+                                                     const int *__restrict__ col, const float *__restrict__ val,
+                                                     const float *__restrict__ B, float *__restrict__ C,
+                                                     int *__restrict__ E, const SpmmWs *__restrict__ hdr,
+                                                     const int4 *__restrict__ units, float *__restrict__ part,
+                                                     int *__restrict__ parte) {
+  __shared__ RowsLds lds;
+  if ((int)blockIdx.x < nbu)
+    spmm_units_body<G, V, OP, HAS_VAL>(blockIdx.x, nbu, lds, N, ch, rowptr, col, val, B, C, E, hdr, units, part,
+                                       parte);
+  else
+    spmm_rows_body<G, V, OP, HAS_VAL>(blockIdx.x - nbu, lds, M, N, rowptr, col, val, B, C, E);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K3: waves stride over the unit table; the wave that meets the FIRST unit of a multi-unit row folds that row's
+// partial rows in unit order (groups take interleaved units, 4 independent partial loads in flight per lane,
+// then the fixed cross-group tree).
 template <int G, int V, int OP>
 __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restrict__ rowptr,
                                                        float *__restrict__ C, int *__restrict__ E,
-                                                       const SpmmWs *__restrict__ hdr, const int4 *__restrict__ multi,
+                                                       const SpmmWs *__restrict__ hdr, const int4 *__restrict__ units,
                                                        const float *__restrict__ part,
                                                        const int *__restrict__ parte) {
   constexpr int NG = kWave / G;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
+  constexpr int UP = 4;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane / G, l = lane % G;
   const int f0 = (blockIdx.y * G + l) * V;
   const bool fl = f0 < N;
-  const int n_multi = hdr->n_multi;
-  const int wstride = gridDim.x * (kBlock / kWave);
-  for (int i = blockIdx.x * (kBlock / kWave) + wave; i < n_multi; i += wstride) {
-    const int4 d = multi[i];  // {row, partial slot base, units, -}
+  const int n_units = hdr->n_units;
+  const int wstride = gridDim.x * (kBlock / kWave) * kWave;
+  for (int i0 = (blockIdx.x * (kBlock / kWave) + wave) * kWave; i0 < n_units; i0 += wstride) {
+   // 64 descriptors per wave-load; rows to fold = first unit of a multi-unit row
+   int4 dl = make_int4(0, 1, 0, 0);
+   if (i0 + lane < n_units) dl = units[i0 + lane];  // {row, unit index in row, first unit of the row, units in row}
+   unsigned long long todo = __ballot(dl.y == 0 && dl.w > 1);
+   while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    int4 d;
+    d.x = __shfl(dl.x, src, 64);
+    d.z = __shfl(dl.z, src, 64);
+    d.w = __shfl(dl.w, src, 64);
     float acc[V];
     int ei[V], ep[V];
 #pragma unroll
@@ -485,26 +569,33 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
       ei[v] = -1;
       ep[v] = INT_MAX;
     }
-    for (int k = g; k < d.z; k += NG) {
-      if (fl) {
-        float x[V];
-        const int64_t slot = (int64_t)(d.y + k) * N + f0;
-        load_vec<V>(part + slot, x);
-        if constexpr (ARG) {
-          int xe[V];
-          load_vec<V>(parte + slot, xe);
+    for (int k = g; k < d.w; k += NG * UP) {
+      float x[UP][V];
+      int xe[UP][V];
+#pragma unroll
+      for (int q = 0; q < UP; q++) {
+        if (k + q * NG < d.w && fl) {
+          const int64_t slot = (int64_t)(d.z + k + q * NG) * N + f0;
+          load_vec<V>(part + slot, x[q]);
+          if constexpr (ARG) load_vec<V>(parte + slot, xe[q]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < UP; q++) {
+        if (k + q * NG < d.w && fl) {
 #pragma unroll
           for (int v = 0; v < V; v++) {
-            // a partial that never improved on the identity carries E=-1 and must not win
-            if (xe[v] != -1 && arg_better<OP>(acc[v], ep[v], x[v], k)) {
-              acc[v] = x[v];
-              ei[v] = xe[v];
-              ep[v] = k;
+            if constexpr (ARG) {
+              // a partial that never improved on the identity carries E=-1 and must not win
+              if (xe[q][v] != -1 && arg_better<OP>(acc[v], ep[v], x[q][v], k + q * NG)) {
+                acc[v] = x[q][v];
+                ei[v] = xe[q][v];
+                ep[v] = k + q * NG;
+              }
+            } else {
+              acc[v] += x[q][v];
             }
           }
-        } else {
-#pragma unroll
-          for (int v = 0; v < V; v++) acc[v] += x[v];
         }
       }
     }
@@ -518,6 +609,7 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
       store_vec_stream<V>(C + (int64_t)d.x * N + f0, acc);
       if constexpr (ARG) store_vec_stream<V>(E + (int64_t)d.x * N + f0, ei);
     }
+   }
   }
 }
 
@@ -610,23 +702,25 @@ static int launch_all(const SpmmArgs &a) {
   char *w = static_cast<char *>(a.ws);
   SpmmWs *hdr = reinterpret_cast<SpmmWs *>(w);
   int4 *units = reinterpret_cast<int4 *>(w + L.off_units);
-  int4 *multi = reinterpret_cast<int4 *>(w + L.off_multi);
   float *part = reinterpret_cast<float *>(w + L.off_part);
   int *parte = reinterpret_cast<int *>(w + L.off_parte);
   if (hipMemsetAsync(hdr, 0, sizeof(SpmmWs), a.st) != hipSuccess) return DGS_ELAUNCH;
+  const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
+  hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, a.rowptr, hdr, units);
+  // unit / multi counts live on the device: a bounded number of persistent unit blocks stride over the table
   const int rows_per_block = (kBlock / kWave) * kRowsPerWave;
-  const dim3 g1((unsigned)((a.M + rows_per_block - 1) / rows_per_block), (unsigned)a.tiles);
-  hipLaunchKernelGGL((spmm_rows<G, V, OP, HAS_VAL>), g1, dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, L.ch, a.rowptr,
-                     a.col, a.val, a.B, a.C, a.E, hdr, units, multi);
-  // unit / multi counts live on the device: launch a bounded persistent grid, waves stride over the tables
+  const int64_t nbr = (a.M + rows_per_block - 1) / rows_per_block;
   const int64_t ub = (L.max_units + 3) / 4;
-  const dim3 g2((unsigned)(ub < 4096 ? (ub < 1 ? 1 : ub) : 4096), (unsigned)a.tiles);
-  hipLaunchKernelGGL((spmm_units<G, V, OP, HAS_VAL>), g2, dim3(kBlock), 0, a.st, (int)a.N, L.ch, a.rowptr, a.col,
-                     a.val, a.B, a.C, a.E, hdr, units, part, parte);
-  const int64_t mb = (L.max_multi + 3) / 4;
-  const dim3 g3((unsigned)(mb < 1024 ? (mb < 1 ? 1 : mb) : 1024), (unsigned)a.tiles);
-  hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.C, a.E, hdr, multi,
-                     part, parte);
+#ifndef DGS_NBU
+#define DGS_NBU 1024
+#endif
+  const int nbu = (int)(ub < DGS_NBU ? (ub < 1 ? 1 : ub) : DGS_NBU);
+  hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
+                     a.st, (int)a.M, (int)a.N, L.ch, nbu, a.rowptr, a.col, a.val, a.B, a.C, a.E, hdr, units, part,
+                     parte);
+  const dim3 g3((unsigned)(nbu < 256 ? nbu : 256), (unsigned)a.tiles);
+  hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.C, a.E, hdr, units, part,
+                     parte);
   return check_launch();
 }
 
