@@ -1,0 +1,213 @@
+"""Multi-GPU SpMM: 1-D row partition + halo feature exchange (new design; the reference is single-device only,
+SURVEY.md R4 / section 8e).
+
+One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for the tests).
+Rank g owns a contiguous block of rows of A and the matching rows of the dense operand B and of the output C.
+A row of A may reference columns owned by other ranks; those feature rows ("halo") are fetched once per SpMM call
+with ONE all-to-all-v:
+
+    offline  HaloPlan:  unique remote column ids grouped by owner  -> recv_ids   (what I need)
+                        transpose of the plan (all-to-all of counts + ids) -> send_ids (what peers need from me)
+                        local CSR re-labelled into the extended index space [local rows | halo slots]
+    per call pack   : gather_rows(B_loc, send_ids)            (HIP kernel dgs_gather_rows_f32)
+             exchange: all_to_all_single(B_ext[Mloc:], packed, recv_splits, send_splits)   (RCCL)
+             compute : C = spmm(A_ext, B_ext)                  (the single-GPU kernels, unchanged numerics)
+
+xGMI is point-to-point (7 links per GPU), so an all-to-all uses every link at once - the right collective shape for
+this fabric; there is no all-reduce anywhere.  Only feature rows travel; the graph never does.
+max/min return global column ids in E (ext -> global relabel), first-occurrence ties are preserved because the
+order of a row's entries is never changed.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class RowPartition:
+    """Rows [row_offsets[rank], row_offsets[rank+1]) of a global M x M CSR; ``col`` holds GLOBAL column ids."""
+    rank: int
+    world: int
+    row_offsets: List[int]
+    rowptr: torch.Tensor  # int32 [Mloc+1]
+    col: torch.Tensor     # int32 [nnz], global ids, CSR order inside rows
+    val: Optional[torch.Tensor]  # float32 [nnz] or None
+
+    @property
+    def r0(self):
+        return self.row_offsets[self.rank]
+
+    @property
+    def n_local(self):
+        return self.row_offsets[self.rank + 1] - self.row_offsets[self.rank]
+
+    @property
+    def nnz(self):
+        return int(self.col.numel())
+
+
+def partition_csr(rowptr, col, val, world: int) -> List[RowPartition]:
+    """Split a global CSR (numpy or torch, square) into ``world`` contiguous equal row blocks."""
+    rowptr = torch.as_tensor(rowptr)
+    col = torch.as_tensor(col)
+    val = None if val is None else torch.as_tensor(val)
+    M = rowptr.numel() - 1
+    per = (M + world - 1) // world
+    offs = [min(M, i * per) for i in range(world + 1)]
+    parts = []
+    for r in range(world):
+        s, e = int(rowptr[offs[r]]), int(rowptr[offs[r + 1]])
+        parts.append(RowPartition(r, world, offs, (rowptr[offs[r]:offs[r + 1] + 1] - s).to(torch.int32).contiguous(),
+                                  col[s:e].to(torch.int32).contiguous(),
+                                  None if val is None else val[s:e].to(torch.float32).contiguous()))
+    return parts
+
+
+def synthetic_partition(rank: int, world: int, n_local: int, deg: int, cols: str = 'powerlaw', locality: float = 0.8,
+                        alpha: float = 2.1, dmax: int = 1 << 16, seed: int = 0, device='cpu') -> RowPartition:
+    """Rank-local block of a synthetic power-law graph with ``n_local`` rows per rank (weak scaling).
+
+    Row degrees: truncated Pareto (as bench/graphgen.py).  Each entry stays inside the rank's own row block with
+    probability ``locality`` (1 - edge cut; partitioned real graphs have cuts of 10-30 %), else it goes to a
+    uniformly chosen other rank.  Inside the owner's block the column follows a popularity law that depends on
+    (seed, owner) only, so every rank agrees on which columns are hubs."""
+    from bench import graphgen  # generators live next to bench.py; only used by benchmarks and tests
+    dev = torch.device(device)
+    rng = np.random.Generator(np.random.PCG64(seed * 1000 + rank))
+    degs = graphgen.powerlaw_degrees(n_local, n_local * deg, alpha, min(dmax, n_local), rng)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed * 1000 + rank)
+    deg_t = torch.from_numpy(degs).to(dev)
+    total = int(deg_t.sum())
+    row = torch.repeat_interleave(torch.arange(n_local, device=dev), deg_t)
+    if world > 1:
+        remote = torch.rand(total, generator=gen, device=dev) >= locality
+        other = torch.randint(0, world - 1, (total,), generator=gen, device=dev)
+        other = other + (other >= rank).long()
+        owner = torch.where(remote, other, torch.full_like(other, rank))
+    else:
+        owner = torch.zeros(total, dtype=torch.long, device=dev)
+    if cols == 'uniform':
+        inner = torch.randint(0, n_local, (total,), generator=gen, device=dev)
+    else:
+        inner = torch.empty(total, dtype=torch.long, device=dev)
+        u = torch.rand(total, generator=gen, device=dev, dtype=torch.float64)
+        for h in range(world):  # popularity of owner h's columns: a function of (seed, h) only
+            prng = np.random.Generator(np.random.PCG64(seed * 7919 + h))
+            w = graphgen.powerlaw_degrees(n_local, n_local * deg, alpha, min(dmax, n_local), prng).astype(np.float64) + 0.05
+            w = w[prng.permutation(n_local)]
+            cdf = torch.from_numpy(np.cumsum(w) / w.sum()).to(dev)
+            m = owner == h
+            inner[m] = torch.searchsorted(cdf, u[m], right=True).clamp_(max=n_local - 1)
+    K = world * n_local
+    key = torch.unique_consecutive(torch.sort(row * K + owner * n_local + inner).values)
+    row = key // K
+    col = (key - row * K).to(torch.int32)
+    counts = torch.bincount(row, minlength=n_local)
+    rowptr = torch.zeros(n_local + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=rowptr[1:])
+    vg = torch.Generator(device=dev)
+    vg.manual_seed(seed * 1000 + rank + 17)
+    val = torch.rand(col.numel(), generator=vg, device=dev)
+    return RowPartition(rank, world, [i * n_local for i in range(world + 1)], rowptr.to(torch.int32), col, val)
+
+
+def _all_to_all_v(out: torch.Tensor, inp: torch.Tensor, out_splits: List[int], in_splits: List[int], group=None):
+    """all_to_all_single with per-peer splits (first-dim rows); nccl(RCCL) and gloo both implement it."""
+    dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+
+
+class HaloPlan:
+    """Who needs which feature rows.  Built once per partition (collective: every rank must call it)."""
+
+    def __init__(self, part: RowPartition, group=None):
+        dev = part.col.device
+        world, rank = part.world, part.rank
+        offs = torch.tensor(part.row_offsets, device=dev, dtype=torch.int64)
+        col = part.col.long()
+        owner = torch.bucketize(col, offs[1:], right=True)  # owner[i] = rank whose block contains col[i]
+        is_remote = owner != rank
+        rem = torch.unique(col[is_remote])  # sorted => grouped by owner (blocks are contiguous)
+        rem_owner = torch.bucketize(rem, offs[1:], right=True)
+        recv_splits = torch.bincount(rem_owner, minlength=world)
+        # extended column ids: local -> [0, n_local); remote -> n_local + position in `rem`
+        ext = torch.where(is_remote, part.n_local + torch.searchsorted(rem, col), col - part.r0)
+        self.col_ext = ext.to(torch.int32).contiguous()
+        self.recv_ids = rem  # global ids, ascending
+        self.recv_splits = recv_splits.tolist()
+        self.n_halo = int(rem.numel())
+        self.ext2glob = torch.cat([torch.arange(part.r0, part.r0 + part.n_local, device=dev), rem])
+        if world == 1:  # nothing to exchange; no process group needed
+            self.send_splits = [0]
+            self.send_ids = torch.zeros(0, dtype=torch.int32, device=dev)
+            return
+        # transpose the plan: tell every owner which of its rows I need
+        send_counts = torch.empty(world, dtype=torch.int64, device=dev)
+        _all_to_all_v(send_counts, recv_splits.contiguous(), [1] * world, [1] * world, group)
+        self.send_splits = send_counts.tolist()
+        send_ids = torch.empty(int(send_counts.sum()), dtype=torch.int64, device=dev)
+        _all_to_all_v(send_ids, rem.contiguous(), self.send_splits, self.recv_splits, group)
+        self.send_ids = (send_ids - part.r0).to(torch.int32).contiguous()  # local row indices peers asked for
+        assert self.send_ids.numel() == 0 or (int(self.send_ids.min()) >= 0 and int(self.send_ids.max()) < part.n_local)
+
+
+class _HipOps:
+    """The product compute path: the HIP kernels through the C ABI."""
+
+    def __init__(self):
+        from . import _capi
+        self._c = _capi
+
+    def spmm(self, op, rowptr, col, val, B):
+        return self._c.spmm(op, rowptr, col, val, B)
+
+    def gather_rows(self, src, ids):
+        return self._c.gather_rows(src, ids)
+
+
+_OPS = {'sum': 0, 'max': 1, 'min': 2, 'mean': 3}
+
+
+class DistSpMM:
+    """C_loc = reduce(A_loc_rows (*) B_global) with B row-partitioned like A.  ``ops`` is injectable so that the
+    exchange logic can be exercised on CPU/gloo with a stand-in compute back end (tests only)."""
+
+    def __init__(self, part: RowPartition, n_feat: int, ops=None, group=None):
+        self.part, self.N, self.group = part, n_feat, group
+        self.ops = ops if ops is not None else _HipOps()
+        self.plan = HaloPlan(part, group)
+        self.n_halo = self.plan.n_halo
+        dev = part.col.device
+        # one buffer for [local rows | halo rows]: the exchange lands directly where the kernel reads it
+        self.B_ext = torch.empty((part.n_local + self.n_halo, n_feat), dtype=torch.float32, device=dev)
+        t = torch.tensor([part.nnz], dtype=torch.int64, device=dev)
+        if part.world > 1:
+            dist.all_reduce(t, group=group)
+        self.global_nnz = int(t.item())
+        self.last_E = None
+
+    def local_features(self) -> torch.Tensor:
+        """View of the first n_local rows of the exchange buffer: fill it in place to skip the copy in spmm()."""
+        return self.B_ext[:self.part.n_local]
+
+    def exchange(self, B_loc: torch.Tensor) -> torch.Tensor:
+        p, plan = self.part, self.plan
+        if B_loc.data_ptr() != self.B_ext.data_ptr():
+            self.B_ext[:p.n_local].copy_(B_loc)
+        if p.world > 1:
+            packed = self.ops.gather_rows(self.B_ext[:p.n_local], plan.send_ids)
+            _all_to_all_v(self.B_ext[p.n_local:], packed, plan.recv_splits, plan.send_splits, self.group)
+        return self.B_ext
+
+    def spmm(self, B_loc: torch.Tensor, reduce: str = 'sum') -> torch.Tensor:
+        B_ext = self.exchange(B_loc)
+        C, E = self.ops.spmm(_OPS[reduce], self.part.rowptr, self.plan.col_ext, self.part.val, B_ext)
+        if E is not None:  # ext ids -> global column ids (-1 stays -1)
+            g = self.plan.ext2glob[E.clamp(min=0).long()].to(torch.int32)
+            self.last_E = torch.where(E >= 0, g, E)
+        return C

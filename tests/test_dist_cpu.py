@@ -1,0 +1,92 @@
+"""world_size-2 (and 3) gloo tests of the multi-GPU path on CPU: partitioner, halo plan, all-to-all-v exchange
+and ext->global relabel.  The local product uses the CPU oracle as a stand-in compute back end (tests only);
+the result must equal the single-process oracle on the unpartitioned graph: bit-exact for max/min (+E), and
+bit-exact for sum too because the relabel never changes the order of a row's entries."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleOps:
+    def spmm(self, op, rowptr, col, val, B):
+        import oracle
+        C, E = oracle.spmm(op, rowptr.numpy(), col.numpy(), None if val is None else val.numpy(), B.numpy())
+        return torch.from_numpy(C), (torch.from_numpy(E) if op in (1, 2) else None)
+
+    def gather_rows(self, src, ids):
+        return src[ids.long()].contiguous()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, cols, q):
+    for p in (ROOT, os.path.join(ROOT, 'dgsparse-lib_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import oracle
+        from bench import graphgen
+        from dgsparse import dist as dd
+        M, N = 600 * world, 24
+        rp, col, st = graphgen.powerlaw_csr(M, 9000 * world, alpha=2.0, dmax=M // 2, cols=cols, seed=5)
+        val = graphgen.weights(col.shape[0], 'tied', 5)
+        X = (np.random.default_rng(1).integers(-2, 3, (M, N)) / 4).astype(np.float32)
+        part = dd.partition_csr(rp, col, val, world)[rank]
+        eng = dd.DistSpMM(part, N, ops=OracleOps())
+        r0, r1 = part.row_offsets[rank], part.row_offsets[rank + 1]
+        res = {}
+        for red in ('sum', 'mean', 'max', 'min'):
+            C = eng.spmm(torch.from_numpy(X[r0:r1].copy()), red)
+            Cg, Eg = oracle.spmm(red, rp, col, val, X)
+            ok = np.array_equal(C.numpy().view(np.int32), Cg[r0:r1].view(np.int32))
+            if red in ('max', 'min'):
+                ok = ok and np.array_equal(eng.last_E.numpy(), Eg[r0:r1])
+            res[red] = bool(ok)
+        # plan sanity: halo = unique remote columns, send/recv splits are each other's transpose
+        remote = np.unique(col[rp[r0]:rp[r1]][(col[rp[r0]:rp[r1]] < r0) | (col[rp[r0]:rp[r1]] >= r1)])
+        res['halo'] = eng.n_halo == remote.shape[0]
+        tot = torch.tensor([sum(eng.plan.send_splits), sum(eng.plan.recv_splits)])
+        dist.all_reduce(tot)
+        res['transpose'] = int(tot[0]) == int(tot[1])
+        res['nnz'] = eng.global_nnz == col.shape[0]
+        # weak-scaling generator: consistent global column range, local block ids
+        sp = dd.synthetic_partition(rank, world, 512, 8, locality=0.7, seed=3)
+        res['synth'] = int(sp.col.max()) < 512 * world and sp.rowptr.numel() == 513
+        e2 = dd.DistSpMM(sp, 8, ops=OracleOps())
+        Y = e2.spmm(torch.rand(512, 8), 'sum')
+        res['synth_run'] = tuple(Y.shape) == (512, 8) and bool(torch.isfinite(Y).all())
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,cols', [(2, 'powerlaw'), (2, 'uniform'), (3, 'powerlaw')])
+def test_dist_spmm_matches_single_process(world, cols):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cols, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in out:
+        assert all(res.values()), (rank, res)

@@ -95,3 +95,19 @@ def test_errors_are_loud():
         dgsparse.spmm_sum(dcsr, X.cpu(), 0)  # no CPU fallback
     with pytest.raises(AssertionError):
         dgsparse.SparseTensor(rowptr=dcsr.storage.rowptr().long(), col=dcsr.storage.col())
+
+
+def test_dist_engine_single_rank_on_gpu():
+    """The partitioned code path (plan, ext relabel, exchange buffer) with one rank on the GPU: must equal the plain
+    operator bit for bit.  The N>1 exchange itself is covered by tests/test_dist_cpu.py (gloo, world 2 and 3)."""
+    from dgsparse import _capi
+    from dgsparse import dist as dd
+    sp = dd.synthetic_partition(0, 1, 4096, 12, seed=2, device='cuda')
+    X = torch.rand(4096, 64, device='cuda')
+    eng = dd.DistSpMM(sp, 64)
+    for red, op in (('sum', 0), ('max', 1)):
+        C = eng.spmm(X, red)
+        Cr, Er = _capi.spmm(op, sp.rowptr, sp.col, sp.val, X)
+        assert torch.equal(C, Cr)
+        if red == 'max':
+            assert torch.equal(eng.last_E, Er)

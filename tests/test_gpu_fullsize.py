@@ -1,0 +1,139 @@
+"""BASELINE.json's configurations at FULL size on the GPU (synthetic, dataset-shaped: no dataset can be fetched,
+SURVEY.md R2), checked through size-independent properties plus an oracle comparison on a row sample:
+
+  * unit weights, all-ones features      -> sum = row degree exactly, mean = 1, empty rows = 0
+  * features encoding the column id      -> max = last (largest) column of the row, min = first, E = that id
+  * linearity                            -> spmm(A, X1 + X2) ~= spmm(A, X1) + spmm(A, X2)
+  * oracle on a sub-CSR of sampled rows (always including the longest rows), bit-exact for max/min + E
+  * SDDMM: D1 = e_k rows, D2 = features  -> out[e] = D2[col(e), k]; and oracle on sampled rows
+  * csr2csc: applying it twice (transpose of the transpose) returns the original CSR; colptr = column histogram
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from bench import graphgen
+from util import assert_bitexact, assert_close, assert_sum_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def capi():
+    from dgsparse import _capi
+    return _capi
+
+
+def sample_rows(rp, k, seed=0):
+    deg = (rp[1:] - rp[:-1])
+    top = torch.topk(deg, 8).indices
+    g = torch.Generator(device=rp.device)
+    g.manual_seed(seed)
+    rnd = torch.randint(0, rp.numel() - 1, (k,), generator=g, device=rp.device)
+    return torch.unique(torch.cat([top, rnd]))
+
+
+def sub_csr(rp, col, val, rows):
+    """CSR made of the selected rows (same column space), on the host."""
+    rpc, rows_c = rp.cpu().numpy(), rows.cpu().numpy()
+    idx = np.concatenate([np.arange(rpc[r], rpc[r + 1]) for r in rows_c]) if len(rows_c) else np.zeros(0, np.int64)
+    lens = np.array([rpc[r + 1] - rpc[r] for r in rows_c])
+    srp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    t = torch.from_numpy(idx).to(col.device)
+    return srp, col[t].cpu().numpy(), (None if val is None else val[t].cpu().numpy())
+
+
+CONFIGS = [  # (name, feat, reduces)   BASELINE.json configs[1], [2], north_star sweep
+    ('arxiv', 64, ('sum',)),
+    ('synth1m', 64, ('sum', 'max')),
+    ('synth1m', 32, ('sum',)),
+    ('reddit', 128, ('sum', 'max')),
+]
+
+
+@pytest.mark.parametrize('name,N,reduces', CONFIGS)
+def test_spmm_fullsize_properties(capi, name, N, reduces):
+    rp, col, st = graphgen.dataset_shaped(name, seed=0, device='cuda', as_torch=True)
+    M, K, nnz = st['M'], st['K'], st['nnz']
+    deg = (rp[1:] - rp[:-1])
+    # 1. degree property (exact: small integers in fp32)
+    ones = torch.ones((K, N), device='cuda')
+    C, _ = capi.spmm(oracle.SUM, rp, col, None, ones)
+    assert torch.equal(C[:, 0], deg.float()) and torch.equal(C[:, N - 1], deg.float())
+    Cm, _ = capi.spmm(oracle.MEAN, rp, col, None, ones)
+    assert torch.equal(Cm[:, 1], (deg > 0).float())
+    del C, Cm, ones
+    # 2. column-id property for max/min (+E), exact
+    if 'max' in reduces:
+        ids = torch.arange(K, device='cuda', dtype=torch.float32)[:, None].expand(K, N).contiguous()
+        lastcol = torch.full((M,), -1, dtype=torch.int32, device='cuda')
+        nz = deg > 0
+        lastcol[nz] = col[(rp[1:][nz] - 1).long()]
+        firstcol = torch.full((M,), -1, dtype=torch.int32, device='cuda')
+        firstcol[nz] = col[rp[:-1][nz].long()]
+        Cx, Ex = capi.spmm(oracle.MAX, rp, col, None, ids)
+        assert torch.equal(Ex[:, 0], lastcol) and torch.equal(Ex[:, N - 1], lastcol)
+        assert torch.equal(Cx[:, 0], torch.where(nz, lastcol.float(), torch.zeros_like(Cx[:, 0])))
+        Cn, En = capi.spmm(oracle.MIN, rp, col, None, ids)
+        assert torch.equal(En[:, 0], firstcol)
+        del ids, Cx, Ex, Cn, En
+    # 3. sampled rows vs oracle, 4. linearity
+    g = torch.Generator(device='cuda')
+    g.manual_seed(1)
+    val = torch.rand(nnz, generator=g, device='cuda')
+    X = torch.rand((K, N), generator=g, device='cuda')
+    rows = sample_rows(rp, 300)
+    srp, scol, sval = sub_csr(rp, col, val, rows)
+    Xh = X.cpu().numpy()
+    for red in reduces:
+        C, E = capi.spmm(oracle.REDUCE[red], rp, col, val, X)
+        Co, Eo = oracle.spmm(red, srp, scol, sval, Xh, fma=True)
+        got = C[rows.long()].cpu().numpy()
+        if red == 'max':
+            assert_bitexact(got, Co, f'{name} max values')
+            assert_bitexact(E[rows.long()].cpu().numpy(), Eo, f'{name} max E')
+        else:
+            C64 = oracle.spmm_sum_f64(srp, scol, sval, Xh)
+            assert_sum_parity(got, Co, C64, None, 1e-5, 2e-6, f'{name} sum')
+            X2 = torch.rand((K, N), generator=g, device='cuda')
+            C2, _ = capi.spmm(oracle.SUM, rp, col, val, X2)
+            C12, _ = capi.spmm(oracle.SUM, rp, col, val, X + X2)
+            assert torch.allclose(C12, C + C2, rtol=2e-5, atol=1e-4)
+            del X2, C2, C12
+        del C, E
+
+
+def test_sddmm_products_shaped_fullsize(capi):
+    """BASELINE.json configs[3]: SDDMM on a products-shaped CSR (2.4M rows, ~62M nnz), F=64."""
+    rp, col, st = graphgen.dataset_shaped('products', seed=0, device='cuda', as_torch=True)
+    M, K, nnz, F = st['M'], st['K'], st['nnz'], 64
+    g = torch.Generator(device='cuda')
+    g.manual_seed(2)
+    D2 = torch.rand((K, F), generator=g, device='cuda')
+    D1 = torch.zeros((M, F), device='cuda')
+    D1[:, 5] = 1.0  # out[e] = D2[col(e), 5] exactly
+    out = capi.sddmm(rp, col, D1, D2)
+    assert torch.equal(out, D2[col.long(), 5])
+    D1 = torch.rand((M, F), generator=g, device='cuda')
+    out = capi.sddmm(rp, col, D1, D2)
+    rows = sample_rows(rp, 200)
+    srp, scol, _ = sub_csr(rp, col, None, rows)
+    ref = oracle.sddmm(srp, scol, D1[rows.long()].cpu().numpy(), D2.cpu().numpy(), fma=True)
+    rpc = rp.cpu().numpy()
+    idx = np.concatenate([np.arange(rpc[r], rpc[r + 1]) for r in rows.cpu().numpy()])
+    assert_close(out.cpu().numpy()[idx], ref, 1e-5, 2e-6, 'sddmm sampled rows')
+
+
+def test_csr2csc_fullsize_involution(capi):
+    """nnz well above 2^24, where the reference's float-encoded permutation (storage.py:164-169) breaks."""
+    rp, col, st = graphgen.dataset_shaped('products', seed=1, device='cuda', as_torch=True, scale=0.5)
+    M, K, nnz = st['M'], st['K'], st['nnz']
+    assert nnz > (1 << 24)
+    val = torch.arange(nnz, device='cuda', dtype=torch.float32)  # not exact above 2^24: payload only
+    colptr, row, cval, perm = capi.csr2csc(rp, col, val, K)
+    assert torch.equal(colptr[1:] - colptr[:-1], torch.bincount(col.long(), minlength=K).int())
+    assert bool((perm.long().sort().values == torch.arange(nnz, device='cuda')).all())  # a permutation
+    assert torch.equal(col[perm.long()], torch.repeat_interleave(torch.arange(K, device='cuda'), (colptr[1:] - colptr[:-1]).long()).int())
+    rp2, col2, _, _ = capi.csr2csc(colptr, row, None, M)  # transpose back
+    assert torch.equal(rp2, rp) and torch.equal(col2, col)

@@ -217,3 +217,41 @@ def test_gather_scatter_rows(capi):
     ref[ids.long()] += g
     capi.scatter_add_rows(dst, ids, g)
     assert torch.equal(dst, ref)
+
+
+def test_gespmm_and_sddmm_compat_shims(capi):
+    """The reference's standalone C entry points (src/ge-spmm/gespmm.h:32-41, src/sddmm/sddmm.h:10), same symbol
+    names and argument order, default stream."""
+    import ctypes
+    lib = ctypes.CDLL(capi.LIB_PATH)
+
+    class Descr(ctypes.Structure):
+        _fields_ = [('nrow', ctypes.c_int), ('ncol', ctypes.c_int), ('nnz', ctypes.c_int),
+                    ('indptr', ctypes.c_void_p), ('indices', ctypes.c_void_p), ('data', ctypes.c_void_p)]
+
+    M, K, N = 700, 650, 48
+    rp, col = rand_graph(M, K, 9000, seed=11)
+    val = graphgen.weights(col.shape[0], 'uniform', 11)
+    X = graphgen.features(K, N, 11)
+    drp, dcol, dval, dX = dev(rp), dev(col), dev(val), dev(X)
+    out = torch.empty(M, N, device='cuda')
+    torch.cuda.synchronize()
+    lib.gespmmCsrSpMM.argtypes = [Descr, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_bool, ctypes.c_int]
+    lib.gespmmCsrSpMM(Descr(M, K, -1, drp.data_ptr(), dcol.data_ptr(), dval.data_ptr()), dX.data_ptr(), N,
+                      out.data_ptr(), True, 10)  # nnz < 0: read indptr[nrow]; GESPMM_ALG_DEFAULT
+    torch.cuda.synchronize()
+    Co, _ = oracle.spmm('sum', rp, col, val, X, fma=True)
+    assert_close(out.cpu().numpy(), Co, RTOL, ATOL, 'gespmmCsrSpMM')
+    out.zero_()
+    lib.spmm_cuda_no_edge_value.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5
+    lib.spmm_cuda_no_edge_value(M, N, drp.data_ptr(), dcol.data_ptr(), None, dX.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    Co1, _ = oracle.spmm('sum', rp, col, None, X, fma=True)
+    assert_close(out.cpu().numpy(), Co1, RTOL, ATOL, 'spmm_cuda_no_edge_value')
+    D1 = graphgen.features(M, N, 12)
+    o2 = torch.empty(col.shape[0], device='cuda')
+    lib.sddmm_cuda_csr.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 5
+    lib.sddmm_cuda_csr(M, N, col.shape[0], drp.data_ptr(), dcol.data_ptr(), dev(D1).data_ptr(), dX.data_ptr(),
+                       o2.data_ptr())
+    torch.cuda.synchronize()
+    assert_close(o2.cpu().numpy(), oracle.sddmm(rp, col, D1, X, fma=True), RTOL, ATOL, 'sddmm_cuda_csr')
