@@ -98,8 +98,13 @@ extern "C" void gespmmCsrSpMM(const struct SpMatCsrDescr_t A, float *B, const in
     if (hipMemcpy(&last, A.indptr + A.nrow, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return;
     nnz = last;
   }
-  dgs_spmm_csr_f32(DGS_SUM, A.nrow, A.ncol, N, nnz, A.indptr, A.indices, A.data, B, C, nullptr, 0, nullptr, 0,
-                   nullptr);
+  // The reference entry point owns no workspace argument: take it from the stream-ordered allocator on the
+  // default stream (no host synchronisation; cf. the per-call cudaMalloc in the reference's csr2cscKernel).
+  const size_t wsb = dgs_spmm_csr_workspace_bytes(DGS_SUM, A.nrow, N, nnz);
+  void *ws = nullptr;
+  if (wsb && hipMallocAsync(&ws, wsb, nullptr) != hipSuccess) return;
+  dgs_spmm_csr_f32(DGS_SUM, A.nrow, A.ncol, N, nnz, A.indptr, A.indices, A.data, B, C, nullptr, 0, ws, wsb, nullptr);
+  if (ws) (void)hipFreeAsync(ws, nullptr);
 }
 extern "C" void spmm_cuda(int nrowA, int ncolB, int *rowptr, int *colind, float *values, float *dense, float *out) {
   struct SpMatCsrDescr_t A = {nrowA, 0, -1, rowptr, colind, values};
