@@ -1,14 +1,24 @@
-// sddmm.hip -- CSR SDDMM (+ MEAN scaling, + arg mask) for gfx950.
+// sddmm.hip -- CSR SDDMM (+ MEAN scaling, + arg mask) for gfx950, nnz-balanced.
 //   out[e] = sum_k D1[row(e),k] * D2[col(e),k]
-// Replaces sddmmCSR{2,1}Scale<REDUCE> / sddmmCSR1Scale_with_mask (reference include/cuda/sddmm_cuda.cuh:
-// 222-401, 403-507), which are edge-balanced: 4 edges per 32-lane warp slice, a binary search over rowptr per
-// edge (findRow, cuda_util.cuh:150-166) and a re-read of the D1 row for every edge.  Here the schedule is
-// row-group: a group of G lanes x V features owns a row, keeps its D1 slice (and the E slice for the mask
-// variant) in registers for the whole row, streams the row's columns, reduces each dot product across the
-// group with a log2(G) xor-butterfly, and writes G results at a time with one coalesced store.
+// Replaces sddmmCSR{2,1}Scale<REDUCE> / sddmmCSR1Scale_with_mask (reference include/cuda/sddmm_cuda.cuh:222-401,
+// 403-507): edge-balanced, 4 edges per 32-lane warp slice, one binary search over rowptr PER EDGE (findRow,
+// cuda_util.cuh:150-166).
+//
+// Schedule here: one wave per chunk of 256 consecutive nnz (grid-stride), so a 50k-nnz row costs the same per nnz
+// as a 3-nnz row.  Per 64-nnz tile:
+//   * ONE binary search per chunk finds the row of the first nnz; inside the tile the row of every nnz comes from
+//     a merge of the (sorted) next 64 row boundaries with the (sorted) nnz positions: boundary lanes drop a +1 at
+//     their position in an LDS histogram, a wave prefix sum turns it into "rows advanced" - no per-edge search;
+//   * (col,row) pairs are staged in LDS; the NG=64/G groups take interleaved nnz; a group (G lanes x V floats) reads
+//     the D1 row slice and the D2 row slice with coalesced dwordx4 loads (the D1 slice is an L1/L2 hit while the
+//     row lasts), U nnz in flight per group, xor-butterfly per dot product;
+//   * the 64 results go through LDS and leave with one coalesced store.
 #include "dgs_common.h"
 
 namespace dgs {
+
+constexpr int kSdChunk = 256;  // nnz per wave-chunk
+constexpr int kSdU = 4;        // nnz in flight per group
 
 // xor-butterfly over the G lanes of a group (G power of two <= 64): every lane ends with the total.
 template <int G>
@@ -18,101 +28,141 @@ __device__ __forceinline__ float group_allreduce(float x) {
   return x;
 }
 
+__device__ __forceinline__ int wave_incl_scan(int x, int lane) {
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const int t = __shfl_up(x, d, kWave);
+    if (lane >= d) x += t;
+  }
+  return x;
+}
+
 template <int G, int V, bool MEAN, bool MASK>
-__global__ __launch_bounds__(kBlock) void sddmm_rowgroup(int M, int F, int tiles, const int *__restrict__ rowptr,
-                                                         const int *__restrict__ col,
-                                                         const float *__restrict__ D1,
-                                                         const float *__restrict__ D2, const int *__restrict__ E,
-                                                         float *__restrict__ out) {
-  constexpr int ROWS = kBlock / G;
-  const int g = threadIdx.x / G, l = threadIdx.x % G;
-  int64_t row = (int64_t)blockIdx.x * ROWS + g;
-  // Whole groups leave together (row is group-uniform); partial waves keep shuffles inside live groups.
-  if (row >= M) return;
-  const int s = rowptr[row], e = rowptr[row + 1];
-  if (e <= s) return;
-  const float scale = MEAN ? 1.0f / 1.0f : 1.0f;
-  (void)scale;
-  const float deg = (float)(e - s);
-  const int f0 = l * V;
-  const bool live0 = f0 < F;
-  float a0[V];
-  int m0[V];
-#pragma unroll
-  for (int v = 0; v < V; v++) {
-    a0[v] = 0.0f;
-    m0[v] = -2;
-  }
-  if (live0) {
-    load_vec<V>(D1 + row * F + f0, a0);
-    if constexpr (MASK) load_vec<V>(E + row * F + f0, m0);
-  }
-  for (int base = s; base < e; base += G) {
-    float keep = 0.0f;
-    const int cnt = min(G, e - base);
-    for (int j = 0; j < cnt; j++) {
-      const int c = col[base + j];
-      float part = 0.0f;
-      if (live0) {
-        float b[V];
-        load_vec<V>(D2 + (int64_t)c * F + f0, b);
-#pragma unroll
-        for (int v = 0; v < V; v++) {
-          if constexpr (MASK) {
-            if (m0[v] == c) part = __builtin_fmaf(a0[v], b[v], part);
-          } else {
-            part = __builtin_fmaf(a0[v], b[v], part);
-          }
-        }
+__global__ __launch_bounds__(kBlock) void sddmm_nnzbal(int M, int F, int tiles, int nnz,
+                                                       const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                       const float *__restrict__ D1, const float *__restrict__ D2,
+                                                       const int *__restrict__ E, float *__restrict__ out) {
+  constexpr int NG = kWave / G;
+  __shared__ int2 s_tile[kBlock / kWave][kWave];  // {col, row}
+  __shared__ int s_cnt[kBlock / kWave][kWave];    // boundary histogram, then the 64 results (as float bits)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane / G, l = lane % G;
+  int2 *tile = s_tile[wave];
+  int *cnt = s_cnt[wave];
+  const int nchunks = (nnz + kSdChunk - 1) / kSdChunk;
+  const int wstride = gridDim.x * (kBlock / kWave);
+
+  for (int c = blockIdx.x * (kBlock / kWave) + wave; c < nchunks; c += wstride) {
+    const int p0 = c * kSdChunk, p1 = min(nnz, p0 + kSdChunk);
+    // row of p0: last r with rowptr[r] <= p0 (skips empty rows); wave-uniform scalar search
+    int r;
+    {
+      int lo = 0, hi = M;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rowptr[mid] <= p0) lo = mid; else hi = mid - 1;
       }
-      for (int t = 1; t < tiles; t++) {  // F > G*V: further feature tiles, D1/E slices re-read (L1-hot)
-        const int f = (t * G + l) * V;
-        if (f < F) {
-          float a[V], b[V];
-          load_vec<V>(D1 + row * F + f, a);
-          load_vec<V>(D2 + (int64_t)c * F + f, b);
-          if constexpr (MASK) {
-            int m[V];
-            load_vec<V>(E + row * F + f, m);
-#pragma unroll
-            for (int v = 0; v < V; v++)
-              if (m[v] == c) part = __builtin_fmaf(a[v], b[v], part);
-          } else {
-#pragma unroll
-            for (int v = 0; v < V; v++) part = __builtin_fmaf(a[v], b[v], part);
-          }
-        }
-      }
-      const float tot = group_allreduce<G>(part);
-      if (l == j) keep = tot;
+      r = lo;
     }
-    if (l < cnt) {
-      if constexpr (MEAN) keep /= deg;  // sddmm_cuda.cuh:266-272: divide by deg(row(e)) when deg > 0
-      out[base + l] = keep;
+    for (int t0 = p0; t0 < p1; t0 += kWave) {
+      const int cntn = min(kWave, p1 - t0);
+      // ---- rows of the tile's nnz: histogram of row starts falling inside (t0, t0+63], prefix-summed
+      __builtin_amdgcn_wave_barrier();
+      cnt[lane] = 0;
+      __builtin_amdgcn_wave_barrier();
+      int rbase = r;
+      while (true) {
+        const int rr = rbase + 1 + lane;
+        const int bnd = (rr <= M) ? rowptr[rr] : INT_MAX;  // start of row rr (rowptr[M] = nnz ends the last row)
+        const int d = bnd - t0;
+        if (rr < M && d >= 0 && d < kWave) atomicAdd(&cnt[d], 1);
+        const int last_bnd = __shfl(bnd, kWave - 1, kWave);
+        if (last_bnd > t0 + kWave - 1 || rbase + kWave >= M) break;
+        rbase += kWave;  // more than 64 row starts inside this tile (runs of empty rows): keep going
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int adv = wave_incl_scan(cnt[lane], lane);
+      const int myrow = r + adv;
+      int mycol = 0;
+      if (lane < cntn) mycol = ld_stream(col + t0 + lane);
+      __builtin_amdgcn_wave_barrier();
+      tile[lane] = make_int2(mycol, myrow);
+      __builtin_amdgcn_wave_barrier();
+      r = __shfl(myrow, cntn - 1, kWave);  // row of the tile's last nnz: where the next tile starts
+
+      // ---- dot products: group g takes nnz g, g+NG, ...; kSdU of them in flight
+      for (int j0 = g; j0 < cntn; j0 += NG * kSdU) {
+        float part[kSdU];
+        int2 cr[kSdU];
+#pragma unroll
+        for (int q = 0; q < kSdU; q++) {
+          part[q] = 0.0f;
+          cr[q] = tile[min(j0 + q * NG, cntn - 1)];
+        }
+        for (int t = 0; t < tiles; t++) {
+          const int f = (t * G + l) * V;
+          if (f < F) {
+            float a[kSdU][V], b[kSdU][V];
+            int m[kSdU][V];
+#pragma unroll
+            for (int q = 0; q < kSdU; q++) {
+              load_vec<V>(D1 + (int64_t)cr[q].y * F + f, a[q]);
+              load_vec<V>(D2 + (int64_t)cr[q].x * F + f, b[q]);
+              if constexpr (MASK) load_vec<V>(E + (int64_t)cr[q].y * F + f, m[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < kSdU; q++)
+#pragma unroll
+              for (int v = 0; v < V; v++) {
+                if constexpr (MASK) {
+                  if (m[q][v] == cr[q].x) part[q] = __builtin_fmaf(a[q][v], b[q][v], part[q]);
+                } else {
+                  part[q] = __builtin_fmaf(a[q][v], b[q][v], part[q]);
+                }
+              }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < kSdU; q++) {
+          float tot = group_allreduce<G>(part[q]);
+          const int j = j0 + q * NG;
+          if (j < cntn && l == 0) {
+            if constexpr (MEAN) {  // sddmm_cuda.cuh:266-272: divide by deg(row(e)) (always > 0 for a stored entry)
+              const int rw = cr[q].y;
+              tot /= (float)(rowptr[rw + 1] - rowptr[rw]);
+            }
+            cnt[j] = __float_as_int(tot);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < cntn) out[t0 + lane] = __int_as_float(cnt[lane]);
     }
   }
 }
 
 template <int G, int V, bool MEAN, bool MASK>
-static int launch_sddmm(int64_t M, int64_t F, int tiles, const int *rowptr, const int *col, const float *D1,
-                        const float *D2, const int *E, float *out, hipStream_t st) {
-  const dim3 grid((unsigned)((M + (kBlock / G) - 1) / (kBlock / G)));
-  hipLaunchKernelGGL((sddmm_rowgroup<G, V, MEAN, MASK>), grid, dim3(kBlock), 0, st, (int)M, (int)F, tiles, rowptr,
-                     col, D1, D2, E, out);
+static int launch_sddmm(int64_t M, int64_t F, int tiles, int64_t nnz, const int *rowptr, const int *col,
+                        const float *D1, const float *D2, const int *E, float *out, hipStream_t st) {
+  const int64_t nchunks = (nnz + kSdChunk - 1) / kSdChunk;
+  int64_t blocks = (nchunks + (kBlock / kWave) - 1) / (kBlock / kWave);
+  if (blocks > 8192) blocks = 8192;  // persistent beyond this: waves stride over the chunks
+  hipLaunchKernelGGL((sddmm_nnzbal<G, V, MEAN, MASK>), dim3((unsigned)blocks), dim3(kBlock), 0, st, (int)M, (int)F,
+                     tiles, (int)nnz, rowptr, col, D1, D2, E, out);
   return check_launch();
 }
 
 template <int V, bool MEAN, bool MASK>
-static int dispatch_sddmm(int G, int64_t M, int64_t F, int tiles, const int *rowptr, const int *col, const float *D1,
-                          const float *D2, const int *E, float *out, hipStream_t st) {
+static int dispatch_sddmm(int G, int64_t M, int64_t F, int tiles, int64_t nnz, const int *rowptr, const int *col,
+                          const float *D1, const float *D2, const int *E, float *out, hipStream_t st) {
   switch (G) {
-    case 1: return launch_sddmm<1, V, MEAN, MASK>(M, F, tiles, rowptr, col, D1, D2, E, out, st);
-    case 2: return launch_sddmm<2, V, MEAN, MASK>(M, F, tiles, rowptr, col, D1, D2, E, out, st);
-    case 4: return launch_sddmm<4, V, MEAN, MASK>(M, F, tiles, rowptr, col, D1, D2, E, out, st);
-    case 8: return launch_sddmm<8, V, MEAN, MASK>(M, F, tiles, rowptr, col, D1, D2, E, out, st);
-    case 16: return launch_sddmm<16, V, MEAN, MASK>(M, F, tiles, rowptr, col, D1, D2, E, out, st);
-    case 32: return launch_sddmm<32, V, MEAN, MASK>(M, F, tiles, rowptr, col, D1, D2, E, out, st);
-    case 64: return launch_sddmm<64, V, MEAN, MASK>(M, F, tiles, rowptr, col, D1, D2, E, out, st);
+    case 1: return launch_sddmm<1, V, MEAN, MASK>(M, F, tiles, nnz, rowptr, col, D1, D2, E, out, st);
+    case 2: return launch_sddmm<2, V, MEAN, MASK>(M, F, tiles, nnz, rowptr, col, D1, D2, E, out, st);
+    case 4: return launch_sddmm<4, V, MEAN, MASK>(M, F, tiles, nnz, rowptr, col, D1, D2, E, out, st);
+    case 8: return launch_sddmm<8, V, MEAN, MASK>(M, F, tiles, nnz, rowptr, col, D1, D2, E, out, st);
+    case 16: return launch_sddmm<16, V, MEAN, MASK>(M, F, tiles, nnz, rowptr, col, D1, D2, E, out, st);
+    case 32: return launch_sddmm<32, V, MEAN, MASK>(M, F, tiles, nnz, rowptr, col, D1, D2, E, out, st);
+    case 64: return launch_sddmm<64, V, MEAN, MASK>(M, F, tiles, nnz, rowptr, col, D1, D2, E, out, st);
   }
   return DGS_EINVAL;
 }
@@ -127,8 +177,8 @@ static int run_sddmm(int64_t M, int64_t K, int64_t F, int64_t nnz, const int *ro
   if (F == 0) return hipMemsetAsync(out, 0, (size_t)nnz * sizeof(float), st) == hipSuccess ? DGS_OK : DGS_ELAUNCH;
   const bool al = is_aligned16(D1) && is_aligned16(D2) && (!MASK || is_aligned16(E));
   const FeatMap fm = feat_map(F, al);
-  if (fm.V == 4) return dispatch_sddmm<4, MEAN, MASK>(fm.G, M, F, fm.tiles, rowptr, col, D1, D2, E, out, st);
-  return dispatch_sddmm<1, MEAN, MASK>(fm.G, M, F, fm.tiles, rowptr, col, D1, D2, E, out, st);
+  if (fm.V == 4) return dispatch_sddmm<4, MEAN, MASK>(fm.G, M, F, fm.tiles, nnz, rowptr, col, D1, D2, E, out, st);
+  return dispatch_sddmm<1, MEAN, MASK>(fm.G, M, F, fm.tiles, nnz, rowptr, col, D1, D2, E, out, st);
 }
 
 }  // namespace dgs
