@@ -1,0 +1,22 @@
+import sys, time, torch
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/dgsparse-lib_amd')
+from bench import graphgen
+from dgsparse import _capi
+import dgsparse
+for name in ['cora','pubmed']:
+    rp,col,st=graphgen.dataset_shaped(name,device='cuda',as_torch=True)
+    val=torch.ones(st['nnz'],device='cuda'); X=torch.rand(st['K'],64,device='cuda')
+    for _ in range(20): _capi.spmm(0,rp,col,val,X)
+    torch.cuda.synchronize(); t=time.perf_counter()
+    for _ in range(1000): _capi.spmm(0,rp,col,val,X)
+    t1=time.perf_counter()-t; torch.cuda.synchronize(); t2=time.perf_counter()-t
+    print(name,'host enqueue us/call',t1/1000*1e6,'total us/call',t2/1000*1e6)
+    tcsr=torch.sparse_csr_tensor(rp,col,val,size=(st['M'],st['K']))
+    A=dgsparse.SparseTensor.from_torch_sparse_csr_tensor(tcsr,True)
+    for _ in range(20): dgsparse.spmm_sum(A,X,0)
+    torch.cuda.synchronize(); t=time.perf_counter()
+    for _ in range(1000): dgsparse.spmm_sum(A,X,0)
+    torch.cuda.synchronize(); print(name,'dgsparse.spmm_sum us/call',(time.perf_counter()-t)/1000*1e6)
+    t=time.perf_counter()
+    for _ in range(1000): torch.sparse.mm(tcsr,X)
+    torch.cuda.synchronize(); print(name,'torch.sparse.mm (hipSPARSE) us/call',(time.perf_counter()-t)/1000*1e6)

@@ -38,7 +38,7 @@
 //   Measured on MI355X (profiles/): the fused kernel is bound by the L2-miss path (~6.5 TB/s of 128-B fabric
 //   reads at a ~30% L2 hit rate on the 1M x 1M power-law graph); see DESIGN.md for the ladder that led here.
 //
-//   spmm_rowgroup_seq (the first, single-kernel version) is kept for tiny problems.
+//   spmm_small: inputs up to 2^18 nnz / 2^16 rows take ONE launch (row blocks only, long rows reduced in place).
 #include "dgs_common.h"
 
 namespace dgs {
@@ -263,8 +263,9 @@ struct RowsLds {
   int4 rows[kBlock / kWave][kRowsPerWave + 1];  // {start, end, next non-empty short row, -}
 };
 
-template <int G, int V, int OP, bool HAS_VAL>
-__device__ __forceinline__ void spmm_rows_body(int bid, RowsLds &lds, int M, int N, const int *__restrict__ rowptr,
+template <int G, int V, int OP, bool HAS_VAL, bool INLINE>
+__device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, int M, int N,
+                                               const int *__restrict__ rowptr,
                                                const int *__restrict__ col, const float *__restrict__ val,
                                                const float *__restrict__ B, float *__restrict__ C,
                                                int *__restrict__ E) {
@@ -272,11 +273,11 @@ __device__ __forceinline__ void spmm_rows_body(int bid, RowsLds &lds, int M, int
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane / G, l = lane % G;
-  const int r0 = (bid * (kBlock / kWave) + wave) * kRowsPerWave;
+  const int r0 = (bid * (kBlock / kWave) + wave) * rpw;  // rpw <= 64 rows per wave (fewer on small inputs)
   if (r0 >= M) return;  // wave-uniform
   int2 *tile = lds.tile[wave];
   int4 *rows = lds.rows[wave];
-  const int nrows = min(kRowsPerWave, M - r0);
+  const int nrows = min(rpw, M - r0);
   const int f0 = (blockIdx.y * G + l) * V;
   const bool fl = f0 < N;
 
@@ -287,7 +288,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, RowsLds &lds, int M, int
   }
   const int len_i = e_i - s_i;
   const bool long_i = len_i > kT1;   // not streamed: medium (whole wave, below) or huge (unit table)
-  const bool huge_i = len_i > kT2;
+  const bool huge_i = !INLINE && len_i > kT2;  // INLINE (small inputs, single launch): no unit table at all
   const bool live_i = lane < nrows && len_i > 0 && !long_i;  // non-empty short row: produces output in the stream
   {
     // index of the next live row after this lane's row (64 = none)
@@ -527,7 +528,19 @@ __global__ __launch_bounds__(kBlock) void spmm_fused(int M, int N, int ch, int n
     spmm_units_body<G, V, OP, HAS_VAL>(blockIdx.x, nbu, lds, N, ch, rowptr, col, val, B, C, E, hdr, units, part,
                                        parte);
   else
-    spmm_rows_body<G, V, OP, HAS_VAL>(blockIdx.x - nbu, lds, M, N, rowptr, col, val, B, C, E);
+    spmm_rows_body<G, V, OP, HAS_VAL, false>(blockIdx.x - nbu, kRowsPerWave, lds, M, N, rowptr, col, val, B, C, E);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Small inputs (the Cora/Citeseer/Pubmed/PPI class: a few 10^4 rows, <= 2.6e5 nnz) finish in a few microseconds,
+// so launch count is what matters: ONE launch, row blocks only, every long row reduced by its whole wave in place.
+template <int G, int V, int OP, bool HAS_VAL>
+__global__ __launch_bounds__(kBlock) void spmm_small(int M, int N, int rpw, const int *__restrict__ rowptr,
+                                                     const int *__restrict__ col, const float *__restrict__ val,
+                                                     const float *__restrict__ B, float *__restrict__ C,
+                                                     int *__restrict__ E) {
+  __shared__ RowsLds lds;
+  spmm_rows_body<G, V, OP, HAS_VAL, true>(blockIdx.x, rpw, lds, M, N, rowptr, col, val, B, C, E);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -614,70 +627,6 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Single-kernel version (no workspace): one group per row, sequential, 4-deep unroll.  Used for tiny inputs.
-template <int G, int V, int OP, bool HAS_VAL>
-__global__ __launch_bounds__(kBlock) void spmm_rowgroup_seq(int M, int N, const int *__restrict__ rowptr,
-                                                            const int *__restrict__ col,
-                                                            const float *__restrict__ val,
-                                                            const float *__restrict__ B, float *__restrict__ C,
-                                                            int *__restrict__ E) {
-  constexpr int ROWS = kBlock / G;
-  constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
-  const int g = threadIdx.x / G, l = threadIdx.x % G;
-  const int64_t row = (int64_t)blockIdx.x * ROWS + g;
-  const int f0 = (blockIdx.y * G + l) * V;
-  if (row >= M || f0 >= N) return;
-  const int s = rowptr[row], e = rowptr[row + 1];
-
-  float acc[V];
-  int ei[V];
-#pragma unroll
-  for (int v = 0; v < V; v++) {
-    acc[v] = reduce_init<OP>();
-    ei[v] = -1;
-  }
-  const float *Bf = B + f0;
-  constexpr int U = 4;
-  int p = s;
-  for (; p + U <= e; p += U) {
-    int c[U];
-    float w[U];
-    float x[U][V];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      c[u] = col[p + u];
-      w[u] = HAS_VAL ? val[p + u] : 1.0f;
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) load_vec<V>(Bf + (int64_t)c[u] * N, x[u]);
-#pragma unroll
-    for (int u = 0; u < U; u++)
-#pragma unroll
-      for (int v = 0; v < V; v++) reduce_step<OP>(acc[v], ei[v], w[u], x[u][v], c[u]);
-  }
-  for (; p < e; p++) {
-    const int c = col[p];
-    const float w = HAS_VAL ? val[p] : 1.0f;
-    float x[V];
-    load_vec<V>(Bf + (int64_t)c * N, x);
-#pragma unroll
-    for (int v = 0; v < V; v++) reduce_step<OP>(acc[v], ei[v], w, x[v], c);
-  }
-  if (e > s) {
-    if constexpr (OP == DGS_MEAN) {
-      const float d = (float)(e - s);
-#pragma unroll
-      for (int v = 0; v < V; v++) acc[v] /= d;
-    }
-  } else {  // empty row: 0 and E = -1 (spmm_cuda.cuh:49-51)
-#pragma unroll
-    for (int v = 0; v < V; v++) acc[v] = 0.0f;
-  }
-  store_vec<V>(C + row * N + f0, acc);
-  if constexpr (ARG) store_vec<V>(E + row * N + f0, ei);
-}
-
-// ---------------------------------------------------------------------------------------------------------
 struct SpmmArgs {
   int64_t M, N, nnz;
   const int *rowptr, *col;
@@ -693,8 +642,13 @@ struct SpmmArgs {
 template <int G, int V, int OP, bool HAS_VAL>
 static int launch_all(const SpmmArgs &a) {
   if (!a.ws) {
-    const dim3 grid((unsigned)((a.M + (kBlock / G) - 1) / (kBlock / G)), (unsigned)a.tiles);
-    hipLaunchKernelGGL((spmm_rowgroup_seq<G, V, OP, HAS_VAL>), grid, dim3(kBlock), 0, a.st, (int)a.M, (int)a.N,
+    // fewer rows per wave on small inputs: parallelism (>= ~2k waves) matters more than staging efficiency
+    constexpr int NGc = kWave / G;
+    int rpw = kRowsPerWave;
+    while (rpw > NGc && rpw > 4 && (a.M + rpw - 1) / rpw < 2048) rpw >>= 1;
+    const int rpb = (kBlock / kWave) * rpw;
+    const dim3 grid((unsigned)((a.M + rpb - 1) / rpb), (unsigned)a.tiles);
+    hipLaunchKernelGGL((spmm_small<G, V, OP, HAS_VAL>), grid, dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, rpw,
                        a.rowptr, a.col, a.val, a.B, a.C, a.E);
     return check_launch();
   }
@@ -754,8 +708,8 @@ static int dispatch_g(int G, const SpmmArgs &a) {
   return DGS_EINVAL;
 }
 
-// Inputs this small finish in a few microseconds in the single kernel; three launches would only add latency.
-static inline bool tiny_problem(int64_t M, int64_t nnz) { return nnz <= 4096 && M <= 4096; }
+// Inputs this small finish in a few microseconds: launch count dominates, so they take the single-launch path.
+static inline bool tiny_problem(int64_t M, int64_t nnz) { return nnz <= (1 << 18) && M <= (1 << 16); }
 
 }  // namespace dgs
 

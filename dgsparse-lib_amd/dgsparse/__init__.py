@@ -11,6 +11,7 @@ from .sddmm import sddmm
 from .spmm import spmm_max, spmm_mean, spmm_min, spmm_sum
 from .storage import Storage
 from .tensor import SparseTensor
+from . import nn  # noqa: F401,E402
 
 __version__ = '0.1'
 

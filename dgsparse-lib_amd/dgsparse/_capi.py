@@ -85,13 +85,13 @@ def _need_gpu(*ts) -> torch.device:
 def _i32(t, name):
     if t.dtype != torch.int32 or t.dim() != 1:
         raise TypeError(f'dgsparse: {name} must be a 1-D int32 tensor (got {t.dtype}, dim {t.dim()})')
-    return t.contiguous()
+    return t if t.is_contiguous() else t.contiguous()
 
 
 def _f32mat(t, name):
     if t.dtype != torch.float32 or t.dim() != 2:
         raise TypeError(f'dgsparse: {name} must be a 2-D float32 tensor (got {t.dtype}, dim {t.dim()})')
-    return t.contiguous()
+    return t if t.is_contiguous() else t.contiguous()
 
 
 def _f32vec(t, name, n):
@@ -109,8 +109,29 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream(dev):
+    if _raw_stream is not None:  # ~0.3 us instead of ~1.5 us through torch.cuda.current_stream()
+        return _raw_stream(dev.index if dev.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _on_device:
+    """``with torch.cuda.device(dev)`` only when dev is not already current (the context manager costs ~5 us)."""
+    __slots__ = ('ctx',)
+
+    def __init__(self, dev):
+        self.ctx = None if (dev.index is None or dev.index == torch.cuda.current_device()) else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
 
 
 def spmm(reduce_op, rowptr, col, values, dense, algorithm=0, want_E=None):
@@ -126,7 +147,7 @@ def spmm(reduce_op, rowptr, col, values, dense, algorithm=0, want_E=None):
     arg = reduce_op in (MAX, MIN) if want_E is None else want_E
     out = torch.empty((M, N), dtype=torch.float32, device=dev)
     E = torch.empty((M, N), dtype=torch.int32, device=dev) if arg else None
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         wsb = _lib.dgs_spmm_csr_workspace_bytes(reduce_op, M, N, nnz)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
         _check(_lib.dgs_spmm_csr_f32(reduce_op, M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(dense), _p(out),
@@ -149,7 +170,7 @@ def spmm_mask(ptr, idx, values, grad, E, n_out=None):
     out = torch.empty((rows, N), dtype=torch.float32, device=dev)
     if rows > Mo:
         out[Mo:].zero_()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _check(_lib.dgs_spmm_csr_mask_f32(Mo, Mi, N, nnz, _p(ptr), _p(idx), _p(values), _p(grad), _p(E), _p(out),
                                           _stream(dev)), 'spmm_mask')
     return out
@@ -166,7 +187,7 @@ def sddmm(rowptr, col, D1, D2, reduce_op=SUM, E=None):
     if D2.shape[1] != F or D1.shape[0] < M:
         raise ValueError(f'dgsparse: sddmm shape mismatch D1 {tuple(D1.shape)} D2 {tuple(D2.shape)} rows {M}')
     out = torch.empty(nnz, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         if E is not None:
             if E.dtype != torch.int32 or E.shape != D1.shape:
                 raise TypeError('dgsparse: E must be int32 with the shape of D1')
@@ -189,7 +210,7 @@ def csr2csc(rowptr, col, values, n_cols, want_perm=True):
     row = torch.empty(nnz, dtype=torch.int32, device=dev)
     cscval = torch.empty(nnz, dtype=torch.float32, device=dev) if values is not None else None
     perm = torch.empty(nnz, dtype=torch.int32, device=dev) if want_perm else None
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         wsb = _lib.dgs_csr2csc_workspace_bytes(M, n_cols, nnz)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         _check(_lib.dgs_csr2csc_i32(M, n_cols, nnz, _p(rowptr), _p(col), _p(values), _p(colptr), _p(row), _p(cscval),
@@ -202,7 +223,7 @@ def gather_rows(src, ids):
     src = _f32mat(src, 'src')
     ids = _i32(ids, 'ids')
     out = torch.empty((ids.numel(), src.shape[1]), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _check(_lib.dgs_gather_rows_f32(ids.numel(), src.shape[1], _p(ids), _p(src), _p(out), _stream(dev)), 'gather')
     return out
 
@@ -212,7 +233,7 @@ def scatter_add_rows(dst, ids, src):
     assert dst.is_contiguous() and dst.dtype == torch.float32
     src = _f32mat(src, 'src')
     ids = _i32(ids, 'ids')
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _check(_lib.dgs_scatter_add_rows_f32(ids.numel(), src.shape[1], _p(ids), _p(src), _p(dst), _stream(dev)),
                'scatter_add')
     return dst
