@@ -15,6 +15,7 @@ SHAPES = {
     'citeseer': dict(M=3327, nnz=9104, dmax=99, alpha=2.8),
     'pubmed': dict(M=19717, nnz=88648, dmax=171, alpha=2.6),
     'ppi': dict(M=56944, nnz=1612348, dmax=721, alpha=2.9),
+    'ppi0': dict(M=1767, nnz=32318, dmax=200, alpha=2.9),  # graph 0 of PPI = what test/utils.py:36-38 loads
     'arxiv': dict(M=169343, nnz=1166243, dmax=13161, alpha=2.1),
     'reddit': dict(M=232965, nnz=114615892, dmax=21657, alpha=3.5),
     'products': dict(M=2449029, nnz=61859140, dmax=17481, alpha=2.4),

@@ -111,3 +111,27 @@ def test_dist_engine_single_rank_on_gpu():
         assert torch.equal(C, Cr)
         if red == 'max':
             assert torch.equal(eng.last_E, Er)
+
+
+def test_standalone_cabi_driver_on_mtx(tmp_path):
+    """examples/spmm_mtx (C++ over the C ABI, the counterpart of example/ge-spmm/spmm.cu): builds, loads a
+    MatrixMarket file, self-checks all four reduces + SDDMM against its host loop."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(['make', '-s', '-C', os.path.join(root, 'examples')])
+    import numpy as np
+    rng = np.random.default_rng(0)
+    n = 3000
+    deg = np.minimum(rng.zipf(1.7, n), 1500)
+    rows = np.repeat(np.arange(n), deg)
+    cols = rng.integers(0, n, rows.shape[0])
+    ent = sorted({(int(max(a, b)), int(min(a, b))) for a, b in zip(rows, cols)})
+    p = str(tmp_path / 'g.mtx')
+    with open(p, 'w') as f:
+        f.write('%%MatrixMarket matrix coordinate pattern symmetric\n')
+        f.write(f'{n} {n} {len(ent)}\n')
+        f.writelines(f'{a + 1} {b + 1}\n' for a, b in ent)
+    out = subprocess.run([os.path.join(root, 'examples', 'spmm_mtx'), p, '48'], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count('passed') == 5 and 'FAILED' not in out.stdout
