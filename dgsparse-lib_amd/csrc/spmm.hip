@@ -43,6 +43,12 @@
 
 namespace dgs {
 
+// Internal fifth reduce op: masked sum = backward of max/min w.r.t. the dense operand, run on the CSC arrays:
+//   out[j,f] = sum_p [Em[idx[p],f] == j] * val[p] * G[idx[p],f]
+// (reference csrspmm_seqreduce_rowbalance_with_mask_kernel, include/cuda/spmm_cuda.cuh:400-433; the formula, not that
+// kernel's stale-variable behaviour).  Same schedule as the forward; the E pointer carries the saved arg ids (input).
+constexpr int kOpMaskSum = 4;
+
 // ---------------------------------------------------------------------------------------------------------
 // tuning constants
 #ifndef DGS_T1
@@ -214,8 +220,8 @@ __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, const int
 template <int G, int V, int OP, bool HAS_VAL>
 __device__ __forceinline__ void coop_accumulate(int p0, int p1, int lane, int g, int f0, bool fl, int N,
                                                 const int *__restrict__ col, const float *__restrict__ val,
-                                                const float *__restrict__ B, int2 *tile, float (&acc)[V],
-                                                int (&ei)[V], int (&ep)[V]) {
+                                                const float *__restrict__ B, const int *__restrict__ Em, int orow,
+                                                int2 *tile, float (&acc)[V], int (&ei)[V], int (&ep)[V]) {
   constexpr int NG = kWave / G;
   for (int t0 = p0; t0 < p1; t0 += kWave) {
     const int cnt = min(kWave, p1 - t0);
@@ -230,6 +236,7 @@ __device__ __forceinline__ void coop_accumulate(int p0, int p1, int lane, int g,
       int c[kU];
       float w[kU];
       float x[kU][V];
+      int m[kU][V];
 #pragma unroll
       for (int q = 0; q < kU; q++) {
         if (j + q * NG < cnt) {
@@ -240,13 +247,21 @@ __device__ __forceinline__ void coop_accumulate(int p0, int p1, int lane, int g,
       }
 #pragma unroll
       for (int q = 0; q < kU; q++)
-        if (j + q * NG < cnt && fl) load_vec<V>(B + (int64_t)c[q] * N + f0, x[q]);
+        if (j + q * NG < cnt && fl) {
+          load_vec<V>(B + (int64_t)c[q] * N + f0, x[q]);
+          if constexpr (OP == kOpMaskSum) load_vec<V>(Em + (int64_t)c[q] * N + f0, m[q]);
+        }
 #pragma unroll
       for (int q = 0; q < kU; q++)
         if (j + q * NG < cnt && fl) {
 #pragma unroll
-          for (int v = 0; v < V; v++)
-            reduce_step_pos<OP>(acc[v], ei[v], ep[v], w[q], x[q][v], c[q], t0 + j + q * NG);
+          for (int v = 0; v < V; v++) {
+            if constexpr (OP == kOpMaskSum) {
+              if (m[q][v] == orow) acc[v] = __builtin_fmaf(w[q], x[q][v], acc[v]);
+            } else {
+              reduce_step_pos<OP>(acc[v], ei[v], ep[v], w[q], x[q][v], c[q], t0 + j + q * NG);
+            }
+          }
         }
     }
   }
@@ -391,10 +406,13 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
       const int last = pe - 1;
       int2 cv[kU1];
       float x[kU1][V];
+      int mk[kU1][V];
+      const int *El = E + (fl ? f0 : 0);
 #pragma unroll
       for (int u = 0; u < kU1; u++) {
         cv[u] = tile[min(ps + u, last)];
         load_vec<V>(Bl + (int64_t)(cv[u].x & 0x7fffffff) * N, x[u]);
+        if constexpr (OP == kOpMaskSum) load_vec<V>(El + (int64_t)(cv[u].x & 0x7fffffff) * N, mk[u]);
       }
       for (int p = ps; p < pe; p += kU1) {
 #pragma unroll
@@ -404,7 +422,13 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
             const int c = cvu.x & 0x7fffffff;
             const float w = __int_as_float(cvu.y);
 #pragma unroll
-            for (int v = 0; v < V; v++) reduce_step<OP>(acc[v], ei[v], w, x[u][v], c);
+            for (int v = 0; v < V; v++) {
+              if constexpr (OP == kOpMaskSum) {
+                if (mk[u][v] == r0 + cur) acc[v] = __builtin_fmaf(w, x[u][v], acc[v]);
+              } else {
+                reduce_step<OP>(acc[v], ei[v], w, x[u][v], c);
+              }
+            }
             if (cvu.x < 0) {  // last nnz of row `cur` (group-uniform)
               const int4 q = rows[cur];
               if constexpr (OP == DGS_MEAN) {
@@ -427,6 +451,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
           // refill the slot just consumed (same registers: no copies, so the waits stay counted)
           cv[u] = tile[min(p + u + kU1, last)];
           load_vec<V>(Bl + (int64_t)(cv[u].x & 0x7fffffff) * N, x[u]);
+          if constexpr (OP == kOpMaskSum) load_vec<V>(El + (int64_t)(cv[u].x & 0x7fffffff) * N, mk[u]);
         }
       }
     }
@@ -447,7 +472,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
       ei[v] = -1;
       ep[v] = INT_MAX;
     }
-    coop_accumulate<G, V, OP, HAS_VAL>(rs, re, lane, g, f0, fl, N, col, val, B, tile, acc, ei, ep);
+    coop_accumulate<G, V, OP, HAS_VAL>(rs, re, lane, g, f0, fl, N, col, val, B, E, r0 + r, tile, acc, ei, ep);
     cross_group_reduce<G, V, OP>(acc, ei, ep);
     if (g == 0 && fl) {
       if constexpr (OP == DGS_MEAN) {
@@ -492,7 +517,7 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
       ei[v] = -1;
       ep[v] = INT_MAX;
     }
-    coop_accumulate<G, V, OP, HAS_VAL>(p0, p1, lane, g, f0, fl, N, col, val, B, tile, acc, ei, ep);
+    coop_accumulate<G, V, OP, HAS_VAL>(p0, p1, lane, g, f0, fl, N, col, val, B, E, d.x, tile, acc, ei, ep);
     cross_group_reduce<G, V, OP>(acc, ei, ep);
     if (g == 0 && fl) {
       if (d.w == 1) {  // the whole row was this unit: final result
@@ -690,6 +715,7 @@ static int dispatch_op(const SpmmArgs &a) {
     case DGS_MAX: return dispatch_val<G, V, DGS_MAX>(a);
     case DGS_MIN: return dispatch_val<G, V, DGS_MIN>(a);
     case DGS_MEAN: return dispatch_val<G, V, DGS_MEAN>(a);
+    case kOpMaskSum: return dispatch_val<G, V, kOpMaskSum>(a);
   }
   return DGS_EINVAL;
 }
@@ -739,6 +765,28 @@ extern "C" int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, 
                   (need == 0 || is_aligned16(workspace));
   const FeatMap fm = feat_map(N, al);
   SpmmArgs a{M, N, nnz, rowptr, col, val, B, C, arg ? E : nullptr, fm.tiles, need ? workspace : nullptr, st, reduce_op};
+  if (fm.V == 4) return dispatch_g<4>(fm.G, a);
+  return dispatch_g<1>(fm.G, a);
+}
+
+// Masked SpMM (max/min backward w.r.t. the dense operand) on the CSC arrays: same launcher, internal op kOpMaskSum.
+extern "C" size_t dgs_spmm_csr_mask_workspace_bytes(int64_t Mout, int64_t N, int64_t nnz) {
+  return dgs_spmm_csr_workspace_bytes(DGS_SUM, Mout, N, nnz);
+}
+
+extern "C" int dgs_spmm_csr_mask_f32(int64_t Mout, int64_t Min, int64_t N, int64_t nnz, const int32_t *ptr,
+                                     const int32_t *idx, const float *val, const float *G, const int32_t *E,
+                                     float *out, void *workspace, size_t workspace_bytes, dgsStream_t stream) {
+  if (Mout < 0 || Min < 0 || N < 0 || nnz < 0) return DGS_EINVAL;
+  if (Mout >= INT32_MAX || Min >= INT32_MAX || N >= INT32_MAX || nnz >= INT32_MAX) return DGS_ERANGE;
+  if (Mout == 0 || N == 0) return DGS_OK;
+  if (!ptr || !out || (nnz > 0 && (!idx || !G || !E))) return DGS_EINVAL;
+  const size_t need = dgs_spmm_csr_mask_workspace_bytes(Mout, N, nnz);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return DGS_EWORKSPACE;
+  const bool al = is_aligned16(G) && is_aligned16(E) && is_aligned16(out) && (need == 0 || is_aligned16(workspace));
+  const FeatMap fm = feat_map(N, al);
+  SpmmArgs a{Mout, N, nnz, ptr, idx, val, G, out, const_cast<int32_t *>(E), fm.tiles, need ? workspace : nullptr,
+             static_cast<hipStream_t>(stream), kOpMaskSum};
   if (fm.V == 4) return dispatch_g<4>(fm.G, a);
   return dispatch_g<1>(fm.G, a);
 }

@@ -34,7 +34,9 @@ _lib.dgs_spmm_csr_workspace_bytes.argtypes = [_int, _i64, _i64, _i64]
 _lib.dgs_spmm_csr_f32.restype = _int
 _lib.dgs_spmm_csr_f32.argtypes = [_int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _sz, _vp]
 _lib.dgs_spmm_csr_mask_f32.restype = _int
-_lib.dgs_spmm_csr_mask_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+_lib.dgs_spmm_csr_mask_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
+_lib.dgs_spmm_csr_mask_workspace_bytes.restype = _sz
+_lib.dgs_spmm_csr_mask_workspace_bytes.argtypes = [_i64, _i64, _i64]
 _lib.dgs_sddmm_csr_f32.restype = _int
 _lib.dgs_sddmm_csr_f32.argtypes = [_int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]
 _lib.dgs_sddmm_csr_mask_f32.restype = _int
@@ -49,7 +51,7 @@ _lib.dgs_scatter_add_rows_f32.restype = _int
 _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
 EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
-           'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
+           'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
            'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'gespmmCsrSpMM', 'spmm_cuda',
            'spmm_cuda_no_edge_value', 'sddmm_cuda_csr']
 
@@ -171,8 +173,10 @@ def spmm_mask(ptr, idx, values, grad, E, n_out=None):
     if rows > Mo:
         out[Mo:].zero_()
     with _on_device(dev):
+        wsb = _lib.dgs_spmm_csr_mask_workspace_bytes(Mo, N, nnz)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
         _check(_lib.dgs_spmm_csr_mask_f32(Mo, Mi, N, nnz, _p(ptr), _p(idx), _p(values), _p(grad), _p(E), _p(out),
-                                          _stream(dev)), 'spmm_mask')
+                                          _p(ws), wsb, _stream(dev)), 'spmm_mask')
     return out
 
 

@@ -11,7 +11,9 @@ with ONE all-to-all-v:
                         local CSR re-labelled into the extended index space [local rows | halo slots]
     per call pack   : gather_rows(B_loc, send_ids)            (HIP kernel dgs_gather_rows_f32)
              exchange: all_to_all_single(B_ext[Mloc:], packed, recv_splits, send_splits)   (RCCL)
-             compute : C = spmm(A_ext, B_ext)                  (the single-GPU kernels, unchanged numerics)
+             compute : sum/mean: C = spmm(A_loc, B_loc) WHILE the exchange is in flight (RCCL runs on its own
+                                 stream), then C += spmm(A_rem, B_halo)      [A = A_loc + A_rem by column owner]
+                       max/min : C, E = spmm(A_ext, B_ext) after the exchange (one pass keeps first-wins ties exact)
 
 xGMI is point-to-point (7 links per GPU), so an all-to-all uses every link at once - the right collective shape for
 this fabric; there is no all-reduce anywhere.  Only feature rows travel; the graph never does.
@@ -142,6 +144,20 @@ class HaloPlan:
         self.recv_splits = recv_splits.tolist()
         self.n_halo = int(rem.numel())
         self.ext2glob = torch.cat([torch.arange(part.r0, part.r0 + part.n_local, device=dev), rem])
+        # A = A_loc + A_rem (same rows): lets the local product run while the halo is still in flight
+        nl = part.n_local
+        counts = (part.rowptr[1:] - part.rowptr[:-1]).long()
+        rows = torch.repeat_interleave(torch.arange(nl, device=dev), counts)
+
+        def _sub(mask, shift):
+            rp = torch.zeros(nl + 1, dtype=torch.int64, device=dev)
+            rp[1:] = torch.cumsum(torch.bincount(rows[mask], minlength=nl), 0)
+            return (rp.to(torch.int32), (ext[mask] - shift).to(torch.int32).contiguous(),
+                    None if part.val is None else part.val[mask].contiguous())
+
+        self.loc = _sub(~is_remote, 0)
+        self.rem = _sub(is_remote, nl)
+        self.deg = counts.clamp(min=1).to(torch.float32)
         if world == 1:  # nothing to exchange; no process group needed
             self.send_splits = [0]
             self.send_ids = torch.zeros(0, dtype=torch.int32, device=dev)
@@ -177,8 +193,8 @@ class DistSpMM:
     """C_loc = reduce(A_loc_rows (*) B_global) with B row-partitioned like A.  ``ops`` is injectable so that the
     exchange logic can be exercised on CPU/gloo with a stand-in compute back end (tests only)."""
 
-    def __init__(self, part: RowPartition, n_feat: int, ops=None, group=None):
-        self.part, self.N, self.group = part, n_feat, group
+    def __init__(self, part: RowPartition, n_feat: int, ops=None, group=None, overlap: bool = True):
+        self.part, self.N, self.group, self.overlap = part, n_feat, group, overlap
         self.ops = ops if ops is not None else _HipOps()
         self.plan = HaloPlan(part, group)
         self.n_halo = self.plan.n_halo
@@ -195,18 +211,35 @@ class DistSpMM:
         """View of the first n_local rows of the exchange buffer: fill it in place to skip the copy in spmm()."""
         return self.B_ext[:self.part.n_local]
 
-    def exchange(self, B_loc: torch.Tensor) -> torch.Tensor:
+    def exchange(self, B_loc: torch.Tensor, async_op: bool = False):
+        """Pack + all-to-all-v of the halo rows into B_ext[n_local:].  Returns (B_ext, work handle or None)."""
         p, plan = self.part, self.plan
         if B_loc.data_ptr() != self.B_ext.data_ptr():
             self.B_ext[:p.n_local].copy_(B_loc)
+        work = None
         if p.world > 1:
-            packed = self.ops.gather_rows(self.B_ext[:p.n_local], plan.send_ids)
-            _all_to_all_v(self.B_ext[p.n_local:], packed, plan.recv_splits, plan.send_splits, self.group)
-        return self.B_ext
+            self._packed = self.ops.gather_rows(self.B_ext[:p.n_local], plan.send_ids)  # kept alive until waited
+            work = dist.all_to_all_single(self.B_ext[p.n_local:], self._packed, plan.recv_splits, plan.send_splits,
+                                          group=self.group, async_op=async_op)
+        return self.B_ext, work
 
     def spmm(self, B_loc: torch.Tensor, reduce: str = 'sum') -> torch.Tensor:
-        B_ext = self.exchange(B_loc)
+        p, plan = self.part, self.plan
+        if self.overlap and p.world > 1 and reduce in ('sum', 'mean'):
+            B_ext, work = self.exchange(B_loc, async_op=True)
+            C, _ = self.ops.spmm(0, plan.loc[0], plan.loc[1], plan.loc[2], B_ext[:p.n_local])  # overlaps the exchange
+            if work is not None:
+                work.wait()  # current stream waits for the collective; the host does not block
+            if self.n_halo > 0:
+                Cr, _ = self.ops.spmm(0, plan.rem[0], plan.rem[1], plan.rem[2], B_ext[p.n_local:])
+                C += Cr
+            if reduce == 'mean':
+                C /= plan.deg[:, None]
+            self.last_E = None
+            return C
+        B_ext, _ = self.exchange(B_loc)
         C, E = self.ops.spmm(_OPS[reduce], self.part.rowptr, self.plan.col_ext, self.part.val, B_ext)
+        self.last_E = None
         if E is not None:  # ext ids -> global column ids (-1 stays -1)
             g = self.plan.ext2glob[E.clamp(min=0).long()].to(torch.int32)
             self.last_E = torch.where(E >= 0, g, E)

@@ -69,11 +69,13 @@ int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz
  *           csrspmm_seqreduce_rowbalance_with_mask_kernel, include/cuda/spmm_cuda.cuh:400-433
  *           (the formula, not that kernel's stale-variable bug).
  *   ptr[Mout+1], idx[nnz] = colptr,row of A; val = values permuted to CSC order or NULL;
- *   G[Min,N] grad of the SpMM output; E[Min,N] saved arg ids; out[Mout,N].
+ *   G[Min,N] grad of the SpMM output; E[Min,N] saved arg ids; out[Mout,N].  Same schedule (and workspace
+ *   protocol) as dgs_spmm_csr_f32, so hub columns with 10^4+ entries are split like long rows.
  */
+size_t dgs_spmm_csr_mask_workspace_bytes(int64_t Mout, int64_t N, int64_t nnz);
 int dgs_spmm_csr_mask_f32(int64_t Mout, int64_t Min, int64_t N, int64_t nnz, const int32_t *ptr,
                           const int32_t *idx, const float *val, const float *G, const int32_t *E,
-                          float *out, dgsStream_t stream);
+                          float *out, void *workspace, size_t workspace_bytes, dgsStream_t stream);
 
 /*
  * CSR SDDMM:  out[e] = sum_k D1[row(e),k] * D2[col(e),k]   (/ deg(row(e)) when reduce_op==DGS_MEAN)

@@ -48,7 +48,8 @@ def _worker(rank, world, port, cols, q):
         val = graphgen.weights(col.shape[0], 'tied', 5)
         X = (np.random.default_rng(1).integers(-2, 3, (M, N)) / 4).astype(np.float32)
         part = dd.partition_csr(rp, col, val, world)[rank]
-        eng = dd.DistSpMM(part, N, ops=OracleOps())
+        eng = dd.DistSpMM(part, N, ops=OracleOps(), overlap=False)
+        eng_ov = dd.DistSpMM(part, N, ops=OracleOps(), overlap=True)
         r0, r1 = part.row_offsets[rank], part.row_offsets[rank + 1]
         res = {}
         for red in ('sum', 'mean', 'max', 'min'):
@@ -58,6 +59,9 @@ def _worker(rank, world, port, cols, q):
             if red in ('max', 'min'):
                 ok = ok and np.array_equal(eng.last_E.numpy(), Eg[r0:r1])
             res[red] = bool(ok)
+            if red in ('sum', 'mean'):  # overlapped path: local part + halo part, summation order differs
+                Co = eng_ov.spmm(torch.from_numpy(X[r0:r1].copy()), red)
+                res[red + '_overlap'] = bool(np.allclose(Co.numpy(), Cg[r0:r1], rtol=1e-5, atol=2e-6))
         # plan sanity: halo = unique remote columns, send/recv splits are each other's transpose
         remote = np.unique(col[rp[r0]:rp[r1]][(col[rp[r0]:rp[r1]] < r0) | (col[rp[r0]:rp[r1]] >= r1)])
         res['halo'] = eng.n_halo == remote.shape[0]

@@ -255,3 +255,23 @@ def test_gespmm_and_sddmm_compat_shims(capi):
                        o2.data_ptr())
     torch.cuda.synchronize()
     assert_close(o2.cpu().numpy(), oracle.sddmm(rp, col, D1, X, fma=True), RTOL, ATOL, 'sddmm_cuda_csr')
+
+
+@pytest.mark.parametrize('N', [32, 64, 100])
+def test_masked_backward_with_hub_columns(capi, N):
+    """max/min backward on a graph whose CSC has hub columns with thousands of entries (the split path of the
+    masked SpMM) and whose CSR has long rows (nnz-balanced masked SDDMM)."""
+    M, K = 5000, 5000
+    rp, col, st = graphgen.powerlaw_csr(M, 120000, K=K, alpha=1.8, dmax=4000, seed=50 + N)
+    val = graphgen.weights(col.shape[0], 'signed', N)
+    X = graphgen.features(K, N, N) - np.float32(0.5)
+    G = graphgen.features(M, N, N + 1) - np.float32(0.5)
+    colptr, row, tval, perm = oracle.csr2csc(rp, col, val, K)
+    assert np.diff(colptr).max() > 500
+    _, E = oracle.spmm('max', rp, col, val, X)
+    gX = capi.spmm_mask(dev(colptr), dev(row), dev(tval), dev(G), dev(E)).cpu().numpy()
+    ref = oracle.spmm_mask(colptr, row, tval, G, E, fma=True)
+    S = oracle.spmm_sum_f64(colptr, row, np.abs(tval), np.abs(G), absval=True)
+    assert_sum_parity(gX, ref, ref.astype(np.float64), S, RTOL, ATOL, 'spmm_mask')
+    gW = capi.sddmm(dev(rp), dev(col), dev(G), dev(X), E=dev(E)).cpu().numpy()
+    assert_close(gW, oracle.sddmm_mask(rp, col, G, X, E, fma=True), RTOL, ATOL, 'sddmm_mask')
