@@ -1,4 +1,4 @@
-// spmm.hip -- CSR SpMM (sum / max / min / mean + arg ids) for gfx950.
+// spmm_impl.h -- CSR SpMM (sum / max / min / mean + arg ids) for gfx950.
 //
 // Replaces csrspmm_seqreduce_rowbalance_kernel (reference include/cuda/spmm_cuda.cuh:10-55), which maps ONE
 // THREAD to one (row, feature), re-reads col/val through L1 once per feature and walks every row - however
@@ -39,6 +39,7 @@
 //   reads at a ~30% L2 hit rate on the 1M x 1M power-law graph); see DESIGN.md for the ladder that led here.
 //
 //   spmm_small: inputs up to 2^18 nnz / 2^16 rows take ONE launch (row blocks only, long rows reduced in place).
+#pragma once
 #include "dgs_common.h"
 
 namespace dgs {
@@ -164,7 +165,7 @@ __device__ __forceinline__ void reduce_step_pos(float &res, int &eidx, int &epos
 // atomics cost ~12 ns each when they serialise at L2; per-row atomics made this kernel 44 us, per-block ones ~5).
 // Only the position of a row's units in the table depends on the atomics, never a value.
 constexpr int kK0Rows = 16;
-__global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, const int *__restrict__ rowptr,
+static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, const int *__restrict__ rowptr,
                                                         SpmmWs *__restrict__ hdr, int4 *__restrict__ units) {
   __shared__ int s_wsum[kBlock / kWave];
   __shared__ int s_base;
@@ -708,14 +709,20 @@ static int dispatch_val(const SpmmArgs &a) {
   return a.val ? launch_all<G, V, OP, true>(a) : launch_all<G, V, OP, false>(a);
 }
 
+// The kernels are instantiated in three translation units so that the build parallelises
+// (spmm_v4a.hip: V=4 sum/mean/masked-sum, spmm_v4b.hip: V=4 max/min, spmm_v1.hip: V=1 everything).
 template <int G, int V>
 static int dispatch_op(const SpmmArgs &a) {
   switch (a.reduce_op) {
+#if !defined(DGS_TU_ARG_ONLY)
     case DGS_SUM: return dispatch_val<G, V, DGS_SUM>(a);
-    case DGS_MAX: return dispatch_val<G, V, DGS_MAX>(a);
-    case DGS_MIN: return dispatch_val<G, V, DGS_MIN>(a);
     case DGS_MEAN: return dispatch_val<G, V, DGS_MEAN>(a);
     case kOpMaskSum: return dispatch_val<G, V, kOpMaskSum>(a);
+#endif
+#if !defined(DGS_TU_SUM_ONLY)
+    case DGS_MAX: return dispatch_val<G, V, DGS_MAX>(a);
+    case DGS_MIN: return dispatch_val<G, V, DGS_MIN>(a);
+#endif
   }
   return DGS_EINVAL;
 }
@@ -737,56 +744,9 @@ static int dispatch_g(int G, const SpmmArgs &a) {
 // Inputs this small finish in a few microseconds: launch count dominates, so they take the single-launch path.
 static inline bool tiny_problem(int64_t M, int64_t nnz) { return nnz <= (1 << 18) && M <= (1 << 16); }
 
+// one entry per translation unit
+int spmm_run_v4_sum(int G, const SpmmArgs &a);  // V=4: sum, mean, masked sum
+int spmm_run_v4_arg(int G, const SpmmArgs &a);  // V=4: max, min
+int spmm_run_v1(int G, const SpmmArgs &a);      // V=1: all ops
+
 }  // namespace dgs
-
-using namespace dgs;
-
-extern "C" size_t dgs_spmm_csr_workspace_bytes(int reduce_op, int64_t M, int64_t N, int64_t nnz) {
-  if (M <= 0 || N <= 0 || nnz <= 0 || tiny_problem(M, nnz)) return 0;
-  return ws_layout(reduce_op, N, nnz).total;
-}
-
-extern "C" int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,
-                                const int32_t *col, const float *val, const float *B, float *C, int32_t *E,
-                                int algorithm, void *workspace, size_t workspace_bytes, dgsStream_t stream) {
-  (void)algorithm;  // every algorithm id returns the algorithm-0 result
-  if (reduce_op < DGS_SUM || reduce_op > DGS_MEAN || M < 0 || K < 0 || N < 0 || nnz < 0) return DGS_EINVAL;
-  if (M >= INT32_MAX || K >= INT32_MAX || N >= INT32_MAX || nnz >= INT32_MAX) return DGS_ERANGE;
-  const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
-  if (M == 0 || N == 0) return DGS_OK;
-  if (!rowptr || !C || (nnz > 0 && (!col || !B)) || (arg && !E)) return DGS_EINVAL;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (E && !arg) {  // the reference leaves E = -1 for sum/mean (Eidx is never updated)
-    if (hipMemsetAsync(E, 0xFF, (size_t)M * N * sizeof(int32_t), st) != hipSuccess) return DGS_ELAUNCH;
-  }
-  const size_t need = dgs_spmm_csr_workspace_bytes(reduce_op, M, N, nnz);
-  if (need > 0 && (!workspace || workspace_bytes < need)) return DGS_EWORKSPACE;
-  const bool al = is_aligned16(B) && is_aligned16(C) && (!arg || is_aligned16(E)) &&
-                  (need == 0 || is_aligned16(workspace));
-  const FeatMap fm = feat_map(N, al);
-  SpmmArgs a{M, N, nnz, rowptr, col, val, B, C, arg ? E : nullptr, fm.tiles, need ? workspace : nullptr, st, reduce_op};
-  if (fm.V == 4) return dispatch_g<4>(fm.G, a);
-  return dispatch_g<1>(fm.G, a);
-}
-
-// Masked SpMM (max/min backward w.r.t. the dense operand) on the CSC arrays: same launcher, internal op kOpMaskSum.
-extern "C" size_t dgs_spmm_csr_mask_workspace_bytes(int64_t Mout, int64_t N, int64_t nnz) {
-  return dgs_spmm_csr_workspace_bytes(DGS_SUM, Mout, N, nnz);
-}
-
-extern "C" int dgs_spmm_csr_mask_f32(int64_t Mout, int64_t Min, int64_t N, int64_t nnz, const int32_t *ptr,
-                                     const int32_t *idx, const float *val, const float *G, const int32_t *E,
-                                     float *out, void *workspace, size_t workspace_bytes, dgsStream_t stream) {
-  if (Mout < 0 || Min < 0 || N < 0 || nnz < 0) return DGS_EINVAL;
-  if (Mout >= INT32_MAX || Min >= INT32_MAX || N >= INT32_MAX || nnz >= INT32_MAX) return DGS_ERANGE;
-  if (Mout == 0 || N == 0) return DGS_OK;
-  if (!ptr || !out || (nnz > 0 && (!idx || !G || !E))) return DGS_EINVAL;
-  const size_t need = dgs_spmm_csr_mask_workspace_bytes(Mout, N, nnz);
-  if (need > 0 && (!workspace || workspace_bytes < need)) return DGS_EWORKSPACE;
-  const bool al = is_aligned16(G) && is_aligned16(E) && is_aligned16(out) && (need == 0 || is_aligned16(workspace));
-  const FeatMap fm = feat_map(N, al);
-  SpmmArgs a{Mout, N, nnz, ptr, idx, val, G, out, const_cast<int32_t *>(E), fm.tiles, need ? workspace : nullptr,
-             static_cast<hipStream_t>(stream), kOpMaskSum};
-  if (fm.V == 4) return dispatch_g<4>(fm.G, a);
-  return dispatch_g<1>(fm.G, a);
-}

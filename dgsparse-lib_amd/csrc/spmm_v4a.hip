@@ -1,0 +1,62 @@
+// spmm_v4a.hip -- instantiates the V=4 sum / mean / masked-sum SpMM kernels and holds the C entry points.
+#define DGS_TU_SUM_ONLY
+#include "spmm_impl.h"
+
+namespace dgs {
+int spmm_run_v4_sum(int G, const SpmmArgs &a) { return dispatch_g<4>(G, a); }
+}  // namespace dgs
+
+using namespace dgs;
+
+static int run(const FeatMap &fm, const SpmmArgs &a) {
+  if (fm.V != 4) return spmm_run_v1(fm.G, a);
+  return (a.reduce_op == DGS_MAX || a.reduce_op == DGS_MIN) ? spmm_run_v4_arg(fm.G, a) : spmm_run_v4_sum(fm.G, a);
+}
+
+extern "C" size_t dgs_spmm_csr_workspace_bytes(int reduce_op, int64_t M, int64_t N, int64_t nnz) {
+  if (M <= 0 || N <= 0 || nnz <= 0 || tiny_problem(M, nnz)) return 0;
+  return ws_layout(reduce_op, N, nnz).total;
+}
+
+extern "C" int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,
+                                const int32_t *col, const float *val, const float *B, float *C, int32_t *E,
+                                int algorithm, void *workspace, size_t workspace_bytes, dgsStream_t stream) {
+  (void)algorithm;  // every algorithm id returns the algorithm-0 result
+  if (reduce_op < DGS_SUM || reduce_op > DGS_MEAN || M < 0 || K < 0 || N < 0 || nnz < 0) return DGS_EINVAL;
+  if (M >= INT32_MAX || K >= INT32_MAX || N >= INT32_MAX || nnz >= INT32_MAX) return DGS_ERANGE;
+  const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
+  if (M == 0 || N == 0) return DGS_OK;
+  if (!rowptr || !C || (nnz > 0 && (!col || !B)) || (arg && !E)) return DGS_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (E && !arg) {  // the reference leaves E = -1 for sum/mean (Eidx is never updated)
+    if (hipMemsetAsync(E, 0xFF, (size_t)M * N * sizeof(int32_t), st) != hipSuccess) return DGS_ELAUNCH;
+  }
+  const size_t need = dgs_spmm_csr_workspace_bytes(reduce_op, M, N, nnz);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return DGS_EWORKSPACE;
+  const bool al = is_aligned16(B) && is_aligned16(C) && (!arg || is_aligned16(E)) &&
+                  (need == 0 || is_aligned16(workspace));
+  const FeatMap fm = feat_map(N, al);
+  SpmmArgs a{M, N, nnz, rowptr, col, val, B, C, arg ? E : nullptr, fm.tiles, need ? workspace : nullptr, st, reduce_op};
+  return run(fm, a);
+}
+
+// Masked SpMM (max/min backward w.r.t. the dense operand) on the CSC arrays: same launcher, internal op kOpMaskSum.
+extern "C" size_t dgs_spmm_csr_mask_workspace_bytes(int64_t Mout, int64_t N, int64_t nnz) {
+  return dgs_spmm_csr_workspace_bytes(DGS_SUM, Mout, N, nnz);
+}
+
+extern "C" int dgs_spmm_csr_mask_f32(int64_t Mout, int64_t Min, int64_t N, int64_t nnz, const int32_t *ptr,
+                                     const int32_t *idx, const float *val, const float *G, const int32_t *E,
+                                     float *out, void *workspace, size_t workspace_bytes, dgsStream_t stream) {
+  if (Mout < 0 || Min < 0 || N < 0 || nnz < 0) return DGS_EINVAL;
+  if (Mout >= INT32_MAX || Min >= INT32_MAX || N >= INT32_MAX || nnz >= INT32_MAX) return DGS_ERANGE;
+  if (Mout == 0 || N == 0) return DGS_OK;
+  if (!ptr || !out || (nnz > 0 && (!idx || !G || !E))) return DGS_EINVAL;
+  const size_t need = dgs_spmm_csr_mask_workspace_bytes(Mout, N, nnz);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return DGS_EWORKSPACE;
+  const bool al = is_aligned16(G) && is_aligned16(E) && is_aligned16(out) && (need == 0 || is_aligned16(workspace));
+  const FeatMap fm = feat_map(N, al);
+  SpmmArgs a{Mout, N, nnz, ptr, idx, val, G, out, const_cast<int32_t *>(E), fm.tiles, need ? workspace : nullptr,
+             static_cast<hipStream_t>(stream), kOpMaskSum};
+  return run(fm, a);
+}
