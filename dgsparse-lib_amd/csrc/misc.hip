@@ -120,3 +120,25 @@ extern "C" void spmm_cuda_no_edge_value(int nrowA, int ncolB, int *rowptr, int *
 extern "C" void sddmm_cuda_csr(int m, int k, int nnz, int *rowptr, int *colind, float *D1, float *D2, float *out) {
   dgs_sddmm_csr_f32(DGS_SUM, m, INT32_MAX - 1, k, nnz, rowptr, colind, D1, D2, out, nullptr);
 }
+extern "C" void sddmm_cuda_coo(int k, int nnz, int *rowind, int *colind, float *D1, float *D2, float *out) {
+  dgs_sddmm_coo_f32(k, nnz, rowind, colind, D1, D2, out, nullptr);
+}
+// src/ge-spmm/gespmm.cc:13-24: the reference's kernel selector.  Every id runs the same schedule here.
+extern "C" enum gespmmAlg_t gespmmAlgSel(int dense_ncol, bool transpose_BC) {
+  if (!transpose_BC) return GESPMM_ALG_PARREDUCE_ROWBALANCE_NON_TRANSPOSE;
+  if (dense_ncol >= 32) return GESPMM_ALG_ROWCACHING_ROWBALANCE;
+  return dense_ncol > 4 ? GESPMM_ALG_SEQREDUCE_ROWBALANCE : GESPMM_ALG_PARREDUCE_ROWBALANCE;
+}
+// src/ge-spmm/gespmm.h:64-84: the per-algorithm entry points (row-major B/C).  The nnz-balanced variants of the
+// reference ACCUMULATE into a caller-zeroed C with atomics (example/ge-spmm/spmm.cu:182); these overwrite C, which
+// is the same result under that calling convention.
+#define DGS_GESPMM_ALIAS(name)                                                                       \
+  extern "C" void name(const struct SpMatCsrDescr_t A, const float *B, const int N, float *C) {     \
+    gespmmCsrSpMM(A, const_cast<float *>(B), N, C, true, GESPMM_ALG_DEFAULT);                        \
+  }
+DGS_GESPMM_ALIAS(csrspmm_parreduce_rowbalance)
+DGS_GESPMM_ALIAS(csrspmm_parreduce_nnzbalance)
+DGS_GESPMM_ALIAS(csrspmm_seqreduce_rowbalance)
+DGS_GESPMM_ALIAS(csrspmm_seqreduce_nnzbalance)
+DGS_GESPMM_ALIAS(csrspmm_rowcaching_rowbalance)
+DGS_GESPMM_ALIAS(csrspmm_rowcaching_nnzbalance)

@@ -141,6 +141,87 @@ __global__ __launch_bounds__(kBlock) void sddmm_nnzbal(int M, int F, int tiles, 
   }
 }
 
+// COO SDDMM: out[e] = <D1[rowind[e]], D2[colind[e]]> (reference sddmm_cuda_coo, src/cuda/spmm_cuda.cu:305-329 and the
+// standalone src/sddmm/sddmm.h:7).  Same group mapping as the CSR kernel, the row id simply comes from the array.
+template <int G, int V>
+__global__ __launch_bounds__(kBlock) void sddmm_coo(int F, int tiles, int nnz, const int *__restrict__ rowind,
+                                                    const int *__restrict__ colind, const float *__restrict__ D1,
+                                                    const float *__restrict__ D2, float *__restrict__ out) {
+  constexpr int NG = kWave / G;
+  __shared__ int2 s_tile[kBlock / kWave][kWave];
+  __shared__ int s_res[kBlock / kWave][kWave];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane / G, l = lane % G;
+  int2 *tile = s_tile[wave];
+  int *res = s_res[wave];
+  const int ntiles = (nnz + kWave - 1) / kWave;
+  const int wstride = gridDim.x * (kBlock / kWave);
+  for (int t = blockIdx.x * (kBlock / kWave) + wave; t < ntiles; t += wstride) {
+    const int t0 = t * kWave, cntn = min(kWave, nnz - t0);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < cntn) tile[lane] = make_int2(ld_stream(colind + t0 + lane), ld_stream(rowind + t0 + lane));
+    __builtin_amdgcn_wave_barrier();
+    for (int j0 = g; j0 < cntn; j0 += NG * kSdU) {
+      float part[kSdU];
+      int2 cr[kSdU];
+#pragma unroll
+      for (int q = 0; q < kSdU; q++) {
+        part[q] = 0.0f;
+        cr[q] = tile[min(j0 + q * NG, cntn - 1)];
+      }
+      for (int tt = 0; tt < tiles; tt++) {
+        const int f = (tt * G + l) * V;
+        if (f < F) {
+          float a[kSdU][V], b[kSdU][V];
+#pragma unroll
+          for (int q = 0; q < kSdU; q++) {
+            load_vec<V>(D1 + (int64_t)cr[q].y * F + f, a[q]);
+            load_vec<V>(D2 + (int64_t)cr[q].x * F + f, b[q]);
+          }
+#pragma unroll
+          for (int q = 0; q < kSdU; q++)
+#pragma unroll
+            for (int v = 0; v < V; v++) part[q] = __builtin_fmaf(a[q][v], b[q][v], part[q]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kSdU; q++) {
+        const float tot = group_allreduce<G>(part[q]);
+        const int j = j0 + q * NG;
+        if (j < cntn && l == 0) res[j] = __float_as_int(tot);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < cntn) out[t0 + lane] = __int_as_float(res[lane]);
+  }
+}
+
+template <int G, int V>
+static int launch_coo(int64_t F, int tiles, int64_t nnz, const int *rowind, const int *colind, const float *D1,
+                      const float *D2, float *out, hipStream_t st) {
+  const int64_t ntiles = (nnz + kWave - 1) / kWave;
+  int64_t blocks = (ntiles + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL((sddmm_coo<G, V>), dim3((unsigned)blocks), dim3(kBlock), 0, st, (int)F, tiles, (int)nnz, rowind,
+                     colind, D1, D2, out);
+  return check_launch();
+}
+
+template <int V>
+static int dispatch_coo(int G, int64_t F, int tiles, int64_t nnz, const int *rowind, const int *colind,
+                        const float *D1, const float *D2, float *out, hipStream_t st) {
+  switch (G) {
+    case 1: return launch_coo<1, V>(F, tiles, nnz, rowind, colind, D1, D2, out, st);
+    case 2: return launch_coo<2, V>(F, tiles, nnz, rowind, colind, D1, D2, out, st);
+    case 4: return launch_coo<4, V>(F, tiles, nnz, rowind, colind, D1, D2, out, st);
+    case 8: return launch_coo<8, V>(F, tiles, nnz, rowind, colind, D1, D2, out, st);
+    case 16: return launch_coo<16, V>(F, tiles, nnz, rowind, colind, D1, D2, out, st);
+    case 32: return launch_coo<32, V>(F, tiles, nnz, rowind, colind, D1, D2, out, st);
+    case 64: return launch_coo<64, V>(F, tiles, nnz, rowind, colind, D1, D2, out, st);
+  }
+  return DGS_EINVAL;
+}
+
 template <int G, int V, bool MEAN, bool MASK>
 static int launch_sddmm(int64_t M, int64_t F, int tiles, int64_t nnz, const int *rowptr, const int *col,
                         const float *D1, const float *D2, const int *E, float *out, hipStream_t st) {
@@ -198,4 +279,17 @@ extern "C" int dgs_sddmm_csr_mask_f32(int64_t M, int64_t K, int64_t F, int64_t n
                                       const int32_t *col, const float *D1, const float *D2, const int32_t *E,
                                       float *out, dgsStream_t stream) {
   return run_sddmm<false, true>(M, K, F, nnz, rowptr, col, D1, D2, E, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dgs_sddmm_coo_f32(int64_t F, int64_t nnz, const int32_t *rowind, const int32_t *colind, const float *D1,
+                                 const float *D2, float *out, dgsStream_t stream) {
+  if (F < 0 || nnz < 0) return DGS_EINVAL;
+  if (F >= INT32_MAX || nnz >= INT32_MAX) return DGS_ERANGE;
+  if (nnz == 0) return DGS_OK;
+  if (!rowind || !colind || !out || (F > 0 && (!D1 || !D2))) return DGS_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (F == 0) return hipMemsetAsync(out, 0, (size_t)nnz * sizeof(float), st) == hipSuccess ? DGS_OK : DGS_ELAUNCH;
+  const FeatMap fm = feat_map(F, is_aligned16(D1) && is_aligned16(D2));
+  if (fm.V == 4) return dispatch_coo<4>(fm.G, F, fm.tiles, nnz, rowind, colind, D1, D2, out, st);
+  return dispatch_coo<1>(fm.G, F, fm.tiles, nnz, rowind, colind, D1, D2, out, st);
 }

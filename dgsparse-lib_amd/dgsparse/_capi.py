@@ -45,6 +45,8 @@ _lib.dgs_csr2csc_workspace_bytes.restype = _sz
 _lib.dgs_csr2csc_workspace_bytes.argtypes = [_i64, _i64, _i64]
 _lib.dgs_csr2csc_i32.restype = _int
 _lib.dgs_csr2csc_i32.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
+_lib.dgs_sddmm_coo_f32.restype = _int
+_lib.dgs_sddmm_coo_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]
 _lib.dgs_gather_rows_f32.restype = _int
 _lib.dgs_gather_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 _lib.dgs_scatter_add_rows_f32.restype = _int
@@ -52,8 +54,10 @@ _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
 EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
            'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
-           'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'gespmmCsrSpMM', 'spmm_cuda',
-           'spmm_cuda_no_edge_value', 'sddmm_cuda_csr']
+           'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'dgs_sddmm_coo_f32', 'gespmmCsrSpMM',
+           'spmm_cuda', 'spmm_cuda_no_edge_value', 'sddmm_cuda_csr', 'sddmm_cuda_coo', 'gespmmAlgSel',
+           'csrspmm_parreduce_rowbalance', 'csrspmm_parreduce_nnzbalance', 'csrspmm_seqreduce_rowbalance',
+           'csrspmm_seqreduce_nnzbalance', 'csrspmm_rowcaching_rowbalance', 'csrspmm_rowcaching_nnzbalance']
 
 
 def version() -> int:
@@ -200,6 +204,22 @@ def sddmm(rowptr, col, D1, D2, reduce_op=SUM, E=None):
         else:
             _check(_lib.dgs_sddmm_csr_f32(reduce_op, M, D2.shape[0], F, nnz, _p(rowptr), _p(col), _p(D1), _p(D2),
                                           _p(out), _stream(dev)), 'sddmm')
+    return out
+
+
+def sddmm_coo(rowind, colind, D1, D2):
+    """out[e] = <D1[rowind[e]], D2[colind[e]]> for COO index arrays."""
+    dev = _need_gpu(rowind, colind, D1, D2)
+    rowind = _i32(rowind, 'rowind')
+    colind = _i32(colind, 'colind')
+    D1 = _f32mat(D1, 'D1')
+    D2 = _f32mat(D2, 'D2')
+    if rowind.numel() != colind.numel() or D1.shape[1] != D2.shape[1]:
+        raise ValueError('dgsparse: sddmm_coo shape mismatch')
+    out = torch.empty(rowind.numel(), dtype=torch.float32, device=dev)
+    with _on_device(dev):
+        _check(_lib.dgs_sddmm_coo_f32(D1.shape[1], rowind.numel(), _p(rowind), _p(colind), _p(D1), _p(D2), _p(out),
+                                      _stream(dev)), 'sddmm_coo')
     return out
 
 

@@ -97,6 +97,12 @@ int dgs_sddmm_csr_mask_f32(int64_t M, int64_t K, int64_t F, int64_t nnz, const i
                            const int32_t *col, const float *D1, const float *D2, const int32_t *E,
                            float *out, dgsStream_t stream);
 
+/* COO SDDMM: out[e] = sum_k D1[rowind[e],k] * D2[colind[e],k].
+ * Replaces: sddmm_cuda_coo(), src/cuda/spmm_cuda.cu:305-329 (sddmmCOO{4,2,1}Scale, include/cuda/sddmm_cuda.cuh:13-220)
+ *           and the standalone C entry src/sddmm/sddmm.h:7. */
+int dgs_sddmm_coo_f32(int64_t F, int64_t nnz, const int32_t *rowind, const int32_t *colind, const float *D1,
+                      const float *D2, float *out, dgsStream_t stream);
+
 /*
  * Stable CSR -> CSC transpose (integer permutation; exact for any nnz < 2^31, unlike the reference's
  * float-encoded permutation, dgsparse/storage.py:164-169, which breaks at nnz >= 2^24).
@@ -150,7 +156,16 @@ void gespmmCsrSpMM(const struct SpMatCsrDescr_t spmatA, float *B, const int N, f
 void spmm_cuda(int nrowA, int ncolB, int *rowptr, int *colind, float *values, float *dense, float *out);
 void spmm_cuda_no_edge_value(int nrowA, int ncolB, int *rowptr, int *colind, float *values, float *dense,
                              float *out);
-/* src/sddmm/sddmm.h:10 */
+/* src/ge-spmm/gespmm.h:34 (selector) and :64-84 (per-algorithm entry points, row-major B/C) */
+enum gespmmAlg_t gespmmAlgSel(int dense_ncol, bool transpose_BC);
+void csrspmm_parreduce_rowbalance(const struct SpMatCsrDescr_t spmatA, const float *B, const int N, float *C);
+void csrspmm_parreduce_nnzbalance(const struct SpMatCsrDescr_t spmatA, const float *B, const int N, float *C);
+void csrspmm_seqreduce_rowbalance(const struct SpMatCsrDescr_t spmatA, const float *B, const int N, float *C);
+void csrspmm_seqreduce_nnzbalance(const struct SpMatCsrDescr_t spmatA, const float *B, const int N, float *C);
+void csrspmm_rowcaching_rowbalance(const struct SpMatCsrDescr_t spmatA, const float *B, const int N, float *C);
+void csrspmm_rowcaching_nnzbalance(const struct SpMatCsrDescr_t spmatA, const float *B, const int N, float *C);
+/* src/sddmm/sddmm.h:7-10 */
+void sddmm_cuda_coo(int k, int nnz, int *rowind, int *colind, float *D1, float *D2, float *out);
 void sddmm_cuda_csr(int m, int k, int nnz, int *rowptr, int *colind, float *D1, float *D2, float *out);
 
 #ifdef __cplusplus

@@ -251,10 +251,29 @@ def test_gespmm_and_sddmm_compat_shims(capi):
     D1 = graphgen.features(M, N, 12)
     o2 = torch.empty(col.shape[0], device='cuda')
     lib.sddmm_cuda_csr.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 5
-    lib.sddmm_cuda_csr(M, N, col.shape[0], drp.data_ptr(), dcol.data_ptr(), dev(D1).data_ptr(), dX.data_ptr(),
+    dD1 = dev(D1)  # keep every operand referenced: a temporary would be recycled by the caching allocator
+    lib.sddmm_cuda_csr(M, N, col.shape[0], drp.data_ptr(), dcol.data_ptr(), dD1.data_ptr(), dX.data_ptr(),
                        o2.data_ptr())
     torch.cuda.synchronize()
     assert_close(o2.cpu().numpy(), oracle.sddmm(rp, col, D1, X, fma=True), RTOL, ATOL, 'sddmm_cuda_csr')
+    # COO SDDMM (dgs_sddmm_coo_f32 + the reference's sddmm_cuda_coo name) and the per-algorithm GE-SpMM aliases
+    rowind = np.repeat(np.arange(M, dtype=np.int32), np.diff(rp))
+    drow = dev(rowind)
+    o3 = capi.sddmm_coo(drow, dcol, dD1, dX)
+    assert_close(o3.cpu().numpy(), oracle.sddmm(rp, col, D1, X, fma=True), RTOL, ATOL, 'sddmm_coo')
+    o2.zero_()
+    lib.sddmm_cuda_coo.argtypes = [ctypes.c_int] * 2 + [ctypes.c_void_p] * 5
+    lib.sddmm_cuda_coo(N, col.shape[0], drow.data_ptr(), dcol.data_ptr(), dD1.data_ptr(), dX.data_ptr(), o2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(o2, o3)
+    out.zero_()
+    lib.csrspmm_rowcaching_nnzbalance.argtypes = [Descr, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.csrspmm_rowcaching_nnzbalance(Descr(M, K, col.shape[0], drp.data_ptr(), dcol.data_ptr(), dval.data_ptr()),
+                                      dX.data_ptr(), N, out.data_ptr())
+    torch.cuda.synchronize()
+    assert_close(out.cpu().numpy(), Co, RTOL, ATOL, 'csrspmm_rowcaching_nnzbalance')
+    lib.gespmmAlgSel.restype = ctypes.c_int
+    assert lib.gespmmAlgSel(64, True) == 8 and lib.gespmmAlgSel(16, True) == 0 and lib.gespmmAlgSel(2, True) == 1
 
 
 @pytest.mark.parametrize('N', [32, 64, 100])
@@ -275,3 +294,38 @@ def test_masked_backward_with_hub_columns(capi, N):
     assert_sum_parity(gX, ref, ref.astype(np.float64), S, RTOL, ATOL, 'spmm_mask')
     gW = capi.sddmm(dev(rp), dev(col), dev(G), dev(X), E=dev(E)).cpu().numpy()
     assert_close(gW, oracle.sddmm_mask(rp, col, G, X, E, fma=True), RTOL, ATOL, 'sddmm_mask')
+
+
+def test_cabi_error_codes(capi):
+    """Return codes of the C ABI itself (no exit(), no exceptions): invalid op, missing E for max, workspace too
+    small, int32 range; dgs_strerror names them."""
+    import ctypes
+    lib = capi._lib
+    M, K, N = 70000, 70000, 64  # large enough to need a workspace
+    rp, col, st = graphgen.powerlaw_csr(M, 600000, K=K, alpha=2.1, dmax=3000, seed=1)
+    drp, dcol, dX = dev(rp), dev(col), torch.rand(K, N, device='cuda')
+    C = torch.empty(M, N, device='cuda')
+    E = torch.empty(M, N, dtype=torch.int32, device='cuda')
+    nnz = col.shape[0]
+    need = lib.dgs_spmm_csr_workspace_bytes(0, M, N, nnz)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+    args = lambda op, Eptr, wsptr, wsb: lib.dgs_spmm_csr_f32(op, M, K, N, nnz, drp.data_ptr(), dcol.data_ptr(), None,  # noqa: E731
+                                                             dX.data_ptr(), C.data_ptr(), Eptr, 0, wsptr, wsb, None)
+    assert args(7, None, ws.data_ptr(), need) == -1  # DGS_EINVAL: bad reduce op
+    assert args(1, None, ws.data_ptr(), need) == -1  # max without E
+    assert args(0, None, ws.data_ptr(), need - 1) == -2  # DGS_EWORKSPACE
+    assert args(0, None, None, 0) == -2
+    assert lib.dgs_spmm_csr_f32(0, 2**31, K, N, nnz, drp.data_ptr(), dcol.data_ptr(), None, dX.data_ptr(), C.data_ptr(),
+                                None, 0, ws.data_ptr(), need, None) == -4  # DGS_ERANGE
+    assert args(1, E.data_ptr(), ws.data_ptr(), lib.dgs_spmm_csr_workspace_bytes(1, M, N, nnz)) in (0, -2)
+    assert args(0, None, ws.data_ptr(), need) == 0
+    torch.cuda.synchronize()
+    Co, _ = oracle.spmm('sum', rp, col, None, dX.cpu().numpy(), fma=True)
+    C64 = oracle.spmm_sum_f64(rp, col, None, dX.cpu().numpy())
+    assert_sum_parity(C.cpu().numpy(), Co, C64, None, RTOL, ATOL, 'after error calls')
+    assert lib.dgs_strerror(-4) == b'size exceeds int32 CSR indexing'
+    # E passed for sum: filled with -1 like the reference's untouched Eidx
+    assert args(0, E.data_ptr(), ws.data_ptr(), need) == 0
+    torch.cuda.synchronize()
+    assert bool((E == -1).all())

@@ -15,7 +15,7 @@ PKG = os.path.join(ROOT, 'dgsparse-lib_amd')
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, 'include', 'dgsparse_hip.h')).read()
     hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
-    declared = set(re.findall(r'\b(dgs_\w+|gespmmCsrSpMM|spmm_cuda\w*|sddmm_cuda_csr)\s*\(', hdr))
+    declared = set(re.findall(r'\b(dgs_\w+|gespmm\w+|csrspmm_\w+|spmm_cuda\w*|sddmm_cuda_\w+)\s*\(', hdr))
     assert len(declared) >= 16
     lib = ctypes.CDLL(os.path.join(PKG, 'dgsparse', 'libdgsparse_hip.so'))
     for sym in sorted(declared):
