@@ -20,3 +20,20 @@ for name in ['cora','pubmed']:
     t=time.perf_counter()
     for _ in range(1000): torch.sparse.mm(tcsr,X)
     torch.cuda.synchronize(); print(name,'torch.sparse.mm (hipSPARSE) us/call',(time.perf_counter()-t)/1000*1e6)
+    st_=A.storage
+    args=(st_.rowptr(),st_.col(),st_.values(),st_.colptr(),st_.row(),st_.csr2csc(),X,True,0)
+    for _ in range(20): torch.ops.dgsparse_spmm.spmm_sum(*args)
+    torch.cuda.synchronize(); t=time.perf_counter()
+    for _ in range(1000): torch.ops.dgsparse_spmm.spmm_sum(*args)
+    torch.cuda.synchronize(); print(name,'torch.ops.dgsparse_spmm.spmm_sum us/call',(time.perf_counter()-t)/1000*1e6)
+    for _ in range(20): torch.ops.dgsparse_spmm.spmm_raw(0,st_.rowptr(),st_.col(),st_.values(),X,True,0)
+    torch.cuda.synchronize(); t=time.perf_counter()
+    for _ in range(1000): torch.ops.dgsparse_spmm.spmm_raw(0,st_.rowptr(),st_.col(),st_.values(),X,True,0)
+    torch.cuda.synchronize(); print(name,'torch.ops.dgsparse_spmm.spmm_raw us/call',(time.perf_counter()-t)/1000*1e6)
+    Xg=X.clone().requires_grad_()
+    def fb():
+        o=dgsparse.spmm_sum(A,Xg,0); o.sum().backward(); Xg.grad=None
+    for _ in range(20): fb()
+    torch.cuda.synchronize(); t=time.perf_counter()
+    for _ in range(300): fb()
+    torch.cuda.synchronize(); print(name,'fwd+bwd (dX only) us/iter',(time.perf_counter()-t)/300*1e6)

@@ -11,10 +11,23 @@ as src/spmm.cpp:52-80,113-141, with three deliberate fixes:
   * the dense gradient always has dense's shape, also when trailing columns of A are empty.
 An extra op ``dgsparse_spmm::sddmm`` exposes SDDMM directly (SURVEY.md R3).
 """
+import importlib.machinery
+import os
+
 import torch
 
 from . import _capi
 from ._capi import MAX, MEAN, MIN, SUM
+
+# Preferred binding: the C++ TORCH_LIBRARY in _spmm_hip*.so next to the package, found and loaded exactly like the
+# reference does with _spmm_cuda*.so (dgsparse/__init__.py:16-26).  It calls the same C ABI; the Python registration
+# below is the same binding written in Python (kept so that the op surface exists even where only the kernel library
+# was built; force it with DGSPARSE_PY_BINDING=1).  Neither is a compute fallback: both end in libdgsparse_hip.so.
+NATIVE_BINDING = False
+_spec = importlib.machinery.PathFinder().find_spec('_spmm_hip', [os.path.dirname(__file__)])
+if _spec is not None and os.environ.get('DGSPARSE_PY_BINDING', '0') != '1':
+    torch.ops.load_library(_spec.origin)
+    NATIVE_BINDING = True
 
 
 def _t_values(values, csr2csc, has_value):
@@ -135,15 +148,23 @@ def _csr2csc_op(rowptr, colind, values):
     return [colptr, row, cscval]
 
 
-_SCHEMA = ('(Tensor rowptr, Tensor col, Tensor values, Tensor colptr, Tensor row, Tensor csr2csc, Tensor dense, '
-           'bool has_value, int algorithm) -> Tensor')
-
-_lib = torch.library.Library('dgsparse_spmm', 'DEF')
-for _name, _fn in (('spmm_sum', SpMMSum), ('spmm_max', SpMMMax), ('spmm_min', SpMMMin), ('spmm_mean', SpMMMean)):
-    _lib.define(_name + _SCHEMA)
-    _lib.impl(_name, _fn.apply, 'CompositeImplicitAutograd')
-_lib.define('csr2csc(Tensor rowptr, Tensor colind, Tensor values) -> Tensor[]')
-_lib.impl('csr2csc', _csr2csc_op, 'CompositeImplicitAutograd')
-_lib.define('sddmm(Tensor rowptr, Tensor col, Tensor D1, Tensor D2, int reduce_op) -> Tensor')
-_lib.impl('sddmm', lambda rowptr, col, D1, D2, reduce_op: _capi.sddmm(rowptr, col, D1, D2, reduce_op),
-          'CompositeImplicitAutograd')
+if not NATIVE_BINDING:
+    _SCHEMA = ('(Tensor rowptr, Tensor col, Tensor values, Tensor colptr, Tensor row, Tensor csr2csc, Tensor dense, '
+               'bool has_value, int algorithm) -> Tensor')
+    _lib = torch.library.Library('dgsparse_spmm', 'DEF')
+    for _name, _fn in (('spmm_sum', SpMMSum), ('spmm_max', SpMMMax), ('spmm_min', SpMMMin), ('spmm_mean', SpMMMean)):
+        _lib.define(_name + _SCHEMA)
+        _lib.impl(_name, _fn.apply, 'CompositeImplicitAutograd')
+    _lib.define('csr2csc(Tensor rowptr, Tensor colind, Tensor values) -> Tensor[]')
+    _lib.impl('csr2csc', _csr2csc_op, 'CompositeImplicitAutograd')
+    _lib.define('sddmm(Tensor rowptr, Tensor col, Tensor D1, Tensor D2, int reduce_op) -> Tensor')
+    _lib.impl('sddmm', lambda rowptr, col, D1, D2, reduce_op: _capi.sddmm(rowptr, col, D1, D2, reduce_op),
+              'CompositeImplicitAutograd')
+    _lib.define('csr2csc_perm(Tensor rowptr, Tensor colind, int n_cols) -> Tensor[]')
+    _lib.impl('csr2csc_perm', lambda rowptr, colind, n_cols: [t for i, t in enumerate(
+        _capi.csr2csc(rowptr, colind, None, n_cols, want_perm=True)) if i != 2], 'CompositeImplicitAutograd')
+    _lib.define('spmm_raw(int op, Tensor rowptr, Tensor col, Tensor values, Tensor dense, bool has_value, '
+                'int algorithm) -> Tensor[]')
+    _lib.impl('spmm_raw', lambda op, rowptr, col, values, dense, has_value, algorithm: [
+        t for t in _capi.spmm(op, rowptr, col, values if has_value else None, dense, algorithm) if t is not None],
+        'CompositeImplicitAutograd')

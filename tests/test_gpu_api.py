@@ -135,3 +135,30 @@ def test_standalone_cabi_driver_on_mtx(tmp_path):
     out = subprocess.run([os.path.join(root, 'examples', 'spmm_mtx'), p, '48'], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count('passed') == 5 and 'FAILED' not in out.stdout
+
+
+def test_hip_graph_capture_and_replay():
+    """The C ABI never allocates or synchronises and launches on the caller's stream, so a whole forward (memset +
+    classify + fused + combine, or the single small-input launch) can be captured in a HIP graph and replayed."""
+    import dgsparse
+    from bench import graphgen
+    for name in ('cora', 'arxiv'):  # single-launch path and the 4-launch path
+        rp, col, st = graphgen.dataset_shaped(name, seed=0, device='cuda', as_torch=True)
+        val = torch.rand(st['nnz'], device='cuda')
+        A = dgsparse.SparseTensor(rowptr=rp, col=col, values=val, has_value=True)
+        X = torch.rand(st['K'], 64, device='cuda')
+        ref = dgsparse.spmm_max(A, X, 0).clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                dgsparse.spmm_max(A, X, 0)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = dgsparse.spmm_max(A, X, 0)
+        X.mul_(2.0)  # replay must see the new contents of the captured input buffer
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, dgsparse.spmm_max(A, X, 0))
+        assert not torch.equal(out, ref)
