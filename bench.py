@@ -42,7 +42,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--feat', type=int, default=64)
     ap.add_argument('--reduce', default='sum', choices=['sum', 'mean', 'max', 'min'])
-    ap.add_argument('--cols', default='powerlaw', choices=['powerlaw', 'uniform'])
+    ap.add_argument('--cols', default='powerlaw', choices=['powerlaw', 'uniform', 'local'])
     ap.add_argument('--rows-log2', type=int, default=20, help='rows per GPU = 2^k')
     ap.add_argument('--deg', type=int, default=16)
     ap.add_argument('--locality', type=float, default=0.8,

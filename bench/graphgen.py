@@ -51,6 +51,10 @@ def _sample_cols(deg_t, K, cols, cdf, gen, device):
     row = torch.repeat_interleave(torch.arange(deg_t.shape[0], device=device), deg_t)
     if cols == 'uniform':
         col = torch.randint(0, K, (total,), generator=gen, device=device)
+    elif cols == 'local':  # community-like: columns within a window around the row id (graphs in a locality-
+        w = max(64, K // 256)  # preserving order, e.g. after METIS/RCM reordering)
+        off = torch.randint(-w, w + 1, (total,), generator=gen, device=device)
+        col = (row * K // deg_t.shape[0] + off).clamp_(0, K - 1)
     else:
         u = torch.rand(total, generator=gen, device=device, dtype=torch.float64)
         col = torch.searchsorted(cdf, u, right=True).clamp_(max=K - 1)
@@ -79,7 +83,7 @@ def powerlaw_csr(M: int, nnz: int, K: int | None = None, alpha: float = 2.1, dma
         w = w[rng.permutation(K)]  # popularity uncorrelated with the row id
         c = np.cumsum(w)
         cdf = torch.from_numpy(c / c[-1]).to(device)
-    elif cols != 'uniform':
+    elif cols not in ('uniform', 'local'):
         raise ValueError(cols)
     deg_t = torch.from_numpy(deg).to(device)
     key = _sample_cols(deg_t, K, cols, cdf, gen, device)

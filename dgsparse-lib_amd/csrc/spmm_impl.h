@@ -52,6 +52,9 @@ constexpr int kOpMaskSum = 4;
 
 // ---------------------------------------------------------------------------------------------------------
 // tuning constants
+#ifndef DGS_XCD_REMAP
+#define DGS_XCD_REMAP 1
+#endif
 #ifndef DGS_T1
 #define DGS_T1 64
 #endif
@@ -169,8 +172,10 @@ static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, co
                                                         SpmmWs *__restrict__ hdr, int4 *__restrict__ units) {
   __shared__ int s_wsum[kBlock / kWave];
   __shared__ int s_base;
-  const int nthreads = gridDim.x * kBlock;
-  const int tid = blockIdx.x * kBlock + threadIdx.x;
+  // block b owns the CONTIGUOUS rows [b*4096, (b+1)*4096): its units form one run of the table that covers
+  // neighbouring rows, which is what lets the unit path give each XCD rows that share columns (see spmm_units_body)
+  const int nthreads = kBlock;
+  const int tid = blockIdx.x * kBlock * kK0Rows + threadIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int mine = 0;
   unsigned hugemask = 0;
@@ -503,9 +508,24 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
   const int f0 = (blockIdx.y * G + l) * V;
   const bool fl = f0 < N;
   const int n_units = hdr->n_units;
-  const int wstride = nblocks * (kBlock / kWave);
-
-  for (int u = bid * (kBlock / kWave) + wave; u < n_units; u += wstride) {
+  // XCD-aware unit mapping (speed hint only): block b runs on XCD b % 8 (observed), so the unit blocks of one XCD
+  // walk one contiguous eighth of the table = a few runs of neighbouring rows (spmm_classify), whose gathers share an L2.
+  int u, uend, wstride;
+#if DGS_XCD_REMAP
+  if ((nblocks & 7) == 0) {
+    const int x = bid & 7, wx = (nblocks >> 3) * (kBlock / kWave);
+    const int lo = (int)(((long long)n_units * x) >> 3);
+    uend = (int)(((long long)n_units * (x + 1)) >> 3);
+    u = lo + (bid >> 3) * (kBlock / kWave) + wave;
+    wstride = wx;
+  } else
+#endif
+  {
+    u = bid * (kBlock / kWave) + wave;
+    uend = n_units;
+    wstride = nblocks * (kBlock / kWave);
+  }
+  for (; u < uend; u += wstride) {
     const int4 d = units[u];  // {row, unit index in row, partial slot base, units in row}
     const int rs = rowptr[d.x], re = rowptr[d.x + 1];
     const int p0 = rs + d.y * ch;
@@ -553,8 +573,19 @@ __global__ __launch_bounds__(kBlock) void spmm_fused(int M, int N, int ch, int n
   if ((int)blockIdx.x < nbu)
     spmm_units_body<G, V, OP, HAS_VAL>(blockIdx.x, nbu, lds, N, ch, rowptr, col, val, B, C, E, hdr, units, part,
                                        parte);
-  else
-    spmm_rows_body<G, V, OP, HAS_VAL, false>(blockIdx.x - nbu, kRowsPerWave, lds, M, N, rowptr, col, val, B, C, E);
+  else {
+    // XCD-aware row mapping: workgroups are dealt round-robin to the 8 XCDs (observed: block b -> XCD b % 8), each
+    // with a private L2.  Give every XCD a CONTIGUOUS eighth of the row blocks, so that neighbouring rows - which
+    // in a locality-preserving ordering share columns - hit the same L2 instead of fetching the same B rows 8x.
+    // Pure speed hint: any placement gives the same result.
+    int rb = blockIdx.x - nbu;
+#if DGS_XCD_REMAP
+    const int nbr = gridDim.x - nbu;
+    const int per = nbr / 8;
+    if (rb < per * 8) rb = (rb % 8) * per + rb / 8;
+#endif
+    spmm_rows_body<G, V, OP, HAS_VAL, false>(rb, kRowsPerWave, lds, M, N, rowptr, col, val, B, C, E);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
