@@ -111,6 +111,23 @@ __device__ __forceinline__ T ld_stream(const T *p) {
   return *p;
 #endif
 }
+// Gather of a dense-operand row slice; DGS_B_NT=1 makes it non-temporal (experiment: scan-resistant insertion?).
+#ifndef DGS_B_NT
+#define DGS_B_NT 0
+#endif
+template <int V>
+__device__ __forceinline__ void load_vec_gather(const float *p, float (&o)[V]) {
+#if DGS_B_NT
+  if constexpr (V == 4) {
+    const dgs_f4 t = __builtin_nontemporal_load(reinterpret_cast<const dgs_f4 *>(p));
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3];
+  } else {
+    o[0] = __builtin_nontemporal_load(p);
+  }
+#else
+  load_vec<V>(p, o);
+#endif
+}
 template <int V>
 __device__ __forceinline__ void store_vec_stream(float *p, const float (&o)[V]) {
 #if DGS_NT

@@ -254,7 +254,7 @@ __device__ __forceinline__ void coop_accumulate(int p0, int p1, int lane, int g,
 #pragma unroll
       for (int q = 0; q < kU; q++)
         if (j + q * NG < cnt && fl) {
-          load_vec<V>(B + (int64_t)c[q] * N + f0, x[q]);
+          load_vec_gather<V>(B + (int64_t)c[q] * N + f0, x[q]);
           if constexpr (OP == kOpMaskSum) load_vec<V>(Em + (int64_t)c[q] * N + f0, m[q]);
         }
 #pragma unroll
@@ -417,7 +417,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
 #pragma unroll
       for (int u = 0; u < kU1; u++) {
         cv[u] = tile[min(ps + u, last)];
-        load_vec<V>(Bl + (int64_t)(cv[u].x & 0x7fffffff) * N, x[u]);
+        load_vec_gather<V>(Bl + (int64_t)(cv[u].x & 0x7fffffff) * N, x[u]);
         if constexpr (OP == kOpMaskSum) load_vec<V>(El + (int64_t)(cv[u].x & 0x7fffffff) * N, mk[u]);
       }
       for (int p = ps; p < pe; p += kU1) {
@@ -456,7 +456,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
           }
           // refill the slot just consumed (same registers: no copies, so the waits stay counted)
           cv[u] = tile[min(p + u + kU1, last)];
-          load_vec<V>(Bl + (int64_t)(cv[u].x & 0x7fffffff) * N, x[u]);
+          load_vec_gather<V>(Bl + (int64_t)(cv[u].x & 0x7fffffff) * N, x[u]);
           if constexpr (OP == kOpMaskSum) load_vec<V>(El + (int64_t)(cv[u].x & 0x7fffffff) * N, mk[u]);
         }
       }

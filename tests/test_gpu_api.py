@@ -162,3 +162,17 @@ def test_hip_graph_capture_and_replay():
         torch.cuda.synchronize()
         assert torch.equal(out, dgsparse.spmm_max(A, X, 0))
         assert not torch.equal(out, ref)
+
+
+def test_rccl_collectives_single_rank():
+    """init_process_group('nccl') + the collective calls of dgsparse/dist.py under torch.distributed.run (1 rank)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+                          '--master-addr', '127.0.0.1', '--master-port', '29533',
+                          os.path.join(root, 'tests', 'nccl_selftest.py')], capture_output=True, text=True, env=env,
+                         timeout=300)
+    assert out.returncode == 0 and 'nccl selftest ok' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

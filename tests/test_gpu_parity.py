@@ -329,3 +329,75 @@ def test_cabi_error_codes(capi):
     assert args(0, E.data_ptr(), ws.data_ptr(), need) == 0
     torch.cuda.synchronize()
     assert bool((E == -1).all())
+
+
+def _threshold_graph(M, K, lens, seed):
+    """CSR whose first rows have exactly the given lengths (duplicates allowed), the rest short random rows."""
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(0, 9, M)
+    deg[:len(lens)] = lens
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    col = rng.integers(0, K, int(rp[-1])).astype(np.int32)
+    for r in range(len(lens)):  # sorted inside the long rows (ties across unit boundaries are then well defined)
+        col[rp[r]:rp[r + 1]].sort()
+    return rp, col
+
+
+@pytest.mark.parametrize('M,N', [(300, 64), (70000, 64), (70000, 32), (5000, 128), (66000, 8)])
+def test_spmm_threshold_boundaries(capi, M, N):
+    """Row lengths sitting exactly on every schedule boundary: 0/1, T1=64 +-1 (stream vs units), the LDS tile capacity
+    512, the unit length 256 +-1 and multiples of it, one very long row; M on both sides of the single-launch limit."""
+    K = 3000
+    lens = [0, 1, 63, 64, 65, 127, 128, 255, 256, 257, 511, 512, 513, 768, 1024, 1025, 4000, 0, 64, 64, 64, 64, 200]
+    rp, col = _threshold_graph(M, K, lens, seed=M + N)
+    val = graphgen.weights(col.shape[0], 'tied', N)
+    X = (np.random.default_rng(N).integers(-2, 3, (K, N)) / 4).astype(np.float32)
+    C64 = oracle.spmm_sum_f64(rp, col, val, X)
+    S64 = oracle.spmm_sum_f64(rp, col, val, X, absval=True)
+    for reduce in ('sum', 'mean', 'max', 'min'):
+        C, E = run_spmm(capi, reduce, rp, col, val, X)
+        Co, Eo = oracle.spmm(reduce, rp, col, val, X, fma=True)
+        if reduce in ('max', 'min'):
+            assert_bitexact(C, Co, f'{reduce} values')
+            assert_bitexact(E, Eo, f'{reduce} E')
+        elif reduce == 'sum':
+            assert_sum_parity(C, Co, C64, S64, RTOL, ATOL, reduce)
+            short = np.diff(rp) <= 64  # rows in the sequential regime must match the fmaf chain bit for bit
+            assert_bitexact(C[short], Co[short], 'sum, rows <= T1')
+        else:
+            deg = np.maximum(np.diff(rp), 1)[:, None]
+            assert_sum_parity(C, Co, C64 / deg, S64 / deg, RTOL, ATOL, reduce)
+
+
+def test_spmm_randomized_stress(capi):
+    """Many random shapes/degree laws/value kinds in one go, every reduce, against the oracle."""
+    rng = np.random.default_rng(2024)
+    for it in range(24):
+        M = int(rng.choice([1, 2, 63, 64, 65, 257, 1000, 4097, 20000]))
+        K = int(rng.choice([1, 5, 64, 1000, 30000]))
+        N = int(rng.choice([1, 2, 4, 5, 8, 16, 31, 32, 48, 64, 96, 128, 192, 256, 300]))
+        nnz = int(rng.integers(0, 40 * M + 1))
+        alpha = float(rng.choice([1.6, 2.1, 3.0]))
+        rp, col, st = graphgen.powerlaw_csr(M, max(nnz, 1), K=K, alpha=alpha, dmax=max(1, min(K, M * 4)), seed=it,
+                                            dedup=bool(it % 2), cols='uniform' if it % 3 else 'powerlaw')
+        kind = ['tied', 'signed', 'uniform', None][it % 4]
+        val = graphgen.weights(col.shape[0], kind, it) if kind else None
+        X = (rng.integers(-3, 4, (K, N)) / 8).astype(np.float32)
+        C64 = oracle.spmm_sum_f64(rp, col, val, X)
+        S64 = oracle.spmm_sum_f64(rp, col, val, X, absval=True)
+        for reduce in ('sum', 'max', 'min', 'mean'):
+            C, E = run_spmm(capi, reduce, rp, col, val, X)
+            Co, Eo = oracle.spmm(reduce, rp, col, val, X, fma=True)
+            tag = f'it={it} M={M} K={K} N={N} nnz={col.shape[0]} {reduce}'
+            if reduce in ('max', 'min'):
+                assert_bitexact(C, Co, tag)
+                assert_bitexact(E, Eo, tag + ' E')
+            elif reduce == 'sum':
+                assert_sum_parity(C, Co, C64, S64, RTOL, ATOL, tag)
+            else:
+                deg = np.maximum(np.diff(rp), 1)[:, None]
+                assert_sum_parity(C, Co, C64 / deg, S64 / deg, RTOL, ATOL, tag)
+        if col.shape[0]:
+            D1 = (rng.integers(-3, 4, (M, N)) / 8).astype(np.float32)
+            out = capi.sddmm(dev(rp), dev(col), dev(D1), dev(X)).cpu().numpy()
+            assert_close(out, oracle.sddmm(rp, col, D1, X, fma=True), RTOL, 1e-5, f'sddmm it={it}')
