@@ -185,6 +185,13 @@ class _HipOps:
     def gather_rows(self, src, ids):
         return self._c.gather_rows(src, ids)
 
+    def scatter_add_rows(self, dst, ids, src):
+        return self._c.scatter_add_rows(dst, ids, src)
+
+    def csr2csc(self, rowptr, col, val, n_cols):
+        colptr, row, cscval, _ = self._c.csr2csc(rowptr, col, val, n_cols, want_perm=False)
+        return colptr, row, cscval
+
 
 _OPS = {'sum': 0, 'max': 1, 'min': 2, 'mean': 3}
 
@@ -244,3 +251,42 @@ class DistSpMM:
             g = self.plan.ext2glob[E.clamp(min=0).long()].to(torch.int32)
             self.last_E = torch.where(E >= 0, g, E)
         return C
+
+    # ---- backward of the sum product w.r.t. the dense operand: dB = A^T dC, with the exchange reversed ----------
+    def _transposed(self):
+        if getattr(self, '_csc', None) is None:  # CSC of the relabelled local matrix, built once
+            p = self.part
+            self._csc = self.ops.csr2csc(p.rowptr, self.plan.col_ext, p.val, p.n_local + self.n_halo)
+        return self._csc
+
+    def spmm_sum_backward_dense(self, grad_C: torch.Tensor) -> torch.Tensor:
+        """grad w.r.t. this rank's rows of B: local part of A_ext^T grad_C plus the halo parts that the peers computed
+        for rows I own (reverse all-to-all-v, then a scatter-add; every send_ids row is unique per peer but one row
+        may be wanted by several peers, so the adds are applied peer by peer - a fixed order, deterministic)."""
+        p, plan = self.part, self.plan
+        colptr, row, tval = self._transposed()
+        g_ext, _ = self.ops.spmm(0, colptr, row, tval, grad_C.contiguous())  # [n_local + n_halo, N]
+        g_loc = g_ext[:p.n_local].contiguous()
+        if p.world > 1:
+            back = torch.empty((int(plan.send_ids.numel()), g_ext.shape[1]), dtype=torch.float32, device=g_ext.device)
+            dist.all_to_all_single(back, g_ext[p.n_local:].contiguous(), plan.send_splits, plan.recv_splits,
+                                   group=self.group)
+            off = 0
+            for n in plan.send_splits:  # one peer at a time: ids are unique inside a peer's block
+                if n:
+                    self.ops.scatter_add_rows(g_loc, plan.send_ids[off:off + n].contiguous(), back[off:off + n].contiguous())
+                off += n
+        return g_loc
+
+
+class DistSpMMSum(torch.autograd.Function):
+    """Autograd wrapper: ``C_loc = DistSpMMSum.apply(engine, B_loc)`` differentiable w.r.t. B_loc."""
+
+    @staticmethod
+    def forward(ctx, engine: 'DistSpMM', B_loc: torch.Tensor):
+        ctx.engine = engine
+        return engine.spmm(B_loc, 'sum')
+
+    @staticmethod
+    def backward(ctx, grad_C):
+        return None, ctx.engine.spmm_sum_backward_dense(grad_C)

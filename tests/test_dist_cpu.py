@@ -24,6 +24,15 @@ class OracleOps:
     def gather_rows(self, src, ids):
         return src[ids.long()].contiguous()
 
+    def scatter_add_rows(self, dst, ids, src):
+        dst[ids.long()] += src
+        return dst
+
+    def csr2csc(self, rowptr, col, val, n_cols):
+        import oracle
+        colptr, row, cscval, _ = oracle.csr2csc(rowptr.numpy(), col.numpy(), None if val is None else val.numpy(), n_cols)
+        return torch.from_numpy(colptr), torch.from_numpy(row), (None if cscval is None else torch.from_numpy(cscval))
+
 
 def _free_port():
     s = socket.socket()
@@ -62,6 +71,14 @@ def _worker(rank, world, port, cols, q):
             if red in ('sum', 'mean'):  # overlapped path: local part + halo part, summation order differs
                 Co = eng_ov.spmm(torch.from_numpy(X[r0:r1].copy()), red)
                 res[red + '_overlap'] = bool(np.allclose(Co.numpy(), Cg[r0:r1], rtol=1e-5, atol=2e-6))
+        # backward of sum w.r.t. B through the reversed exchange == rows [r0,r1) of A^T G on the whole graph
+        G = (np.random.default_rng(2).integers(-2, 3, (M, N)) / 4).astype(np.float32)
+        Bl = torch.from_numpy(X[r0:r1].copy()).requires_grad_()
+        out = dd.DistSpMMSum.apply(eng, Bl)
+        out.backward(torch.from_numpy(G[r0:r1].copy()))
+        cp, rw, tv, _ = oracle.csr2csc(rp, col, val, M)
+        gB, _ = oracle.spmm('sum', cp, rw, tv, G)
+        res['backward'] = bool(np.allclose(Bl.grad.numpy(), gB[r0:r1], rtol=1e-5, atol=2e-6))
         # plan sanity: halo = unique remote columns, send/recv splits are each other's transpose
         remote = np.unique(col[rp[r0]:rp[r1]][(col[rp[r0]:rp[r1]] < r0) | (col[rp[r0]:rp[r1]] >= r1)])
         res['halo'] = eng.n_halo == remote.shape[0]

@@ -111,6 +111,12 @@ def test_dist_engine_single_rank_on_gpu():
         assert torch.equal(C, Cr)
         if red == 'max':
             assert torch.equal(eng.last_E, Er)
+    # backward w.r.t. B through the engine == transposed SpMM of the plain operator
+    G = torch.rand(4096, 64, device='cuda')
+    gB = eng.spmm_sum_backward_dense(G)
+    colptr, row, tval, _ = _capi.csr2csc(sp.rowptr, sp.col, sp.val, 4096)
+    ref, _ = _capi.spmm(0, colptr, row, tval, G)
+    assert torch.equal(gB, ref)
 
 
 def test_standalone_cabi_driver_on_mtx(tmp_path):
