@@ -76,13 +76,14 @@ constexpr int kU1 = DGS_KU1;   // independent B-row gathers in flight per lane, 
 constexpr int kU = 8;          // same for K2 (units)
 
 struct SpmmWs {       // workspace header (zeroed every call with one 16-byte memset)
-  int n_units;        // K0 -> fused/K3: number of unit descriptors
-  int pad[3];
+  int n_units;        // K0 -> fused/K2: number of unit descriptors
+  int n_pslots;       // partial-row slots handed out (multi-unit rows only)
+  int pad[2];
 };
 
 struct WsLayout {
   size_t off_units, off_part, off_parte, total;
-  int64_t max_units;
+  int64_t max_units, max_pslots;
   int ch;
 };
 
@@ -97,10 +98,11 @@ static inline WsLayout ws_layout(int reduce_op, int64_t N, int64_t nnz) {
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
   WsLayout L;
   L.ch = unit_len(nnz);
-  L.max_units = nnz / kT2 + nnz / L.ch + 2;          // sum over huge rows of ceil(len/ch) <= nnz/ch + #huge rows
+  L.max_units = nnz / kT2 + nnz / L.ch + 2;          // sum over long rows of ceil(len/ch) <= nnz/ch + #long rows
+  L.max_pslots = 2 * (nnz / L.ch) + 2;               // same sum over rows longer than ch only (they need partials)
   L.off_units = up(sizeof(SpmmWs));
   L.off_part = L.off_units + up((size_t)L.max_units * sizeof(int4));
-  const size_t prow = up((size_t)L.max_units * N * sizeof(float));  // one partial row per unit (slot = unit id)
+  const size_t prow = up((size_t)L.max_pslots * N * sizeof(float));  // one partial row per unit of a multi-unit row
   L.off_parte = L.off_part + prow;
   const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
   L.total = L.off_parte + (arg ? prow : 0) + 256;
@@ -162,7 +164,7 @@ __device__ __forceinline__ void reduce_step_pos(float &res, int &eidx, int &epos
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K0: scan rowptr once and cut every huge row (len > T2) into units of <= ch nnz: unit = {row, k, first unit of
+// K0: scan rowptr once and cut every long row (len > T2) into units of <= ch nnz: unit = {row, k, first partial slot of
 // the row, units in the row}.  Each thread looks at kK0Rows rows, a block-level exclusive scan turns the per-thread
 // unit counts into offsets, and ONE atomicAdd per block reserves the block's range of the table (same-address
 // atomics cost ~12 ns each when they serialise at L2; per-row atomics made this kernel 44 us, per-block ones ~5).
@@ -172,12 +174,14 @@ static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, co
                                                         SpmmWs *__restrict__ hdr, int4 *__restrict__ units) {
   __shared__ int s_wsum[kBlock / kWave];
   __shared__ int s_base;
+  __shared__ int s_psum[kBlock / kWave];
+  __shared__ int s_pbase;
   // block b owns the CONTIGUOUS rows [b*4096, (b+1)*4096): its units form one run of the table that covers
   // neighbouring rows, which is what lets the unit path give each XCD rows that share columns (see spmm_units_body)
   const int nthreads = kBlock;
   const int tid = blockIdx.x * kBlock * kK0Rows + threadIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int mine = 0;
+  int mine = 0, pmine = 0;  // units of this thread's rows; of which units that need a partial-row slot
   unsigned hugemask = 0;
 #pragma unroll
   for (int i = 0; i < kK0Rows; i++) {
@@ -185,37 +189,56 @@ static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, co
     if (r < M) {
       const int len = rowptr[r + 1] - rowptr[r];
       if (len > kT2) {
-        mine += (len + ch - 1) / ch;
+        const int nch = (len + ch - 1) / ch;
+        mine += nch;
+        if (nch > 1) pmine += nch;
         hugemask |= 1u << i;
       }
     }
   }
-  int incl = mine;
+  int incl = mine, pincl = pmine;
 #pragma unroll
   for (int d = 1; d < kWave; d <<= 1) {
     const int t = __shfl_up(incl, d, kWave);
-    if (lane >= d) incl += t;
+    const int tp = __shfl_up(pincl, d, kWave);
+    if (lane >= d) {
+      incl += t;
+      pincl += tp;
+    }
   }
-  if (lane == kWave - 1) s_wsum[wave] = incl;
+  if (lane == kWave - 1) {
+    s_wsum[wave] = incl;
+    s_psum[wave] = pincl;
+  }
   __syncthreads();
-  int woff = 0, total = 0;
+  int woff = 0, total = 0, pwoff = 0, ptotal = 0;
 #pragma unroll
   for (int w = 0; w < kBlock / kWave; w++) {
-    if (w < wave) woff += s_wsum[w];
+    if (w < wave) {
+      woff += s_wsum[w];
+      pwoff += s_psum[w];
+    }
     total += s_wsum[w];
+    ptotal += s_psum[w];
   }
-  if (threadIdx.x == 0) s_base = total ? atomicAdd(&hdr->n_units, total) : 0;
+  if (threadIdx.x == 0) {
+    s_base = total ? atomicAdd(&hdr->n_units, total) : 0;
+    s_pbase = ptotal ? atomicAdd(&hdr->n_pslots, ptotal) : 0;
+  }
   __syncthreads();
   if (!mine) return;
   int off = s_base + woff + incl - mine;
+  int poff = s_pbase + pwoff + pincl - pmine;
   while (hugemask) {
     const int i = __ffs((int)hugemask) - 1;
     hugemask &= hugemask - 1;
     const int r = i * nthreads + tid;
     const int len = rowptr[r + 1] - rowptr[r];
     const int nch = (len + ch - 1) / ch;
-    for (int k = 0; k < nch; k++) units[off + k] = make_int4(r, k, off, nch);
+    // unit = {row, index in row, first partial slot of the row (-1: single unit, writes C directly), units in row}
+    for (int k = 0; k < nch; k++) units[off + k] = make_int4(r, k, nch > 1 ? poff : -1, nch);
     off += nch;
+    if (nch > 1) poff += nch;
   }
 }
 
@@ -622,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
   for (int i0 = (blockIdx.x * (kBlock / kWave) + wave) * kWave; i0 < n_units; i0 += wstride) {
    // 64 descriptors per wave-load; rows to fold = first unit of a multi-unit row
    int4 dl = make_int4(0, 1, 0, 0);
-   if (i0 + lane < n_units) dl = units[i0 + lane];  // {row, unit index in row, first unit of the row, units in row}
+   if (i0 + lane < n_units) dl = units[i0 + lane];  // {row, unit index in row, first partial slot of the row, units in row}
    unsigned long long todo = __ballot(dl.y == 0 && dl.w > 1);
    while (todo) {
     const int src = __ffsll((long long)todo) - 1;
