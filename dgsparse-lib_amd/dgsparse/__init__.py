@@ -12,6 +12,7 @@ from .spmm import spmm_max, spmm_mean, spmm_min, spmm_sum
 from .storage import Storage
 from .tensor import SparseTensor
 from . import nn  # noqa: F401,E402
+from . import gspmm  # noqa: F401,E402  (GSpMM_u_e / GSpMM_u of the reference's gspmm-fp module)
 
 __version__ = '0.1'
 

@@ -45,6 +45,10 @@ _lib.dgs_csr2csc_workspace_bytes.restype = _sz
 _lib.dgs_csr2csc_workspace_bytes.argtypes = [_i64, _i64, _i64]
 _lib.dgs_csr2csc_i32.restype = _int
 _lib.dgs_csr2csc_i32.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
+_lib.dgs_gspmm_csr_workspace_bytes.restype = _sz
+_lib.dgs_gspmm_csr_workspace_bytes.argtypes = [_int, _int, _i64, _i64, _i64]
+_lib.dgs_gspmm_csr_f32.restype = _int
+_lib.dgs_gspmm_csr_f32.argtypes = [_int, _int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
 _lib.dgs_sddmm_coo_f32.restype = _int
 _lib.dgs_sddmm_coo_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]
 _lib.dgs_gather_rows_f32.restype = _int
@@ -54,7 +58,7 @@ _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
 EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
            'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
-           'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'dgs_sddmm_coo_f32', 'gespmmCsrSpMM',
+           'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'dgs_sddmm_coo_f32', 'dgs_gspmm_csr_workspace_bytes', 'dgs_gspmm_csr_f32', 'gespmmCsrSpMM',
            'spmm_cuda', 'spmm_cuda_no_edge_value', 'sddmm_cuda_csr', 'sddmm_cuda_coo', 'gespmmAlgSel',
            'csrspmm_parreduce_rowbalance', 'csrspmm_parreduce_nnzbalance', 'csrspmm_seqreduce_rowbalance',
            'csrspmm_seqreduce_nnzbalance', 'csrspmm_rowcaching_rowbalance', 'csrspmm_rowcaching_nnzbalance']
@@ -204,6 +208,23 @@ def sddmm(rowptr, col, D1, D2, reduce_op=SUM, E=None):
         else:
             _check(_lib.dgs_sddmm_csr_f32(reduce_op, M, D2.shape[0], F, nnz, _p(rowptr), _p(col), _p(D1), _p(D2),
                                           _p(out), _stream(dev)), 'sddmm')
+    return out
+
+
+def gspmm(reduce_op, compute_op, rowptr, col, values, dense):
+    """C = reduce_p compute(values[p], dense[col[p]]); compute_op 0 add / 1 sub (x - w) / 2 mul / 3 div (x / w)."""
+    dev = _need_gpu(rowptr, col, values, dense)
+    rowptr = _i32(rowptr, 'rowptr')
+    col = _i32(col, 'col')
+    dense = _f32mat(dense, 'dense')
+    M, nnz, (K, N) = rowptr.numel() - 1, col.numel(), dense.shape
+    values = _f32vec(values, 'values', nnz)
+    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    with _on_device(dev):
+        wsb = _lib.dgs_gspmm_csr_workspace_bytes(reduce_op, compute_op, M, N, nnz)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        _check(_lib.dgs_gspmm_csr_f32(reduce_op, compute_op, M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(dense),
+                                      _p(out), _p(ws), wsb, _stream(dev)), 'gspmm')
     return out
 
 

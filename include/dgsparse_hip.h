@@ -97,6 +97,16 @@ int dgs_sddmm_csr_mask_f32(int64_t M, int64_t K, int64_t F, int64_t nnz, const i
                            const int32_t *col, const float *D1, const float *D2, const int32_t *E,
                            float *out, dgsStream_t stream);
 
+/* Generalised SpMM of the reference's gspmm-fp demo module (src/gspmm-fp/gspmm.cc:9-28, GSpMM_u_e / GSpMM_u):
+ *   C[r,:] = reduce_p compute(val[p], B[col[p],:]),  compute_op: 0 ADD a+b, 1 SUB b-a, 2 MUL a*b, 3 DIV b/a
+ * (enum COMPUTEOP, src/gspmm-fp/gspmm.h:16); val == NULL means weight 1 (GSpMM_u).  No arg output.  MUL+sum/mean runs
+ * the full SpMM schedule (and needs its workspace); everything else a compact sequential-row kernel. */
+enum { DGS_COMPUTE_ADD = 0, DGS_COMPUTE_SUB = 1, DGS_COMPUTE_MUL = 2, DGS_COMPUTE_DIV = 3 };
+size_t dgs_gspmm_csr_workspace_bytes(int reduce_op, int compute_op, int64_t M, int64_t N, int64_t nnz);
+int dgs_gspmm_csr_f32(int reduce_op, int compute_op, int64_t M, int64_t K, int64_t N, int64_t nnz,
+                      const int32_t *rowptr, const int32_t *col, const float *val, const float *B, float *C,
+                      void *workspace, size_t workspace_bytes, dgsStream_t stream);
+
 /* COO SDDMM: out[e] = sum_k D1[rowind[e],k] * D2[colind[e],k].
  * Replaces: sddmm_cuda_coo(), src/cuda/spmm_cuda.cu:305-329 (sddmmCOO{4,2,1}Scale, include/cuda/sddmm_cuda.cuh:13-220)
  *           and the standalone C entry src/sddmm/sddmm.h:7. */

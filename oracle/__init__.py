@@ -117,6 +117,21 @@ def spmm_sum_f64(rowptr, col, val, B, mean=False, absval=False):
     return C
 
 
+def gspmm(reduce, compute, rowptr, col, val, B):
+    """Generalised SpMM (gspmm-fp): compute in {'add','sub','mul','div'} = COMPUTEOP {0,1,2,3}."""
+    rop = REDUCE[reduce] if isinstance(reduce, str) else int(reduce)
+    cop = {'add': 0, 'sub': 1, 'mul': 2, 'div': 3}[compute] if isinstance(compute, str) else int(compute)
+    rowptr, p0 = _i(rowptr)
+    col, p1 = _i(col)
+    val, p2 = _f(val)
+    B, p3 = _f(B)
+    C = np.empty((rowptr.shape[0] - 1, B.shape[1]), np.float32)
+    f = lib().orc_gspmm_csr_f32
+    f.argtypes = [ctypes.c_int, ctypes.c_int, _i64, _i64, _i32p, _i32p, _f32p, _f32p, _f32p]
+    assert f(rop, cop, rowptr.shape[0] - 1, B.shape[1], p0, p1, p2, p3, C.ctypes.data_as(_f32p)) == 0
+    return C
+
+
 def spmm_mask(colptr, row, tval, G, E, fma=False):
     """max/min backward w.r.t. dense, on the CSC arrays.  Returns gX[Kcols,N]."""
     colptr, p0 = _i(colptr)

@@ -245,3 +245,38 @@ int orc_spmm_sum_f64(int mean, int absval, int64_t M, int64_t N, const int32_t *
   }
   return 0;
 }
+
+/*
+ * Generalised SpMM of the reference's gspmm-fp demo module: out[r,f] = reduce_p compute(val[p], B[col[p],f]) with
+ * compute in {ADD a+b, SUB b-a, MUL a*b, DIV b/a} (src/gspmm-fp/gspmm.h:15-79: enum COMPUTEOP { ADD, SUB, MUL, DIV })
+ * and the simple sequential kernel weightedSimpleSPMMKernel (src/gspmm-fp/gspmm.cu:212-245): acc starts at
+ * init(reduce) for non-empty rows, 0 for empty ones; MEAN divides by the row length.  No arg output.
+ */
+int orc_gspmm_csr_f32(int reduce_op, int compute_op, int64_t M, int64_t N, const int32_t *rowptr, const int32_t *col,
+                      const float *val, const float *B, float *C) {
+  if (reduce_op < 0 || reduce_op > 3 || compute_op < 0 || compute_op > 3) return -1;
+  for (int64_t r = 0; r < M; r++) {
+    const int64_t s = rowptr[r], e = rowptr[r + 1];
+    for (int64_t f = 0; f < N; f++) {
+      float acc = (e > s) ? orc_init(reduce_op) : 0.0f;
+      for (int64_t p = s; p < e; p++) {
+        const float a = val ? val[p] : 1.0f, b = B[(int64_t)col[p] * N + f];
+        float t;
+        switch (compute_op) {
+        case 0: t = a + b; break;
+        case 1: t = b - a; break;
+        case 2: t = a * b; break;
+        default: t = b / a;
+        }
+        switch (reduce_op) {
+        case ORC_MAX: acc = (acc < t) ? t : acc; break;
+        case ORC_MIN: acc = (acc < t) ? acc : t; break;
+        default: acc = acc + t;
+        }
+      }
+      if (reduce_op == ORC_MEAN && e > s) acc /= (float)(e - s);
+      C[r * N + f] = acc;
+    }
+  }
+  return 0;
+}

@@ -401,3 +401,29 @@ def test_spmm_randomized_stress(capi):
             D1 = (rng.integers(-3, 4, (M, N)) / 8).astype(np.float32)
             out = capi.sddmm(dev(rp), dev(col), dev(D1), dev(X)).cpu().numpy()
             assert_close(out, oracle.sddmm(rp, col, D1, X, fma=True), RTOL, 1e-5, f'sddmm it={it}')
+
+
+@pytest.mark.parametrize('N', [5, 32, 64, 96])
+def test_gspmm_u_e_all_ops(capi, N):
+    """gspmm-fp surface: every REDUCEOP x COMPUTEOP against the oracle restatement of its simple kernel (sequential
+    order on both sides => max/min bit-exact; sums within 1e-5 of the no-FMA chain)."""
+    from dgsparse import gspmm
+    M, K = 3000, 2500
+    rp, col = rand_graph(M, K, 40000, seed=N)
+    val = (graphgen.weights(col.shape[0], 'uniform', N) + np.float32(0.25)).astype(np.float32)  # no zeros: DIV
+    X = graphgen.features(K, N, N) - np.float32(0.5)
+    drp, dcol, dval, dX = dev(rp), dev(col), dev(val), dev(X)
+    for red in gspmm.REDUCEOP:
+        for comp in gspmm.COMPUTEOP:
+            out = gspmm.GSpMM_u_e(drp, dcol, dval.view(-1, 1), dX, red, comp).cpu().numpy()
+            ref = oracle.gspmm(int(red), int(comp), rp, col, val, X)
+            if red in (gspmm.REDUCEOP.MAX, gspmm.REDUCEOP.MIN):
+                assert_bitexact(out, ref, f'{red.name} {comp.name}')
+            else:
+                assert_close(out, ref, RTOL, 1e-5, f'{red.name} {comp.name}')
+        out = gspmm.GSpMM_u(drp, dcol, dX, red).cpu().numpy()
+        ref = oracle.gspmm(int(red), 2, rp, col, None, X)
+        if red in (gspmm.REDUCEOP.MAX, gspmm.REDUCEOP.MIN):
+            assert_bitexact(out, ref, f'u {red.name}')
+        else:
+            assert_close(out, ref, RTOL, 1e-5, f'u {red.name}')
