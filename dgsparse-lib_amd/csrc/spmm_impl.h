@@ -118,8 +118,12 @@ __device__ __forceinline__ bool arg_better(float mine, int mypos, float other, i
   return (mine > other) || (mine == other && opos < mypos);
 }
 
+// ei/ep: arg column id and the position of its FIRST strict improvement.  el: position of the LAST time the value
+// was (re)assigned - needed only for MIN, whose macro `(acc < t) ? acc : t` takes the LATER operand on a tie, so that
+// among equal minima (+0.0 / -0.0 are the only equal floats with different bits) the value of the last one survives
+// while E still names the first one.  MAX keeps the earlier operand on a tie, so value and E travel together.
 template <int G, int V, int OP>
-__device__ __forceinline__ void cross_group_reduce(float (&acc)[V], int (&ei)[V], int (&ep)[V]) {
+__device__ __forceinline__ void cross_group_reduce(float (&acc)[V], int (&ei)[V], int (&ep)[V], int (&el)[V]) {
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
 #pragma unroll
   for (int m = G; m < 64; m <<= 1) {
@@ -129,10 +133,29 @@ __device__ __forceinline__ void cross_group_reduce(float (&acc)[V], int (&ei)[V]
       if constexpr (ARG) {
         const int oi = __shfl_xor(ei[v], m, 64);
         const int op = __shfl_xor(ep[v], m, 64);
-        if (arg_better<OP>(acc[v], ep[v], o, op)) {
-          acc[v] = o;
-          ei[v] = oi;
-          ep[v] = op;
+        if constexpr (OP == DGS_MIN) {
+          const int ol = __shfl_xor(el[v], m, 64);
+          if (acc[v] > o) {
+            acc[v] = o;
+            ei[v] = oi;
+            ep[v] = op;
+            el[v] = ol;
+          } else if (acc[v] == o) {
+            if (op < ep[v]) {
+              ei[v] = oi;
+              ep[v] = op;
+            }
+            if (ol > el[v]) {
+              acc[v] = o;
+              el[v] = ol;
+            }
+          }
+        } else {
+          if (arg_better<OP>(acc[v], ep[v], o, op)) {
+            acc[v] = o;
+            ei[v] = oi;
+            ep[v] = op;
+          }
         }
       } else {
         acc[v] += o;  // IEEE addition is commutative: both partners compute the same sum => fixed tree
@@ -143,7 +166,8 @@ __device__ __forceinline__ void cross_group_reduce(float (&acc)[V], int (&ei)[V]
 
 // position-tracking reduction step for the split path (pos = CSR position, or unit index in K3)
 template <int OP>
-__device__ __forceinline__ void reduce_step_pos(float &res, int &eidx, int &epos, float w, float x, int c, int pos) {
+__device__ __forceinline__ void reduce_step_pos(float &res, int &eidx, int &epos, int &elast, float w, float x, int c,
+                                                int pos) {
   if constexpr (OP == DGS_MAX) {
     const float t = w * x;
     if (res < t) {
@@ -157,6 +181,7 @@ __device__ __forceinline__ void reduce_step_pos(float &res, int &eidx, int &epos
       eidx = c;
       epos = pos;
     }
+    if (!(res < t)) elast = pos;  // the macro assigns t here (also on ties)
     res = (res < t) ? res : t;
   } else {
     res = __builtin_fmaf(w, x, res);
@@ -250,7 +275,8 @@ template <int G, int V, int OP, bool HAS_VAL>
 __device__ __forceinline__ void coop_accumulate(int p0, int p1, int lane, int g, int f0, bool fl, int N,
                                                 const int *__restrict__ col, const float *__restrict__ val,
                                                 const float *__restrict__ B, const int *__restrict__ Em, int orow,
-                                                int2 *tile, float (&acc)[V], int (&ei)[V], int (&ep)[V]) {
+                                                int2 *tile, float (&acc)[V], int (&ei)[V], int (&ep)[V],
+                                                int (&el)[V]) {
   constexpr int NG = kWave / G;
   for (int t0 = p0; t0 < p1; t0 += kWave) {
     const int cnt = min(kWave, p1 - t0);
@@ -288,7 +314,7 @@ __device__ __forceinline__ void coop_accumulate(int p0, int p1, int lane, int g,
             if constexpr (OP == kOpMaskSum) {
               if (m[q][v] == orow) acc[v] = __builtin_fmaf(w[q], x[q][v], acc[v]);
             } else {
-              reduce_step_pos<OP>(acc[v], ei[v], ep[v], w[q], x[q][v], c[q], t0 + j + q * NG);
+              reduce_step_pos<OP>(acc[v], ei[v], ep[v], el[v], w[q], x[q][v], c[q], t0 + j + q * NG);
             }
           }
         }
@@ -494,15 +520,16 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
     med &= med - 1;
     const int rs = __shfl(s_i, r, 64), re = __shfl(e_i, r, 64);
     float acc[V];
-    int ei[V], ep[V];
+    int ei[V], ep[V], el[V];
 #pragma unroll
     for (int v = 0; v < V; v++) {
       acc[v] = reduce_init<OP>();
       ei[v] = -1;
       ep[v] = INT_MAX;
+      el[v] = -1;
     }
-    coop_accumulate<G, V, OP, HAS_VAL>(rs, re, lane, g, f0, fl, N, col, val, B, E, r0 + r, tile, acc, ei, ep);
-    cross_group_reduce<G, V, OP>(acc, ei, ep);
+    coop_accumulate<G, V, OP, HAS_VAL>(rs, re, lane, g, f0, fl, N, col, val, B, E, r0 + r, tile, acc, ei, ep, el);
+    cross_group_reduce<G, V, OP>(acc, ei, ep, el);
     if (g == 0 && fl) {
       if constexpr (OP == DGS_MEAN) {
         const float dg = (float)(re - rs);
@@ -554,15 +581,16 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
     const int p0 = rs + d.y * ch;
     const int p1 = min(p0 + ch, re);
     float acc[V];
-    int ei[V], ep[V];
+    int ei[V], ep[V], el[V];
 #pragma unroll
     for (int v = 0; v < V; v++) {
       acc[v] = reduce_init<OP>();
       ei[v] = -1;
       ep[v] = INT_MAX;
+      el[v] = -1;
     }
-    coop_accumulate<G, V, OP, HAS_VAL>(p0, p1, lane, g, f0, fl, N, col, val, B, E, d.x, tile, acc, ei, ep);
-    cross_group_reduce<G, V, OP>(acc, ei, ep);
+    coop_accumulate<G, V, OP, HAS_VAL>(p0, p1, lane, g, f0, fl, N, col, val, B, E, d.x, tile, acc, ei, ep, el);
+    cross_group_reduce<G, V, OP>(acc, ei, ep, el);
     if (g == 0 && fl) {
       if (d.w == 1) {  // the whole row was this unit: final result
         if constexpr (OP == DGS_MEAN) {
@@ -655,12 +683,13 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
     d.z = __shfl(dl.z, src, 64);
     d.w = __shfl(dl.w, src, 64);
     float acc[V];
-    int ei[V], ep[V];
+    int ei[V], ep[V], el[V];
 #pragma unroll
     for (int v = 0; v < V; v++) {
       acc[v] = reduce_init<OP>();
       ei[v] = -1;
       ep[v] = INT_MAX;
+      el[v] = -1;
     }
     for (int k = g; k < d.w; k += NG * UP) {
       float x[UP][V];
@@ -678,7 +707,21 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
         if (k + q * NG < d.w && fl) {
 #pragma unroll
           for (int v = 0; v < V; v++) {
-            if constexpr (ARG) {
+            if constexpr (OP == DGS_MIN) {
+              // units arrive in increasing k inside a group: a strictly smaller partial takes everything, an equal
+              // one only refreshes the value (later operand wins ties in the MIN macro); E=-1 partials never improved
+              if (xe[q][v] != -1) {
+                if (acc[v] > x[q][v]) {
+                  acc[v] = x[q][v];
+                  ei[v] = xe[q][v];
+                  ep[v] = k + q * NG;
+                  el[v] = k + q * NG;
+                } else if (acc[v] == x[q][v]) {
+                  acc[v] = x[q][v];
+                  el[v] = k + q * NG;
+                }
+              }
+            } else if constexpr (ARG) {
               // a partial that never improved on the identity carries E=-1 and must not win
               if (xe[q][v] != -1 && arg_better<OP>(acc[v], ep[v], x[q][v], k + q * NG)) {
                 acc[v] = x[q][v];
@@ -692,7 +735,7 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
         }
       }
     }
-    cross_group_reduce<G, V, OP>(acc, ei, ep);
+    cross_group_reduce<G, V, OP>(acc, ei, ep, el);
     if (g == 0 && fl) {
       if constexpr (OP == DGS_MEAN) {
         const float dg = (float)(rowptr[d.x + 1] - rowptr[d.x]);

@@ -146,6 +146,21 @@ def spmm_mask(colptr, row, tval, G, E, fma=False):
     return out
 
 
+def spmm_mask_f64(colptr, row, tval, G, E, absval=False):
+    """float64 yardstick of spmm_mask (absval: condition scale sum|val*G| over the passing entries)."""
+    colptr, p0 = _i(colptr)
+    row, p1 = _i(row)
+    tval, p2 = _f(tval)
+    G, p3 = _f(G)
+    E, p4 = _i(E)
+    Mo, N = colptr.shape[0] - 1, G.shape[1]
+    out = np.empty((Mo, N), np.float64)
+    f = lib().orc_spmm_mask_f64
+    f.argtypes = [ctypes.c_int, _i64, _i64, _i32p, _i32p, _f32p, _f32p, _i32p, ctypes.POINTER(ctypes.c_double)]
+    assert f(int(absval), Mo, N, p0, p1, p2, p3, p4, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == 0
+    return out
+
+
 def sddmm(rowptr, col, D1, D2, reduce='sum', fma=False, threads=1):
     op = REDUCE[reduce] if isinstance(reduce, str) else int(reduce)
     rowptr, p0 = _i(rowptr)

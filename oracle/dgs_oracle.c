@@ -280,3 +280,22 @@ int orc_gspmm_csr_f32(int reduce_op, int compute_op, int64_t M, int64_t N, const
   }
   return 0;
 }
+
+/* float64 yardstick of orc_spmm_csr_mask_f32 (same role as orc_spmm_sum_f64). absval: sum of |val*G| over the
+ * entries that pass the mask (condition scale). */
+int orc_spmm_mask_f64(int absval, int64_t Mout, int64_t N, const int32_t *ptr, const int32_t *idx, const float *val,
+                      const float *G, const int32_t *E, double *out) {
+  for (int64_t j = 0; j < Mout; j++)
+    for (int64_t f = 0; f < N; f++) {
+      double res = 0.0;
+      for (int64_t p = ptr[j]; p < ptr[j + 1]; p++) {
+        const int64_t i = idx[p];
+        if (E[i * N + f] == (int32_t)j) {
+          const double t = (double)(val ? val[p] : 1.0f) * (double)G[i * N + f];
+          res += absval ? fabs(t) : t;
+        }
+      }
+      out[j * N + f] = res;
+    }
+  return 0;
+}

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Long-running randomized parity campaign (not collected by pytest): python tests/fuzz_gpu.py [seconds] [seed].
+Random shapes / degree laws / value kinds / feature widths, every reduce + SDDMM + masked backward + csr2csc, each
+checked against the CPU oracle with the same bars as tests/test_gpu_parity.py.  Prints one line per 50 cases."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'dgsparse-lib_amd'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+import oracle  # noqa: E402
+from bench import graphgen  # noqa: E402
+from dgsparse import _capi as capi  # noqa: E402
+from util import assert_bitexact, assert_close, assert_sum_parity  # noqa: E402
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def one_case(rng, it):
+    M = int(rng.choice([1, 3, 64, 65, 255, 256, 1000, 4096, 4097, 30000, 66000, 200000]))
+    K = int(rng.choice([1, 2, 33, 1000, 20000, 150000]))
+    N = int(rng.choice([1, 2, 3, 4, 8, 12, 16, 31, 32, 33, 64, 65, 100, 128, 256, 260]))
+    per = float(rng.choice([0.0, 0.5, 3, 16, 60]))
+    nnz = int(min(M * per, 1.5e6))
+    alpha = float(rng.choice([1.5, 2.1, 3.0, 50.0]))
+    dmax = int(rng.choice([4, 64, 300, 5000, 100000]))
+    rp, col, st = graphgen.powerlaw_csr(M, max(nnz, 1), K=K, alpha=alpha, dmax=max(1, min(K * 3, dmax)), seed=it,
+                                        dedup=bool(rng.integers(0, 2)), cols=str(rng.choice(['uniform', 'powerlaw'])))
+    if rng.integers(0, 3) == 0 and col.shape[0]:  # unsorted columns in some rows
+        col = col.copy()
+        for r in rng.integers(0, M, 8):
+            rng.shuffle(col[rp[r]:rp[r + 1]])
+    kind = [None, 'tied', 'signed', 'uniform'][int(rng.integers(0, 4))]
+    val = graphgen.weights(col.shape[0], kind, it) if kind else None
+    X = (rng.integers(-3, 4, (K, N)) / 8).astype(np.float32)
+    tag = f'it={it} M={M} K={K} N={N} nnz={col.shape[0]} maxdeg={st["max_deg"]} val={kind}'
+    drp, dcol, dval, dX = dev(rp), dev(col), (None if val is None else dev(val)), dev(X)
+    C64 = oracle.spmm_sum_f64(rp, col, val, X)
+    S64 = oracle.spmm_sum_f64(rp, col, val, X, absval=True)
+    Emax = None
+    for reduce in ('sum', 'mean', 'max', 'min'):
+        C, E = capi.spmm(oracle.REDUCE[reduce], drp, dcol, dval, dX)
+        C = C.cpu().numpy()
+        Co, Eo = oracle.spmm(reduce, rp, col, val, X, fma=True)
+        if reduce in ('max', 'min'):
+            assert_bitexact(C, Co, tag + ' ' + reduce)
+            assert_bitexact(E.cpu().numpy(), Eo, tag + ' E ' + reduce)
+            if reduce == 'max':
+                Emax = Eo
+        else:
+            sc = 1 if reduce == 'sum' else np.maximum(np.diff(rp), 1)[:, None]
+            assert_sum_parity(C, Co, C64 / sc, S64 / sc, 1e-5, 2e-6, tag + ' ' + reduce)
+    if col.shape[0]:
+        D1 = (rng.integers(-3, 4, (M, N)) / 8).astype(np.float32)
+        dD1 = dev(D1)
+        assert_close(capi.sddmm(drp, dcol, dD1, dX).cpu().numpy(), oracle.sddmm(rp, col, D1, X, fma=True), 1e-5, 1e-5,
+                     tag + ' sddmm')
+        assert_close(capi.sddmm(drp, dcol, dD1, dX, E=dev(Emax)).cpu().numpy(),
+                     oracle.sddmm_mask(rp, col, D1, X, Emax, fma=True), 1e-5, 1e-5, tag + ' sddmm_mask')
+        colptr, row, tval, perm = oracle.csr2csc(rp, col, val, K)
+        gcolptr, grow, gval, gperm = capi.csr2csc(drp, dcol, dval, K)
+        assert_bitexact(gcolptr.cpu().numpy(), colptr, tag + ' colptr')
+        assert_bitexact(grow.cpu().numpy(), row, tag + ' cscrow')
+        assert_bitexact(gperm.cpu().numpy(), perm, tag + ' perm')
+        gX = capi.spmm_mask(gcolptr, grow, gval, dD1, dev(Emax)).cpu().numpy()
+        ref = oracle.spmm_mask(colptr, row, tval, D1, Emax, fma=True)
+        assert_sum_parity(gX, ref, oracle.spmm_mask_f64(colptr, row, tval, D1, Emax),
+                          oracle.spmm_mask_f64(colptr, row, tval, D1, Emax, absval=True), 1e-5, 2e-6, tag + ' spmm_mask')
+    return tag
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    t0, it = time.time(), 0
+    while time.time() - t0 < budget:
+        tag = one_case(rng, seed * 100000 + it)
+        it += 1
+        if it % 50 == 0:
+            print(f'{it} cases ok, {time.time() - t0:.0f} s, last: {tag}', flush=True)
+    print(f'FUZZ OK: {it} cases in {time.time() - t0:.0f} s (seed {seed})')
+
+
+if __name__ == '__main__':
+    main()

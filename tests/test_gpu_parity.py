@@ -290,8 +290,8 @@ def test_masked_backward_with_hub_columns(capi, N):
     _, E = oracle.spmm('max', rp, col, val, X)
     gX = capi.spmm_mask(dev(colptr), dev(row), dev(tval), dev(G), dev(E)).cpu().numpy()
     ref = oracle.spmm_mask(colptr, row, tval, G, E, fma=True)
-    S = oracle.spmm_sum_f64(colptr, row, np.abs(tval), np.abs(G), absval=True)
-    assert_sum_parity(gX, ref, ref.astype(np.float64), S, RTOL, ATOL, 'spmm_mask')
+    assert_sum_parity(gX, ref, oracle.spmm_mask_f64(colptr, row, tval, G, E),
+                      oracle.spmm_mask_f64(colptr, row, tval, G, E, absval=True), RTOL, ATOL, 'spmm_mask')
     gW = capi.sddmm(dev(rp), dev(col), dev(G), dev(X), E=dev(E)).cpu().numpy()
     assert_close(gW, oracle.sddmm_mask(rp, col, G, X, E, fma=True), RTOL, ATOL, 'sddmm_mask')
 
@@ -427,3 +427,23 @@ def test_gspmm_u_e_all_ops(capi, N):
             assert_bitexact(out, ref, f'u {red.name}')
         else:
             assert_close(out, ref, RTOL, 1e-5, f'u {red.name}')
+
+
+@pytest.mark.parametrize('N', [16, 64])
+def test_signed_zero_ties_on_split_rows(capi, N):
+    """+0.0 and -0.0 compare equal but differ in bits.  The reference macros keep the EARLIER operand on a MAX tie and
+    the LATER one on a MIN tie ((acc<t)?acc:t), while E names the first strict improvement; rows longer than the
+    sequential threshold must reproduce that across groups, units and partial rows."""
+    M, K = 40, 3
+    lens = [70, 300, 1000, 5000] * 10
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    rng = np.random.default_rng(N)
+    col = rng.integers(0, K, int(rp[-1])).astype(np.int32)
+    val = rng.choice(np.array([1.0, -1.0, 0.5, -0.5], np.float32), int(rp[-1]))
+    X = np.zeros((K, N), np.float32)  # every product is +0.0 or -0.0
+    X[2] = np.where(rng.integers(0, 2, N) > 0, 0.0, 3.0)  # some columns also see real values
+    for reduce in ('max', 'min'):
+        C, E = run_spmm(capi, reduce, rp, col, val, X)
+        Co, Eo = oracle.spmm(reduce, rp, col, val, X)
+        assert_bitexact(C, Co, reduce + ' values (signed zeros)')
+        assert_bitexact(E, Eo, reduce + ' E')
