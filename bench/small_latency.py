@@ -37,3 +37,15 @@ for name in ['cora','pubmed']:
     torch.cuda.synchronize(); t=time.perf_counter()
     for _ in range(300): fb()
     torch.cuda.synchronize(); print(name,'fwd+bwd (dX only) us/iter',(time.perf_counter()-t)/300*1e6)
+    # HIP-graph replay of the same forward (capture-safe C ABI: no allocation, no sync, caller's stream)
+    s_ = torch.cuda.Stream(); s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        for _ in range(3): dgsparse.spmm_sum(A, X, 0)
+    torch.cuda.current_stream().wait_stream(s_)
+    g_ = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g_):
+        out_ = dgsparse.spmm_sum(A, X, 0)
+    for _ in range(20): g_.replay()
+    torch.cuda.synchronize(); t=time.perf_counter()
+    for _ in range(1000): g_.replay()
+    torch.cuda.synchronize(); print(name,'HIP graph replay us/call',(time.perf_counter()-t)/1000*1e6)

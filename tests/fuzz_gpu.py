@@ -55,7 +55,7 @@ def one_case(rng, it):
                 Emax = Eo
         else:
             sc = 1 if reduce == 'sum' else np.maximum(np.diff(rp), 1)[:, None]
-            assert_sum_parity(C, Co, C64 / sc, S64 / sc, 1e-5, 2e-6, tag + ' ' + reduce)
+            assert_sum_parity(C, Co, C64 / sc, S64 / sc, 1e-5, 2e-6, tag + ' ' + reduce, lens=np.diff(rp))
     if col.shape[0]:
         D1 = (rng.integers(-3, 4, (M, N)) / 8).astype(np.float32)
         dD1 = dev(D1)
@@ -71,7 +71,8 @@ def one_case(rng, it):
         gX = capi.spmm_mask(gcolptr, grow, gval, dD1, dev(Emax)).cpu().numpy()
         ref = oracle.spmm_mask(colptr, row, tval, D1, Emax, fma=True)
         assert_sum_parity(gX, ref, oracle.spmm_mask_f64(colptr, row, tval, D1, Emax),
-                          oracle.spmm_mask_f64(colptr, row, tval, D1, Emax, absval=True), 1e-5, 2e-6, tag + ' spmm_mask')
+                          oracle.spmm_mask_f64(colptr, row, tval, D1, Emax, absval=True), 1e-5, 2e-6, tag + ' spmm_mask',
+                          lens=np.diff(colptr))
     return tag
 
 

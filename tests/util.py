@@ -56,19 +56,23 @@ def assert_bitexact(a, b, what=''):
                              f'{a[tuple(i)]!r} vs {b[tuple(i)]!r}')
 
 
-def assert_sum_parity(C, Cseq, C64, S64=None, rtol=1e-5, atol=2e-6, what=''):
+def assert_sum_parity(C, Cseq, C64, S64=None, rtol=1e-5, atol=2e-6, what='', lens=None):
     """north_star bar for sum/mean: within 1e-5 relative of the reference's sequential fp32 result.  Where that
     cannot be meaningful -- rows with thousands of nnz, whose sequential fp32 chain is itself further than 1e-5
     from the exact (float64) sum, or cancelling signed data -- the result must instead be at least as close to the
-    exact value as the sequential chain is, or within 1e-6 of the row's condition scale S = sum|w*x|
-    (for the reference's non-negative test data S == |C|, i.e. ten times tighter than 1e-5)."""
+    exact value as the sequential chain is, or within gamma of the row's condition scale S = sum|w*x|, with
+    gamma = max(1e-6, eps/2 * sqrt(n)) for a row of n terms (the statistical error of ANY fp32 summation order; for
+    the reference's non-negative test data S == |C| and n <= 1e4, i.e. at least three times tighter than 1e-5)."""
     C = np.asarray(C, np.float64)
     Cseq = np.asarray(Cseq, np.float64)
     ok = np.isclose(C, Cseq, rtol=rtol, atol=atol)
     err_gpu = np.abs(C - C64)
     err_seq = np.abs(Cseq - C64)
     scale = np.abs(C64) if S64 is None else S64
-    ok |= err_gpu <= np.maximum(err_seq, 1e-6 * scale)
+    gamma = 1e-6
+    if lens is not None:
+        gamma = np.maximum(1e-6, 3e-8 * np.sqrt(np.asarray(lens, np.float64)))[:, None]
+    ok |= err_gpu <= np.maximum(err_seq, gamma * scale)
     if not ok.all():
         i = tuple(np.argwhere(~ok)[0])
         raise AssertionError(f'{what}: {(~ok).sum()} / {ok.size} outside the sum bar; first at {i}: gpu {C[i]!r} '
