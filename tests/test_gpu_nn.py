@@ -75,3 +75,15 @@ def test_gin_matches_dense(agg):
     ref.sum().backward()
     assert torch.allclose(gx, x2.grad, rtol=1e-4, atol=1e-4)
     assert model.conv1._cached_dcsr is not None
+
+
+def test_gcn_training_example_runs():
+    """examples/train_gcn.py: 2-layer GCN trained end to end (SpMM fwd, SDDMM + transposed SpMM bwd); the loss
+    trajectory must match the same model on torch.sparse.mm."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'examples', 'train_gcn.py'), '--dataset', 'cora', '--epochs',
+                          '10'], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'loss trajectories match' in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
