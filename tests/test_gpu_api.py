@@ -177,8 +177,13 @@ def test_rccl_collectives_single_rank():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import socket
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
-                          '--master-addr', '127.0.0.1', '--master-port', '29533',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port),
                           os.path.join(root, 'tests', 'nccl_selftest.py')], capture_output=True, text=True, env=env,
                          timeout=300)
     assert out.returncode == 0 and 'nccl selftest ok' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
