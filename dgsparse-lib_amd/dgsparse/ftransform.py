@@ -1,4 +1,4 @@
-"""``csr2csc(sparse)`` -- mirrors the reference dgsparse/ftransform.py:6-10."""
+"""Format transforms on a ``SparseTensor`` (reference ``dgsparse/ftransform.py:6-10``)."""
 from typing import Tuple
 
 import torch
@@ -7,7 +7,6 @@ from .tensor import SparseTensor
 
 
 def csr2csc(sparse: SparseTensor) -> Tuple[torch.Tensor]:
-    rowptr = sparse.storage._rowptr
-    col = sparse.storage._col
-    values = sparse.storage._values
-    return torch.ops.dgsparse_spmm.csr2csc(rowptr, col, values)
+    """(colptr, row indices, values) of the transposed matrix, values carried along in CSC order."""
+    st = sparse.storage
+    return torch.ops.dgsparse_spmm.csr2csc(st.rowptr(), st.col(), st.values())

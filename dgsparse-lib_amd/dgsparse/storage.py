@@ -1,10 +1,13 @@
-"""``Storage``: CSR arrays + the eagerly built CSC view, mirroring the reference dgsparse/storage.py:6-174
-(same constructor arguments, asserts, accessors raising ValueError, ``Storage.empty()``).
+"""``Storage`` -- the CSR arrays of a sparse matrix plus its CSC view.
 
-Differences (all inside the reference's documented intent):
-  * the CSR->CSC permutation is computed in integers by the HIP csr2csc (exact for any nnz; the reference
-    pushes arange(nnz) through cuSPARSE as float32 values, storage.py:164-169, exact only below 2^24);
-  * rectangular matrices work: the CSC has ``sparse_sizes[1] = col.max()+1`` columns (reference: n x n only).
+Behavioural mirror of the reference's ``dgsparse/storage.py:6-174`` (constructor arguments, what is asserted, which
+accessor raises ``ValueError`` when its array is absent, ``Storage.empty()``, eager CSR->CSC conversion), written
+independently.  Two intended differences:
+
+* the CSR->CSC permutation comes from the integer HIP ``csr2csc`` and is exact for any nnz -- the reference pushes
+  ``arange(nnz)`` through cuSPARSE as float32 *values* (storage.py:164-169), which is exact only below 2**24 entries;
+* rectangular matrices work: the CSC view has ``sparse_sizes[1] = col.max() + 1`` columns (the reference passes
+  ``n, n`` to cuSPARSE and is square-only).
 """
 from typing import Optional
 
@@ -12,170 +15,119 @@ import torch
 
 from . import _capi
 
+_INDEX = torch.int32
+
+
+def _index_array(t: torch.Tensor, like: torch.Tensor, numel: Optional[int] = None, dtypes=(_INDEX,)) -> torch.Tensor:
+    """Asserts the reference's invariants for an index array (dtype, 1-D, same device, length) -> contiguous."""
+    assert t.dtype in dtypes
+    assert t.dim() == 1
+    assert t.device == like.device
+    if numel is not None:
+        assert t.numel() == numel
+    return t.contiguous()
+
 
 class Storage(object):
+    # attribute names are part of the surface: the reference's tests and layers reach into them
     _row: Optional[torch.Tensor]
     _rowptr: Optional[torch.Tensor]
     _col: Optional[torch.Tensor]
     _values: Optional[torch.Tensor]
-    _colptr: torch.Tensor
-    _csr2csc: torch.Tensor
-    _csc2csr: torch.Tensor
+    _colptr: Optional[torch.Tensor]
+    _csr2csc: Optional[torch.Tensor]
+    _csc2csr: Optional[torch.Tensor]
     _colcount: Optional[torch.Tensor]
 
-    def __init__(
-        self,
-        row: Optional[torch.Tensor] = None,
-        rowptr: Optional[torch.Tensor] = None,
-        col: Optional[torch.Tensor] = None,
-        values: Optional[torch.Tensor] = None,
-        colptr: Optional[torch.Tensor] = None,
-        csr2csc: Optional[torch.Tensor] = None,
-        csc2csr: Optional[torch.Tensor] = None,
-        colcount: Optional[torch.Tensor] = None,
-    ):
-        assert row is not None or rowptr is not None
-        assert col is not None
-        assert col.dtype == torch.int
-        assert col.dim() == 1
+    def __init__(self, row=None, rowptr=None, col=None, values=None, colptr=None, csr2csc=None, csc2csr=None,
+                 colcount=None):
+        assert col is not None and (rowptr is not None or row is not None)
+        assert col.dtype == _INDEX and col.dim() == 1
         col = col.contiguous()
+        nnz = col.numel()
 
-        M: int = 0
         if rowptr is not None:
-            M = rowptr.numel() - 1
-        elif row is not None and row.numel() > 0:
-            M = int(row.max()) + 1
-
-        N: int = 0
-        if col.numel() > 0:
-            N = int(col.max()) + 1  # one device sync per construction, as the reference (storage.py:41-43)
-
-        self.sparse_sizes = (M, N)
-        self.nnz = col.size(0)
+            n_rows = rowptr.numel() - 1
+        else:
+            n_rows = int(row.max()) + 1 if row.numel() else 0
+        n_cols = int(col.max()) + 1 if nnz else 0  # one device sync per construction, like the reference
+        self.sparse_sizes = (n_rows, n_cols)
+        self.nnz = nnz
 
         if row is not None:
-            assert row.dtype == torch.int
-            assert row.device == col.device
-            assert row.dim() == 1
-            assert row.numel() == col.numel()
-            row = row.contiguous()
-
+            row = _index_array(row, col, nnz)
         if rowptr is not None:
-            assert rowptr.dtype == torch.int
-            assert rowptr.device == col.device
-            assert rowptr.dim() == 1
-            assert rowptr.numel() - 1 == self.sparse_sizes[0]
-            rowptr = rowptr.contiguous()
+            rowptr = _index_array(rowptr, col, n_rows + 1)
+        else:  # COO rows (sorted, as CSR order requires) -> row pointer
+            rowptr = torch.zeros(n_rows + 1, dtype=_INDEX, device=col.device)
+            if nnz:
+                rowptr[1:] = torch.cumsum(torch.bincount(row.long(), minlength=n_rows), 0)
 
-        if values is not None:
-            assert values.device == col.device
-            assert values.size(0) == self.nnz
-            values = values.contiguous()
+        if values is None:  # unit weights when the caller has none (reference: torch.ones)
+            values = torch.ones(nnz, dtype=torch.float32, device=col.device)
         else:
-            values = torch.ones((self.nnz), dtype=torch.float, device=col.device)
+            assert values.device == col.device and values.size(0) == nnz
+            values = values.contiguous()
 
+        # optional pre-computed CSC pieces (the reference wants int64 here and narrows later; both are accepted)
         if colptr is not None:
-            assert colptr.dtype in (torch.long, torch.int)
-            assert colptr.device == col.device
-            assert colptr.dim() == 1
-            assert colptr.numel() - 1 == self.sparse_sizes[1]
-            colptr = colptr.contiguous().to(torch.int)
-
+            colptr = _index_array(colptr, col, n_cols + 1, (torch.int64, _INDEX)).to(_INDEX)
         if csr2csc is not None:
-            assert csr2csc.dtype in (torch.long, torch.int)
-            assert csr2csc.device == col.device
-            assert csr2csc.dim() == 1
-            assert csr2csc.numel() == col.size(0)
-            csr2csc = csr2csc.contiguous().to(torch.int)
-
+            csr2csc = _index_array(csr2csc, col, nnz, (torch.int64, _INDEX)).to(_INDEX)
         if colcount is not None:
-            assert colcount.dtype == torch.long
-            assert colcount.device == col.device
-            assert colcount.dim() == 1
-            assert colcount.numel() == self.sparse_sizes[1]
-            colcount = colcount.contiguous()
+            colcount = _index_array(colcount, col, n_cols, (torch.int64,))
 
-        if rowptr is None:  # COO rows given: build rowptr (rows must be sorted, as CSR order requires)
-            counts = torch.bincount(row.long(), minlength=M)
-            rowptr = torch.zeros(M + 1, dtype=torch.int, device=col.device)
-            rowptr[1:] = torch.cumsum(counts, 0)
-
-        self._row = row
-        self._rowptr = rowptr
-        self._col = col
-        self._values = values
-        self._colptr = colptr
-        self._csr2csc = csr2csc
-        self._csc2csr = csc2csr
-        self._colcount = colcount
-
-        # convert
+        self._row, self._rowptr, self._col, self._values = row, rowptr, col, values
+        self._colptr, self._csr2csc, self._csc2csr, self._colcount = colptr, csr2csc, csc2csr, colcount
         self.csr2csc_convert()
 
     @classmethod
-    def empty(self):
-        row = torch.tensor([], dtype=torch.int)
-        col = torch.tensor([], dtype=torch.int)
-        return Storage(row=row, rowptr=None, col=col, values=None, colptr=None, csc2csr=None, csr2csc=None,
-                       colcount=None)
+    def empty(cls):
+        """A 0 x 0 matrix on the CPU (reference storage.py:102-116)."""
+        nothing = torch.tensor([], dtype=_INDEX)
+        return cls(row=nothing, rowptr=None, col=nothing.clone())
+
+    # ---- accessors: the array, or ValueError when it does not exist (reference storage.py:118-157) ----------------
+    def _present(self, name: str) -> torch.Tensor:
+        t = getattr(self, name)
+        if t is None:
+            raise ValueError
+        return t
 
     def row(self) -> torch.Tensor:
-        row = self._row
-        if row is not None:
-            return row
-        else:
-            raise ValueError
+        return self._present('_row')
 
     def rowptr(self) -> torch.Tensor:
-        rowptr = self._rowptr
-        if rowptr is not None:
-            return rowptr
-        else:
-            raise ValueError
+        return self._present('_rowptr')
 
     def col(self) -> torch.Tensor:
-        col = self._col
-        if col is not None:
-            return col
-        else:
-            raise ValueError
+        return self._present('_col')
 
     def colptr(self) -> torch.Tensor:
-        colptr = self._colptr
-        if colptr is not None:
-            return colptr
-        else:
-            raise ValueError
+        return self._present('_colptr')
 
     def values(self) -> torch.Tensor:
-        values = self._values
-        if values is not None:
-            return values
-        else:
-            raise ValueError
+        return self._present('_values')
 
     def csr2csc(self) -> torch.Tensor:
-        csr2csc = self._csr2csc
-        if csr2csc is not None:
-            return csr2csc
-        else:
-            raise ValueError
+        return self._present('_csr2csc')
 
     def csr2csc_convert(self):
-        """Builds (colptr, row-of-CSC, csr2csc permutation) once; storage.py:159-174 in the reference.
+        """Fills in whatever is missing of (colptr, CSC row indices, CSR->CSC permutation), once.
 
-        NB the reference stores the CSC row indices in ``_row`` (storage.py:170-171) and spmm passes that as the
-        ``row`` argument of the op; the same convention is kept."""
-        if self._csr2csc is not None and self._colptr is not None and self._row is not None:
+        As in the reference (storage.py:170-173) the CSC row indices land in ``_row`` when no COO rows were given, and
+        that is what the spmm operators pass as their ``row`` argument."""
+        if None not in (self._csr2csc, self._colptr, self._row):
             return self._csr2csc
         if self.nnz == 0:
             dev = self._col.device
-            self._colptr = torch.zeros(self.sparse_sizes[1] + 1, dtype=torch.int, device=dev)
-            self._row = torch.zeros(0, dtype=torch.int, device=dev)
-            self._csr2csc = torch.zeros(0, dtype=torch.int, device=dev)
-            return self._csr2csc
-        colptr, row, _, perm = _capi.csr2csc(self._rowptr, self._col, None, self.sparse_sizes[1], want_perm=True)
-        self._row = row
-        self._colptr = colptr
+            colptr = torch.zeros(self.sparse_sizes[1] + 1, dtype=_INDEX, device=dev)
+            csc_row = perm = torch.zeros(0, dtype=_INDEX, device=dev)
+        else:
+            colptr, csc_row, _, perm = _capi.csr2csc(self._rowptr, self._col, None, self.sparse_sizes[1], want_perm=True)
+        if self._row is None:
+            self._row = csc_row
+        if self._colptr is None:
+            self._colptr = colptr
         self._csr2csc = perm
-        return self._csr2csc
+        return perm
