@@ -247,8 +247,14 @@ static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, co
     ptotal += s_psum[w];
   }
   if (threadIdx.x == 0) {
-    s_base = total ? atomicAdd(&hdr->n_units, total) : 0;
-    s_pbase = ptotal ? atomicAdd(&hdr->n_pslots, ptotal) : 0;
+    // both counters with ONE 64-bit atomic (n_units low word, n_pslots high word; the header is 16-byte aligned):
+    // same-address atomics from all blocks serialise at L2, so one is half the queue of two
+    unsigned long long old = 0;
+    if (total)
+      old = atomicAdd(reinterpret_cast<unsigned long long *>(&hdr->n_units),
+                      (unsigned long long)(unsigned)total | ((unsigned long long)(unsigned)ptotal << 32));
+    s_base = (int)(unsigned)(old & 0xffffffffull);
+    s_pbase = (int)(unsigned)(old >> 32);
   }
   __syncthreads();
   if (!mine) return;
@@ -795,7 +801,9 @@ static int launch_all(const SpmmArgs &a) {
   hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
                      a.st, (int)a.M, (int)a.N, L.ch, nbu, a.rowptr, a.col, a.val, a.B, a.C, a.E, hdr, units, part,
                      parte);
-  const dim3 g3((unsigned)(nbu < 256 ? nbu : 256), (unsigned)a.tiles);
+  // combine: one 64-descriptor chunk per wave is plenty of parallelism for its short dependent chains
+  const int64_t cb = (L.max_units + 255) / 256;
+  const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
   hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.C, a.E, hdr, units, part,
                      parte);
   return check_launch();
