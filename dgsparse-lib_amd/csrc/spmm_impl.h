@@ -64,16 +64,17 @@ constexpr int kOpMaskSum = 4;
 #ifndef DGS_CAP
 #define DGS_CAP 512
 #endif
-constexpr int kT1 = DGS_T1;        // rows up to this many nnz are streamed sequentially by one group in K1
-constexpr int kT2 = DGS_T2;      // rows up to this many nnz are reduced by one whole wave inside K1; longer rows are
-                               // cut into units for K2/K3 (few rows, so their table atomics do not serialise K1)
-constexpr int kCap = DGS_CAP;      // (col,val) pairs per wave LDS tile in K1  (4 KiB per wave, 16 KiB per block)
+constexpr int kT1 = DGS_T1;   // rows up to this many nnz are streamed sequentially by one group (row blocks)
+constexpr int kT2 = DGS_T2;   // rows in (T1, T2] would be reduced in place by the wave that owns their row block; the
+                              // measured optimum is T2 == T1 (every row > T1 becomes units: better balance), so that
+                              // in-place path is live only in spmm_small, where it handles ALL long rows
+constexpr int kCap = DGS_CAP; // (col,val) pairs per wave LDS tile of the row blocks (4 KiB per wave, 16 KiB per block)
 constexpr int kRowsPerWave = 64;
 #ifndef DGS_KU1
 #define DGS_KU1 6
 #endif
-constexpr int kU1 = DGS_KU1;   // independent B-row gathers in flight per lane, K1 (short rows)
-constexpr int kU = 8;          // same for K2 (units)
+constexpr int kU1 = DGS_KU1;   // rolling window of B-row gathers per lane in the row stream
+constexpr int kU = 8;          // gathers in flight per lane in the wave-cooperative unit loop
 
 struct SpmmWs {       // workspace header (zeroed every call with one 16-byte memset)
   int n_units;        // K0 -> fused/K2: number of unit descriptors
