@@ -40,7 +40,10 @@
 //
 //   spmm_small: inputs up to 2^18 nnz / 2^16 rows take ONE launch (row blocks only, long rows reduced in place).
 #pragma once
+#include <stdlib.h>
+
 #include "dgs_common.h"
+#include "spmm_panel.h"
 
 namespace dgs {
 
@@ -79,7 +82,8 @@ constexpr int kU = 8;          // gathers in flight per lane in the wave-coopera
 struct SpmmWs {       // workspace header (zeroed every call with one 16-byte memset)
   int n_units;        // K0 -> fused/K2: number of unit descriptors
   int n_pslots;       // partial-row slots handed out (multi-unit rows only)
-  int pad[2];
+  int arrivals;       // spmm_panel: panel steps finished, summed over workgroups (soft barrier)
+  int pad;
 };
 
 struct WsLayout {
@@ -196,8 +200,9 @@ __device__ __forceinline__ void reduce_step_pos(float &res, int &eidx, int &epos
 // atomics cost ~12 ns each when they serialise at L2; per-row atomics made this kernel 44 us, per-block ones ~5).
 // Only the position of a row's units in the table depends on the atomics, never a value.
 constexpr int kK0Rows = 16;
-static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, const int *__restrict__ rowptr,
-                                                        SpmmWs *__restrict__ hdr, int4 *__restrict__ units) {
+static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, int tlong,
+                                                               const int *__restrict__ rowptr,
+                                                               SpmmWs *__restrict__ hdr, int4 *__restrict__ units) {
   __shared__ int s_wsum[kBlock / kWave];
   __shared__ int s_base;
   __shared__ int s_psum[kBlock / kWave];
@@ -214,7 +219,7 @@ static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, co
     const int r = i * nthreads + tid;
     if (r < M) {
       const int len = rowptr[r + 1] - rowptr[r];
-      if (len > kT2) {
+      if (len > tlong) {
         const int nch = (len + ch - 1) / ch;
         mine += nch;
         if (nch > 1) pmine += nch;
@@ -758,7 +763,7 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
 
 // ---------------------------------------------------------------------------------------------------------
 struct SpmmArgs {
-  int64_t M, N, nnz;
+  int64_t M, K, N, nnz;
   const int *rowptr, *col;
   const float *val, *B;
   float *C;
@@ -769,8 +774,90 @@ struct SpmmArgs {
   int reduce_op;
 };
 
+static inline int cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+static inline int env_int(const char *k, int dflt) {
+  const char *v = getenv(k);
+  return v ? atoi(v) : dflt;
+}
+
+// Column-panel schedule (spmm_panel.h): dense graphs whose dense operand does not fit the L2s.
+static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
+  PanelPlan P{};
+  const int force = env_int("DGS_PANEL", -1);
+  if (force == 0 || !a.ws || tiles != 1 || G < 8 || a.N % 4 || a.M <= 0) return P;
+  P.nwg = cu_count();
+  const bool arg = (a.reduce_op == DGS_MAX || a.reduce_op == DGS_MIN);
+  int slots = (int)(kPanelAccBytes / (a.N * (arg ? 8 : 4)));
+  if (slots > kPanelRMax) slots = kPanelRMax;
+  if (slots < 8) return P;
+  // Worth it when (a) the dense operand overflows the L2s and (b) an XCD's 32 workgroups touch every panel row
+  // several times per sweep: reuse = (rows resident per XCD) * (nnz per row) / K.  Measured crossover ~6 (N = 128).
+  const double bbytes = (double)a.K * a.N * 4.0;
+  const double reuse = (P.nwg / 8.0) * slots * ((double)a.nnz / (double)a.M) / (double)(a.K > 0 ? a.K : 1);
+  if (force != 1 && !(bbytes >= 32e6 && reuse >= 8.0 && a.M >= 4096)) return P;
+  P.nsb = (int)((a.M + (int64_t)P.nwg * slots - 1) / ((int64_t)P.nwg * slots));
+  P.R = (int)((a.M + (int64_t)P.nwg * P.nsb - 1) / ((int64_t)P.nwg * P.nsb));
+  const int64_t pbytes = (int64_t)env_int("DGS_PANEL_KB", 5120) * 1024;
+  int64_t pc = pbytes / (a.N * 4);
+  if (pc < 64) pc = 64;
+  P.pcols = (int)pc;
+  P.npanels = (int)((a.K + pc - 1) / pc);
+  if (P.npanels < 1) P.npanels = 1;
+  P.lead = env_int("DGS_PANEL_LEAD", 1);
+  P.tlong = env_int("DGS_PANEL_TLONG", 4096);
+  P.lds = (size_t)P.R * a.N * (arg ? 8 : 4);
+  P.use = true;
+  return P;
+}
+
 template <int G, int V, int OP, bool HAS_VAL>
 static int launch_all(const SpmmArgs &a) {
+  if constexpr (V == 4 && G >= 8 && OP != kOpMaskSum) {
+    const PanelPlan P = panel_plan(a, a.tiles, G);
+    if (P.use) {
+      // rows up to tlong nnz: panel sweep; longer rows: the unit path (classify -> unit blocks -> combine)
+      const WsLayout L = ws_layout(a.reduce_op, a.N, a.nnz);
+      char *w = static_cast<char *>(a.ws);
+      SpmmWs *hdr = reinterpret_cast<SpmmWs *>(w);
+      int4 *units = reinterpret_cast<int4 *>(w + L.off_units);
+      float *part = reinterpret_cast<float *>(w + L.off_part);
+      int *parte = reinterpret_cast<int *>(w + L.off_parte);
+      if (hipMemsetAsync(hdr, 0, sizeof(SpmmWs), a.st) != hipSuccess) return DGS_ELAUNCH;
+      const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
+      const int tl = P.tlong > L.ch ? P.tlong : L.ch;  // every long row has >= 2 units => all go through combine
+      hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, tl, a.rowptr, hdr,
+                         units);
+      auto kern = spmm_panel<G, OP, HAS_VAL>;
+      static bool attr_set = false;  // per instantiation: allow the 128 KiB of dynamic LDS
+      if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kPanelAccBytes) != hipSuccess)
+          return DGS_ELAUNCH;
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)P.nwg), dim3(kPanelBlock), P.lds, a.st, (int)a.M,
+                         (int)a.N, P.R, tl, P.pcols, P.npanels, P.nsb, P.lead, a.rowptr, a.col, a.val, a.B, a.C,
+                         a.E, &hdr->arrivals);
+      const int nbu = 1024;
+      hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)nbu, 1), dim3(kBlock), 0, a.st, (int)a.M,
+                         (int)a.N, L.ch, nbu, a.rowptr, a.col, a.val, a.B, a.C, a.E, hdr, units, part, parte);
+      const int64_t cb = (L.max_units + 255) / 256;
+      const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), 1);
+      hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.C, a.E, hdr, units,
+                         part, parte);
+      return check_launch();
+    }
+  }
   if (!a.ws) {
     // fewer rows per wave on small inputs: parallelism (>= ~2k waves) matters more than staging efficiency
     constexpr int NGc = kWave / G;
@@ -790,7 +877,7 @@ static int launch_all(const SpmmArgs &a) {
   int *parte = reinterpret_cast<int *>(w + L.off_parte);
   if (hipMemsetAsync(hdr, 0, sizeof(SpmmWs), a.st) != hipSuccess) return DGS_ELAUNCH;
   const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
-  hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, a.rowptr, hdr, units);
+  hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, kT2, a.rowptr, hdr, units);
   // unit / multi counts live on the device: a bounded number of persistent unit blocks stride over the table
   const int rows_per_block = (kBlock / kWave) * kRowsPerWave;
   const int64_t nbr = (a.M + rows_per_block - 1) / rows_per_block;

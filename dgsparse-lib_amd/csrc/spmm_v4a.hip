@@ -18,6 +18,15 @@ extern "C" size_t dgs_spmm_csr_workspace_bytes(int reduce_op, int64_t M, int64_t
   return ws_layout(reduce_op, N, nnz).total;
 }
 
+extern "C" int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz) {
+  if (M <= 0 || N <= 0 || nnz <= 0 || tiny_problem(M, nnz)) return DGS_SCHED_SMALL;
+  const FeatMap fm = feat_map(N, true);
+  SpmmArgs a{M, K, N, nnz, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, fm.tiles, &a, nullptr, reduce_op};
+  return (fm.V == 4 && reduce_op >= DGS_SUM && reduce_op <= DGS_MEAN && panel_plan(a, fm.tiles, fm.G).use)
+             ? DGS_SCHED_PANEL
+             : DGS_SCHED_ROWS;
+}
+
 extern "C" int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,
                                 const int32_t *col, const float *val, const float *B, float *C, int32_t *E,
                                 int algorithm, void *workspace, size_t workspace_bytes, dgsStream_t stream) {
@@ -36,7 +45,7 @@ extern "C" int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, 
   const bool al = is_aligned16(B) && is_aligned16(C) && (!arg || is_aligned16(E)) &&
                   (need == 0 || is_aligned16(workspace));
   const FeatMap fm = feat_map(N, al);
-  SpmmArgs a{M, N, nnz, rowptr, col, val, B, C, arg ? E : nullptr, fm.tiles, need ? workspace : nullptr, st, reduce_op};
+  SpmmArgs a{M, K, N, nnz, rowptr, col, val, B, C, arg ? E : nullptr, fm.tiles, need ? workspace : nullptr, st, reduce_op};
   return run(fm, a);
 }
 
@@ -56,7 +65,7 @@ extern "C" int dgs_spmm_csr_mask_f32(int64_t Mout, int64_t Min, int64_t N, int64
   if (need > 0 && (!workspace || workspace_bytes < need)) return DGS_EWORKSPACE;
   const bool al = is_aligned16(G) && is_aligned16(E) && is_aligned16(out) && (need == 0 || is_aligned16(workspace));
   const FeatMap fm = feat_map(N, al);
-  SpmmArgs a{Mout, N, nnz, ptr, idx, val, G, out, const_cast<int32_t *>(E), fm.tiles, need ? workspace : nullptr,
+  SpmmArgs a{Mout, Min, N, nnz, ptr, idx, val, G, out, const_cast<int32_t *>(E), fm.tiles, need ? workspace : nullptr,
              static_cast<hipStream_t>(stream), kOpMaskSum};
   return run(fm, a);
 }

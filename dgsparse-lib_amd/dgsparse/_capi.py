@@ -31,6 +31,8 @@ _lib.dgs_strerror.restype = ctypes.c_char_p
 _lib.dgs_strerror.argtypes = [_int]
 _lib.dgs_spmm_csr_workspace_bytes.restype = _sz
 _lib.dgs_spmm_csr_workspace_bytes.argtypes = [_int, _i64, _i64, _i64]
+_lib.dgs_spmm_csr_schedule.restype = _int
+_lib.dgs_spmm_csr_schedule.argtypes = [_int, _i64, _i64, _i64, _i64]
 _lib.dgs_spmm_csr_f32.restype = _int
 _lib.dgs_spmm_csr_f32.argtypes = [_int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _sz, _vp]
 _lib.dgs_spmm_csr_mask_f32.restype = _int
@@ -57,6 +59,7 @@ _lib.dgs_scatter_add_rows_f32.restype = _int
 _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
 EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
+           'dgs_spmm_csr_schedule',
            'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
            'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'dgs_sddmm_coo_f32', 'dgs_gspmm_csr_workspace_bytes', 'dgs_gspmm_csr_f32', 'gespmmCsrSpMM',
            'spmm_cuda', 'spmm_cuda_no_edge_value', 'sddmm_cuda_csr', 'sddmm_cuda_coo', 'gespmmAlgSel',
@@ -163,6 +166,15 @@ def spmm(reduce_op, rowptr, col, values, dense, algorithm=0, want_E=None):
         _check(_lib.dgs_spmm_csr_f32(reduce_op, M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(dense), _p(out),
                                      _p(E), int(algorithm), _p(ws), wsb, _stream(dev)), 'spmm')
     return out, E
+
+
+SCHEDULES = ('small', 'rows', 'panel')
+
+
+def spmm_schedule(reduce_op, M, K, N, nnz) -> str:
+    """Which schedule ``spmm`` runs for these sizes: 'small' (one launch), 'rows' (row-stream + units) or 'panel'
+    (column-panel sweep for dense graphs, csrc/spmm_panel.h).  Needs no GPU."""
+    return SCHEDULES[_lib.dgs_spmm_csr_schedule(int(reduce_op), int(M), int(K), int(N), int(nnz))]
 
 
 def spmm_mask(ptr, idx, values, grad, E, n_out=None):

@@ -63,6 +63,20 @@ int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz
                      dgsStream_t stream);
 
 /*
+ * Which schedule dgs_spmm_csr_f32 runs for these sizes with 16-byte aligned operands (introspection for tests,
+ * benchmarks and bug reports; a pure function of its arguments and of the DGS_PANEL* environment overrides):
+ *   DGS_SCHED_SMALL  one launch (inputs up to 2^18 nnz / 2^16 rows),
+ *   DGS_SCHED_ROWS   classify -> fused row-stream/unit kernel -> combine (the general schedule),
+ *   DGS_SCHED_PANEL  column-panel sweep with LDS-resident accumulators (dense graphs: the dense operand does not
+ *                    fit the L2s and every panel row is reused several times per XCD), long rows on the unit path.
+ * No reference counterpart (the reference has one schedule per `algorithm` id, src/cuda/spmm_cuda.cu:14-253).
+ */
+#define DGS_SCHED_SMALL 0
+#define DGS_SCHED_ROWS 1
+#define DGS_SCHED_PANEL 2
+int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz);
+
+/*
  * Masked SpMM = backward of max/min w.r.t. the dense operand, run on the CSC arrays of A:
  *   out[j,:] = sum_{p in [ptr[j],ptr[j+1])} [E[idx[p],:] == j] * val[p] * G[idx[p],:]
  * Replaces: spmm_cuda_with_mask(), src/cuda/spmm_cuda.cu:255-303 /

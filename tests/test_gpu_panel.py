@@ -1,0 +1,186 @@
+"""Column-panel SpMM schedule (csrc/spmm_panel.h), forced on small inputs with DGS_PANEL=1 and shrunk panels /
+long-row threshold so that every mechanism runs: many panels, several super-blocks, rows that span chunks inside one
+panel, rows handed to the unit path, empty rows, unsorted and duplicate columns, K != M.
+
+Bars: max/min values and E bit-exact against the oracle; sum/mean BIT-EXACT against the oracle's sequential fmaf chain
+for every row the panel kernel owns (its accumulator is one chain in CSR order), 1e-5 parity for rows that went
+through the unit path.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import assert_bitexact, assert_sum_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def capi():
+    from dgsparse import _capi
+    return _capi
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def dense_graph(M, K, deg_lo, deg_hi, seed, sort=True, empty_every=0, hubs=(), dup=False):
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(deg_lo, deg_hi + 1, size=M)
+    if empty_every:
+        deg[::empty_every] = 0
+    for i, d in hubs:
+        deg[i] = d
+    deg = np.minimum(deg, K if not dup else deg)
+    rowptr = np.zeros(M + 1, dtype=np.int32)
+    np.cumsum(deg, out=rowptr[1:])
+    col = np.empty(int(rowptr[-1]), dtype=np.int32)
+    for i in range(M):
+        d = int(deg[i])
+        if d == 0:
+            continue
+        c = rng.integers(0, K, size=d) if dup else rng.choice(K, size=d, replace=False)
+        col[rowptr[i]:rowptr[i + 1]] = np.sort(c) if sort else c
+    return rowptr, col
+
+
+def run(capi, reduce, rp, col, val, X):
+    C, E = capi.spmm(oracle.REDUCE[reduce], dev(rp), dev(col), None if val is None else dev(val), dev(X))
+    torch.cuda.synchronize()
+    return C.cpu().numpy(), None if E is None else E.cpu().numpy()
+
+
+def check(capi, monkeypatch, reduce, rp, col, val, X, tlong, kb=4, lead=1, cross=True):
+    monkeypatch.setenv('DGS_PANEL', '1')
+    monkeypatch.setenv('DGS_PANEL_KB', str(kb))
+    monkeypatch.setenv('DGS_PANEL_LEAD', str(lead))
+    monkeypatch.setenv('DGS_PANEL_TLONG', str(tlong))
+    assert capi.spmm_schedule(oracle.REDUCE[reduce], rp.size - 1, X.shape[0], X.shape[1], col.size) == 'panel'
+    C, E = run(capi, reduce, rp, col, val, X)
+    Co, Eo = oracle.spmm(reduce, rp, col, val, X, fma=True)
+    lens = np.diff(rp)
+    own = lens <= max(tlong, 256)  # rows swept by the panel kernel (the launcher raises tlong to the unit length)
+    if reduce in ('max', 'min'):
+        assert_bitexact(C, Co, f'{reduce} values')
+        assert_bitexact(E, Eo, f'{reduce} E')
+    else:
+        assert_bitexact(C[own], Co[own], f'{reduce}: rows owned by the panel kernel vs the sequential fmaf chain')
+        if (~own).any():
+            mean = reduce == 'mean'
+            C64 = oracle.spmm_sum_f64(rp, col, val, X, mean=mean)
+            S64 = oracle.spmm_sum_f64(rp, col, val, X, mean=mean, absval=True)
+            assert_sum_parity(C, Co, C64, S64, 1e-5, 2e-6, f'{reduce}: unit-path rows', lens=lens)
+    if not cross:
+        return
+    # and the forced path must agree with the default dispatch (row-stream on inputs this small)
+    monkeypatch.setenv('DGS_PANEL', '0')
+    assert capi.spmm_schedule(oracle.REDUCE[reduce], rp.size - 1, X.shape[0], X.shape[1], col.size) == 'rows'
+    C0, E0 = run(capi, reduce, rp, col, val, X)
+    if reduce in ('max', 'min'):
+        assert_bitexact(C, C0, 'panel vs row-stream values')
+        assert_bitexact(E, E0, 'panel vs row-stream E')
+    else:
+        np.testing.assert_allclose(C, C0, rtol=2e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('reduce', ['sum', 'mean', 'max', 'min'])
+@pytest.mark.parametrize('N', [32, 64, 96, 128, 256])
+def test_panel_widths(capi, monkeypatch, reduce, N):
+    M, K = 5000, 3000
+    rp, col = dense_graph(M, K, 20, 120, seed=N, empty_every=97)
+    rng = np.random.default_rng(N + 1)
+    val = (rng.random(col.size, dtype=np.float32) - 0.3).astype(np.float32)
+    X = (rng.random((K, N), dtype=np.float32) - 0.5).astype(np.float32)
+    check(capi, monkeypatch, reduce, rp, col, val, X, tlong=4096, kb=max(4, N // 8))
+
+
+@pytest.mark.parametrize('reduce', ['sum', 'max', 'min'])
+def test_panel_no_values(capi, monkeypatch, reduce):
+    rp, col = dense_graph(6000, 3000, 20, 120, seed=5)
+    X = (np.random.default_rng(6).random((3000, 64), dtype=np.float32) - 0.5).astype(np.float32)
+    check(capi, monkeypatch, reduce, rp, col, None, X, tlong=4096, kb=8)
+
+
+@pytest.mark.parametrize('reduce', ['sum', 'mean', 'max', 'min'])
+def test_panel_long_rows_take_the_unit_path(capi, monkeypatch, reduce):
+    M, K = 4200, 6000
+    rp, col = dense_graph(M, K, 30, 200, seed=11, hubs=[(0, 5000), (17, 2900), (4199, 1500), (2100, 700)])
+    rng = np.random.default_rng(12)
+    val = (rng.random(col.size, dtype=np.float32) + 0.25).astype(np.float32)
+    X = (rng.random((K, 128), dtype=np.float32) - 0.5).astype(np.float32)
+    check(capi, monkeypatch, reduce, rp, col, val, X, tlong=512, kb=64)
+
+
+@pytest.mark.parametrize('reduce', ['sum', 'max', 'min'])
+def test_panel_rows_longer_than_a_chunk_inside_one_panel(capi, monkeypatch, reduce):
+    # one panel only (K small), rows of several hundred nnz: the in-visit reload loop runs many times
+    M, K = 2048, 900
+    rp, col = dense_graph(M, K, 100, 800, seed=21)
+    rng = np.random.default_rng(22)
+    val = (rng.random(col.size, dtype=np.float32) - 0.5).astype(np.float32)
+    X = (rng.random((K, 64), dtype=np.float32) - 0.5).astype(np.float32)
+    check(capi, monkeypatch, reduce, rp, col, val, X, tlong=4096, kb=4096)
+
+
+@pytest.mark.parametrize('reduce', ['sum', 'mean', 'max', 'min'])
+def test_panel_unsorted_and_duplicate_columns(capi, monkeypatch, reduce):
+    # the cursor consumes a prefix whatever the column order is: unsorted rows only cost cache hits
+    M, K = 4500, 2000
+    rp, col = dense_graph(M, K, 5, 150, seed=31, sort=False, dup=True, empty_every=50)
+    rng = np.random.default_rng(32)
+    val = (rng.random(col.size, dtype=np.float32) - 0.5).astype(np.float32)
+    X = (rng.integers(-3, 4, size=(K, 32))).astype(np.float32)  # many exact ties for max/min
+    check(capi, monkeypatch, reduce, rp, col, val, X, tlong=4096, kb=4)
+
+
+@pytest.mark.parametrize('lead', [1, 2, 50])
+def test_panel_many_superblocks_and_lead(capi, monkeypatch, lead):
+    # N = 256 -> 128 rows per workgroup: 100k rows = several super-blocks on 256 CUs
+    M, K = 100_000, 1500
+    rp, col = dense_graph(M, K, 0, 24, seed=41, dup=True)
+    rng = np.random.default_rng(42)
+    val = rng.random(col.size, dtype=np.float32)
+    X = rng.random((K, 256), dtype=np.float32)
+    check(capi, monkeypatch, 'sum', rp, col, val, X, tlong=4096, kb=256, lead=lead)
+    check(capi, monkeypatch, 'max', rp, col, val, X, tlong=4096, kb=256, lead=lead)
+
+
+def test_panel_signed_zero_and_nan_rows(capi, monkeypatch):
+    M, K, N = 6000, 700, 32
+    rp, col = dense_graph(M, K, 1, 120, seed=51)
+    rng = np.random.default_rng(52)
+    val = rng.choice(np.array([1.0, -1.0, 0.0, -0.0], dtype=np.float32), size=col.size)
+    X = rng.choice(np.array([0.0, -0.0, 1.0, -2.0], dtype=np.float32), size=(K, N))
+    X[5, :] = np.nan
+    for reduce in ('max', 'min'):
+        # cross-check against the row-stream schedule only for max: min with NaN inputs is order-dependent
+        # (the MIN macro lets the element after a NaN replace the running value), which a split row cannot honour
+        check(capi, monkeypatch, reduce, rp, col, val, X, tlong=4096, kb=4, cross=(reduce == 'max'))
+
+
+def test_panel_default_dispatch_reddit_like(capi, monkeypatch):
+    """Without any override a dense input big enough for the heuristic takes the panel path and matches the oracle."""
+    for k in ('DGS_PANEL', 'DGS_PANEL_KB', 'DGS_PANEL_LEAD', 'DGS_PANEL_TLONG'):
+        monkeypatch.delenv(k, raising=False)
+    M = K = 70_000
+    N = 128
+    assert capi.spmm_schedule(oracle.REDUCE['sum'], M, K, N, 285 * M) == 'panel'
+    assert capi.spmm_schedule(oracle.REDUCE['sum'], M, K, N, 16 * M) == 'rows'  # sparse graph: no panel reuse
+    rp, col = dense_graph(M, K, 150, 420, seed=61, hubs=[(3, 20_000), (69_999, 9000)], dup=True)
+    rng = np.random.default_rng(62)
+    val = rng.random(col.size, dtype=np.float32)
+    X = rng.random((K, N), dtype=np.float32)
+    C, _ = run(capi, 'sum', rp, col, val, X)
+    Co, _ = oracle.spmm('sum', rp, col, val, X, fma=True)
+    lens = np.diff(rp)
+    own = lens <= 4096
+    assert_bitexact(C[own], Co[own], 'panel rows vs sequential chain (default dispatch)')
+    C64 = oracle.spmm_sum_f64(rp, col, val, X)
+    S64 = oracle.spmm_sum_f64(rp, col, val, X, absval=True)
+    assert_sum_parity(C, Co, C64, S64, 1e-5, 2e-6, 'default dispatch', lens=lens)
+    Cm, Em = run(capi, 'max', rp, col, val, X)
+    Cmo, Emo = oracle.spmm('max', rp, col, val, X, fma=True)
+    assert_bitexact(Cm, Cmo, 'max values')
+    assert_bitexact(Em, Emo, 'max E')
