@@ -1,12 +1,14 @@
 #!/bin/bash
 # PMC passes for the headline bench (separate passes: TCC has 4 slots, FETCH_SIZE=3, WRITE_SIZE=2; never mixed
 # with --kernel-trace/--stats).  Usage on the GPU box: bash bench/prof_pmc.sh OUTDIR [bench.py args...]
+# PMC_CMD="python bench/panel_probe.py" bash bench/prof_pmc.sh OUTDIR   profiles another command instead of bench.py
 set -u
 OUT=$1; shift
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$OUT"
-cd /tmp && export TMPDIR=/tmp
-run() { tag=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$tag" -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline $ARGS > "$OUT/$tag.log" 2>&1; }
+export TMPDIR=/tmp
+CMD=${PMC_CMD:-"python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline"}
+run() { tag=$1; shift; (cd "$REPO" && rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$tag" -- $CMD $ARGS > "$OUT/$tag.log" 2>&1); }
 ARGS="$*"
 run fetch FETCH_SIZE
 run write WRITE_SIZE
