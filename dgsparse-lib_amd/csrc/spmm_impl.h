@@ -193,6 +193,44 @@ __device__ __forceinline__ void reduce_step_pos(float &res, int &eidx, int &epos
   }
 }
 
+// MIN with NaN products is ORDER-DEPENDENT: `(acc < t) ? acc : t` turns acc into NaN at a NaN product and lets the
+// NEXT product replace it unconditionally, so no split of the row can be recombined.  The split paths therefore only
+// DETECT the case -- nf[v] = fma(t, 0, nf[v]) goes NaN as soon as one product was NaN (or inf: a false alarm that
+// merely takes the slow path) -- and the affected (row, feature) elements are redone as one sequential chain.
+constexpr int kNanMark = -2;  // partial-row arg id of an element that met a NaN product (never leaves the workspace)
+
+template <int G, int V>
+__device__ __forceinline__ unsigned nan_flags(const float (&nf)[V]) {
+  unsigned m = 0;
+#pragma unroll
+  for (int v = 0; v < V; v++) m |= (nf[v] != nf[v]) ? (1u << v) : 0u;
+#pragma unroll
+  for (int d = G; d < 64; d <<= 1) m |= (unsigned)__shfl_xor((int)m, d, 64);
+  return m;
+}
+
+// Sequential algorithm-0 chain of row [rs,re) for the elements of this lane selected by `mask` (MIN fix-up, rare).
+template <int V, int OP>
+__device__ __forceinline__ void seq_redo(unsigned mask, int rs, int re, int N, int f0, const int *__restrict__ col,
+                                         const float *__restrict__ val, const float *__restrict__ B, float (&acc)[V],
+                                         int (&ei)[V]) {
+#pragma unroll
+  for (int v = 0; v < V; v++)
+    if (mask >> v & 1) {
+      acc[v] = reduce_init<OP>();
+      ei[v] = -1;
+    }
+  for (int p = rs; p < re; p++) {
+    const int c = col[p];
+    const float w = val ? val[p] : 1.0f;
+    float x[V];
+    load_vec<V>(B + (int64_t)c * N + f0, x);
+#pragma unroll
+    for (int v = 0; v < V; v++)
+      if (mask >> v & 1) reduce_step<OP>(acc[v], ei[v], w, x[v], c);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K0: scan rowptr once and cut every long row (len > T2) into units of <= ch nnz: unit = {row, k, first partial slot of
 // the row, units in the row}.  Each thread looks at kK0Rows rows, a block-level exclusive scan turns the per-thread
@@ -288,7 +326,7 @@ __device__ __forceinline__ void coop_accumulate(int p0, int p1, int lane, int g,
                                                 const int *__restrict__ col, const float *__restrict__ val,
                                                 const float *__restrict__ B, const int *__restrict__ Em, int orow,
                                                 int2 *tile, float (&acc)[V], int (&ei)[V], int (&ep)[V],
-                                                int (&el)[V]) {
+                                                int (&el)[V], float (&nf)[V]) {
   constexpr int NG = kWave / G;
   for (int t0 = p0; t0 < p1; t0 += kWave) {
     const int cnt = min(kWave, p1 - t0);
@@ -327,6 +365,7 @@ __device__ __forceinline__ void coop_accumulate(int p0, int p1, int lane, int g,
               if (m[q][v] == orow) acc[v] = __builtin_fmaf(w[q], x[q][v], acc[v]);
             } else {
               reduce_step_pos<OP>(acc[v], ei[v], ep[v], el[v], w[q], x[q][v], c[q], t0 + j + q * NG);
+              if constexpr (OP == DGS_MIN) nf[v] = __builtin_fmaf(w[q] * x[q][v], 0.0f, nf[v]);
             }
           }
         }
@@ -540,8 +579,13 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
       ep[v] = INT_MAX;
       el[v] = -1;
     }
-    coop_accumulate<G, V, OP, HAS_VAL>(rs, re, lane, g, f0, fl, N, col, val, B, E, r0 + r, tile, acc, ei, ep, el);
+    float nf[V] = {};
+    coop_accumulate<G, V, OP, HAS_VAL>(rs, re, lane, g, f0, fl, N, col, val, B, E, r0 + r, tile, acc, ei, ep, el, nf);
     cross_group_reduce<G, V, OP>(acc, ei, ep, el);
+    if constexpr (OP == DGS_MIN) {
+      const unsigned nm = nan_flags<G, V>(nf);
+      if (nm && g == 0 && fl) seq_redo<V, OP>(nm, rs, re, N, f0, col, HAS_VAL ? val : nullptr, B, acc, ei);
+    }
     if (g == 0 && fl) {
       if constexpr (OP == DGS_MEAN) {
         const float dg = (float)(re - rs);
@@ -601,8 +645,21 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
       ep[v] = INT_MAX;
       el[v] = -1;
     }
-    coop_accumulate<G, V, OP, HAS_VAL>(p0, p1, lane, g, f0, fl, N, col, val, B, E, d.x, tile, acc, ei, ep, el);
+    float nf[V] = {};
+    coop_accumulate<G, V, OP, HAS_VAL>(p0, p1, lane, g, f0, fl, N, col, val, B, E, d.x, tile, acc, ei, ep, el, nf);
     cross_group_reduce<G, V, OP>(acc, ei, ep, el);
+    if constexpr (OP == DGS_MIN) {
+      const unsigned nm = nan_flags<G, V>(nf);
+      if (nm && g == 0 && fl) {
+        if (d.w == 1) {
+          seq_redo<V, OP>(nm, rs, re, N, f0, col, HAS_VAL ? val : nullptr, B, acc, ei);
+        } else {  // tell the combine kernel to redo these elements of the row
+#pragma unroll
+          for (int v = 0; v < V; v++)
+            if (nm >> v & 1) ei[v] = kNanMark;
+        }
+      }
+    }
     if (g == 0 && fl) {
       if (d.w == 1) {  // the whole row was this unit: final result
         if constexpr (OP == DGS_MEAN) {
@@ -669,7 +726,9 @@ __global__ __launch_bounds__(kBlock) void spmm_small(int M, int N, int rpw, cons
 // then the fixed cross-group tree).
 template <int G, int V, int OP>
 __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restrict__ rowptr,
-                                                       float *__restrict__ C, int *__restrict__ E,
+                                                       const int *__restrict__ col, const float *__restrict__ val,
+                                                       const float *__restrict__ B, float *__restrict__ C,
+                                                       int *__restrict__ E,
                                                        const SpmmWs *__restrict__ hdr, const int4 *__restrict__ units,
                                                        const float *__restrict__ part,
                                                        const int *__restrict__ parte) {
@@ -696,6 +755,7 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
     d.w = __shfl(dl.w, src, 64);
     float acc[V];
     int ei[V], ep[V], el[V];
+    unsigned nm = 0;  // MIN: elements whose partials met a NaN product
 #pragma unroll
     for (int v = 0; v < V; v++) {
       acc[v] = reduce_init<OP>();
@@ -722,7 +782,9 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
             if constexpr (OP == DGS_MIN) {
               // units arrive in increasing k inside a group: a strictly smaller partial takes everything, an equal
               // one only refreshes the value (later operand wins ties in the MIN macro); E=-1 partials never improved
-              if (xe[q][v] != -1) {
+              if (xe[q][v] == kNanMark) {
+                nm |= 1u << v;
+              } else if (xe[q][v] != -1) {
                 if (acc[v] > x[q][v]) {
                   acc[v] = x[q][v];
                   ei[v] = xe[q][v];
@@ -748,6 +810,11 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
       }
     }
     cross_group_reduce<G, V, OP>(acc, ei, ep, el);
+    if constexpr (OP == DGS_MIN) {
+#pragma unroll
+      for (int dd = G; dd < 64; dd <<= 1) nm |= (unsigned)__shfl_xor((int)nm, dd, 64);
+      if (nm && g == 0 && fl) seq_redo<V, OP>(nm, rowptr[d.x], rowptr[d.x + 1], N, f0, col, val, B, acc, ei);
+    }
     if (g == 0 && fl) {
       if constexpr (OP == DGS_MEAN) {
         const float dg = (float)(rowptr[d.x + 1] - rowptr[d.x]);
@@ -853,8 +920,8 @@ static int launch_all(const SpmmArgs &a) {
                          (int)a.N, L.ch, nbu, a.rowptr, a.col, a.val, a.B, a.C, a.E, hdr, units, part, parte);
       const int64_t cb = (L.max_units + 255) / 256;
       const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), 1);
-      hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.C, a.E, hdr, units,
-                         part, parte);
+      hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B,
+                         a.C, a.E, hdr, units, part, parte);
       return check_launch();
     }
   }
@@ -892,8 +959,8 @@ static int launch_all(const SpmmArgs &a) {
   // combine: one 64-descriptor chunk per wave is plenty of parallelism for its short dependent chains
   const int64_t cb = (L.max_units + 255) / 256;
   const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
-  hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.C, a.E, hdr, units, part,
-                     parte);
+  hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B, a.C,
+                     a.E, hdr, units, part, parte);
   return check_launch();
 }
 

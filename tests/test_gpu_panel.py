@@ -155,9 +155,7 @@ def test_panel_signed_zero_and_nan_rows(capi, monkeypatch):
     X = rng.choice(np.array([0.0, -0.0, 1.0, -2.0], dtype=np.float32), size=(K, N))
     X[5, :] = np.nan
     for reduce in ('max', 'min'):
-        # cross-check against the row-stream schedule only for max: min with NaN inputs is order-dependent
-        # (the MIN macro lets the element after a NaN replace the running value), which a split row cannot honour
-        check(capi, monkeypatch, reduce, rp, col, val, X, tlong=4096, kb=4, cross=(reduce == 'max'))
+        check(capi, monkeypatch, reduce, rp, col, val, X, tlong=4096, kb=4)
 
 
 def test_panel_default_dispatch_reddit_like(capi, monkeypatch):

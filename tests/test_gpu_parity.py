@@ -447,3 +447,33 @@ def test_signed_zero_ties_on_split_rows(capi, N):
         Co, Eo = oracle.spmm(reduce, rp, col, val, X)
         assert_bitexact(C, Co, reduce + ' values (signed zeros)')
         assert_bitexact(E, Eo, reduce + ' E')
+
+
+@pytest.mark.parametrize('N', [16, 64, 256])
+@pytest.mark.parametrize('big', [False, True])
+def test_min_max_nan_products_on_split_rows(capi, N, big):
+    """MIN over NaN products is order-dependent in algorithm 0: `(acc < t) ? acc : t` turns acc into NaN at a NaN product
+    and lets the NEXT product replace it, whatever its size, while E keeps the id of the last strict improvement.  Rows
+    that are split across groups / units / partial rows must still return the sequential answer (they detect the NaN
+    and redo the affected elements as one chain); MAX ignores NaN products.  inf * 0 is a NaN product as well."""
+    lens = [5, 70, 200, 300, 1000, 5000, 64, 65, 256, 257] * (40 if big else 4)  # big: the general 3-kernel schedule
+    K = 50
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    rng = np.random.default_rng(N + big)
+    col = rng.integers(0, K, int(rp[-1])).astype(np.int32)
+    val = rng.choice(np.array([1.0, -1.0, 0.5, 2.0, 0.0], np.float32), int(rp[-1]))
+    X = rng.integers(-4, 5, size=(K, N)).astype(np.float32)
+    X[7, : N // 2] = np.nan          # NaN in half of the features only: the other half must stay on the fast path
+    X[11, 1::3] = np.inf             # inf * 0 -> NaN, inf * (+-w) -> +-inf
+    X[13, ::5] = -np.inf
+    for reduce in ('min', 'max'):
+        C, E = run_spmm(capi, reduce, rp, col, val, X)
+        Co, Eo = oracle.spmm(reduce, rp, col, val, X)
+        assert_bitexact(C, Co, reduce + ' values (NaN products)')
+        assert_bitexact(E, Eo, reduce + ' E (NaN products)')
+    # and without values (weight 1): only the NaN row itself produces NaN products
+    C, E = run_spmm(capi, 'min', rp, col, None, X)
+    Co, Eo = oracle.spmm('min', rp, col, None, X)
+    assert_bitexact(C, Co, 'min values (NaN, no edge values)')
+    assert_bitexact(E, Eo, 'min E (NaN, no edge values)')
+
