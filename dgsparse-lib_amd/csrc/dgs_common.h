@@ -8,6 +8,12 @@
 
 namespace dgs {
 
+// Internal fifth reduce op: masked sum = backward of max/min w.r.t. the dense operand, run on the CSC arrays:
+//   out[j,f] = sum_p [Em[idx[p],f] == j] * val[p] * G[idx[p],f]
+// (reference csrspmm_seqreduce_rowbalance_with_mask_kernel, include/cuda/spmm_cuda.cuh:400-433; the formula, not that
+// kernel's stale-variable behaviour).  Same schedule as the forward; the E pointer carries the saved arg ids (input).
+constexpr int kOpMaskSum = 4;
+
 constexpr int kWave = 64;    // CDNA wavefront
 constexpr int kBlock = 256;  // 4 waves per workgroup, one per SIMD
 

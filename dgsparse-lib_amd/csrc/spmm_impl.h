@@ -47,11 +47,6 @@
 
 namespace dgs {
 
-// Internal fifth reduce op: masked sum = backward of max/min w.r.t. the dense operand, run on the CSC arrays:
-//   out[j,f] = sum_p [Em[idx[p],f] == j] * val[p] * G[idx[p],f]
-// (reference csrspmm_seqreduce_rowbalance_with_mask_kernel, include/cuda/spmm_cuda.cuh:400-433; the formula, not that
-// kernel's stale-variable behaviour).  Same schedule as the forward; the E pointer carries the saved arg ids (input).
-constexpr int kOpMaskSum = 4;
 
 // ---------------------------------------------------------------------------------------------------------
 // tuning constants
@@ -875,7 +870,7 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
   P.nsb = (int)((a.M + (int64_t)P.nwg * slots - 1) / ((int64_t)P.nwg * slots));
   P.R = (int)((a.M + (int64_t)P.nwg * P.nsb - 1) / ((int64_t)P.nwg * P.nsb));
   const int64_t pbytes = (int64_t)env_int("DGS_PANEL_KB", 5120) * 1024;
-  int64_t pc = pbytes / (a.N * 4);
+  int64_t pc = pbytes / (a.N * (a.reduce_op == kOpMaskSum ? 8 : 4));  // masked sum gathers grad AND arg-id rows
   if (pc < 64) pc = 64;
   P.pcols = (int)pc;
   P.npanels = (int)((a.K + pc - 1) / pc);
@@ -889,7 +884,7 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
 
 template <int G, int V, int OP, bool HAS_VAL>
 static int launch_all(const SpmmArgs &a) {
-  if constexpr (V == 4 && G >= 8 && OP != kOpMaskSum) {
+  if constexpr (V == 4 && G >= 8) {
     const PanelPlan P = panel_plan(a, a.tiles, G);
     if (P.use) {
       // rows up to tlong nnz: panel sweep; longer rows: the unit path (classify -> unit blocks -> combine)

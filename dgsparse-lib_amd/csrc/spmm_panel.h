@@ -52,13 +52,14 @@ struct PanelLds {  // the small arrays; the accumulators follow in dynamic LDS
   int *deg, *order, *cur, *rend, *nextc;
 };
 
-// One visit: fold the in-panel prefix of the chunk (c,w) loaded at cur[r] into acc[r].  Groups without a row pass
+// One visit: fold the in-panel prefix of the chunk (c,w) loaded at cur[r] into acc[r].  Masked sum (kOpMaskSum: Em =
+// saved arg ids, orow = this output row) gathers the arg-id row next to the grad row and gates the fma.  Groups without a row pass
 // r = -1 and c = INT_MAX everywhere (cnt = 0).  All 64 lanes must call it together.
 template <int G, int OP, bool HAS_VAL>
 __device__ __forceinline__ void panel_visit(int r, int c, float w, int pend, int N, int lig, int gbase, int f0,
                                             bool active, uint64_t gmask, const PanelLds &L, float *acc, int *acce,
                                             const int *__restrict__ col, const float *__restrict__ val,
-                                            const float *__restrict__ B) {
+                                            const float *__restrict__ B, const int *__restrict__ Em, int orow) {
   constexpr int V = 4;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
   const bool have = r >= 0;
@@ -85,6 +86,7 @@ __device__ __forceinline__ void panel_visit(int r, int c, float w, int pend, int
       float x[kPU][V];
       float wj[kPU];
       int cj[kPU];
+      int mk[kPU][V];
 #pragma unroll
       for (int u = 0; u < kPU; u++) {
         const int src = gbase + ((j + u) & (G - 1));
@@ -93,6 +95,7 @@ __device__ __forceinline__ void panel_visit(int r, int c, float w, int pend, int
         else wj[u] = 1.f;
         if (j + u < cnt && active) {
           load_vec<V>(B + (int64_t)cj[u] * N + f0, x[u]);
+          if constexpr (OP == kOpMaskSum) load_vec<V>(Em + (int64_t)cj[u] * N + f0, mk[u]);
         } else if constexpr (!ARG) {  // sum: a padded step is fma(0, 0, a) = a
           wj[u] = 0.f;
 #pragma unroll
@@ -105,6 +108,12 @@ __device__ __forceinline__ void panel_visit(int r, int c, float w, int pend, int
           if (j + u < cnt && active) {
 #pragma unroll
             for (int v = 0; v < V; v++) reduce_step<OP>(a[v], ae[v], wj[u], x[u][v], cj[u]);
+          }
+        } else if constexpr (OP == kOpMaskSum) {
+          if (j + u < cnt && active) {
+#pragma unroll
+            for (int v = 0; v < V; v++)
+              if (mk[u][v] == orow) a[v] = __builtin_fmaf(wj[u], x[u][v], a[v]);
           }
         } else {
 #pragma unroll
@@ -238,10 +247,12 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int R, i
       grab(r0, c0, w0);
       for (;;) {
         grab(r1, c1, w1);
-        panel_visit<G, OP, HAS_VAL>(r0, c0, w0, pend, N, lig, gbase, f0, active, gmask, L, acc, acce, col, val, B);
+        panel_visit<G, OP, HAS_VAL>(r0, c0, w0, pend, N, lig, gbase, f0, active, gmask, L, acc, acce, col, val, B, E,
+                                    (int)row0 + r0);
         if (!__any(r1 >= 0)) break;
         grab(r0, c0, w0);
-        panel_visit<G, OP, HAS_VAL>(r1, c1, w1, pend, N, lig, gbase, f0, active, gmask, L, acc, acce, col, val, B);
+        panel_visit<G, OP, HAS_VAL>(r1, c1, w1, pend, N, lig, gbase, f0, active, gmask, L, acc, acce, col, val, B, E,
+                                    (int)row0 + r1);
         if (!__any(r0 >= 0)) break;
       }
       __syncthreads();

@@ -182,3 +182,35 @@ def test_panel_default_dispatch_reddit_like(capi, monkeypatch):
     Cmo, Emo = oracle.spmm('max', rp, col, val, X, fma=True)
     assert_bitexact(Cm, Cmo, 'max values')
     assert_bitexact(Em, Emo, 'max E')
+
+
+@pytest.mark.parametrize('N', [32, 128])
+def test_panel_masked_sum_for_max_min_backward(capi, monkeypatch, N):
+    """max/min backward w.r.t. the dense operand = masked SpMM over the CSC arrays (dgs_spmm_csr_mask_f32): on the
+    panel schedule it gathers the saved arg-id row next to the grad row.  Bit-exact against the oracle's sequential
+    fmaf chain for the rows the panel kernel owns; hub columns (> tlong entries) go through the unit path."""
+    M, K = 6000, 2500
+    rp, col = dense_graph(M, K, 30, 110, seed=70 + N)
+    rng = np.random.default_rng(71 + N)
+    val = (rng.random(col.size, dtype=np.float32) - 0.4).astype(np.float32)
+    X = (rng.integers(-3, 4, size=(K, N))).astype(np.float32)  # ties: E must pick the first occurrence
+    G = (rng.random((M, N), dtype=np.float32) - 0.5).astype(np.float32)
+    colptr, row, tval, _ = oracle.csr2csc(rp, col, val, K)
+    _, E = oracle.spmm('max', rp, col, val, X)
+    ref = oracle.spmm_mask(colptr, row, tval, G, E, fma=True)
+    lens = np.diff(colptr)
+    for tlong in (4096, 200):
+        monkeypatch.setenv('DGS_PANEL', '1')
+        monkeypatch.setenv('DGS_PANEL_KB', '16')
+        monkeypatch.setenv('DGS_PANEL_TLONG', str(tlong))
+        gX = capi.spmm_mask(dev(colptr), dev(row), dev(tval), dev(G), dev(E)).cpu().numpy()
+        own = lens <= max(tlong, 256)
+        assert own.any()
+        assert_bitexact(gX[own], ref[own], 'masked sum: panel-owned rows vs the sequential chain')
+        assert_sum_parity(gX, ref, oracle.spmm_mask_f64(colptr, row, tval, G, E),
+                          oracle.spmm_mask_f64(colptr, row, tval, G, E, absval=True), 1e-5, 2e-6, 'masked sum',
+                          lens=lens)
+        monkeypatch.setenv('DGS_PANEL', '0')
+        g0 = capi.spmm_mask(dev(colptr), dev(row), dev(tval), dev(G), dev(E)).cpu().numpy()
+        np.testing.assert_allclose(gX, g0, rtol=2e-5, atol=1e-5)
+
