@@ -42,7 +42,7 @@ def main():
     ap.add_argument('--kb', type=int, nargs='*', default=[1536])
     ap.add_argument('--lead', type=int, nargs='*', default=[1])
     a = ap.parse_args()
-    op = {'sum': _capi.SUM, 'mean': _capi.MEAN, 'max': _capi.MAX, 'min': _capi.MIN}[a.op]
+    op = {'sum': _capi.SUM, 'mean': _capi.MEAN, 'max': _capi.MAX, 'min': _capi.MIN, 'sddmm': -1}[a.op]
     if a.dmax or a.ncols or a.deg:
         sh = graphgen.SHAPES[a.graph]
         rowptr, col, st = graphgen.powerlaw_csr(int(sh['M'] * a.scale),
@@ -57,18 +57,26 @@ def main():
     B = torch.rand((st['K'], a.feat), device='cuda', generator=g)
     val = torch.rand(nnz, device='cuda', generator=g) + 0.5
     print(f'{a.graph}: M={M} nnz={nnz} max_deg={st["max_deg"]} feat={a.feat} op={a.op}', flush=True)
+    if a.op == 'sddmm':
+        D1 = torch.rand((M, a.feat), device='cuda', generator=g)
+
+        def call():
+            return _capi.sddmm(rowptr, col, D1, B), None
+    else:
+        def call():
+            return _capi.spmm(op, rowptr, col, val, B)
     os.environ['DGS_PANEL'] = '0'
-    ref, _ = _capi.spmm(op, rowptr, col, val, B)
-    t0 = timeit(lambda: _capi.spmm(op, rowptr, col, val, B))
+    ref, _ = call()
+    t0 = timeit(lambda: call())
     print(f'row-stream schedule : {t0:8.3f} ms  {2e-6 * nnz * a.feat / t0:8.1f} GFLOP/s', flush=True)
     os.environ['DGS_PANEL'] = '1'
     for kb in a.kb:
         for lead in a.lead:
             os.environ['DGS_PANEL_KB'] = str(kb)
             os.environ['DGS_PANEL_LEAD'] = str(lead)
-            out, _ = _capi.spmm(op, rowptr, col, val, B)
+            out, _ = call()
             err = ((out - ref).abs() / (ref.abs() + 1e-3)).max().item()
-            t = timeit(lambda: _capi.spmm(op, rowptr, col, val, B))
+            t = timeit(lambda: call())
             print(f'panel kb={kb:5d} lead={lead}: {t:8.3f} ms  {2e-6 * nnz * a.feat / t:8.1f} GFLOP/s  '
                   f'max rel diff vs row-stream {err:.2e}', flush=True)
 

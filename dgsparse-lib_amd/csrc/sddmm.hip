@@ -13,7 +13,10 @@
 //     the D1 row slice and the D2 row slice with coalesced dwordx4 loads (the D1 slice is an L1/L2 hit while the
 //     row lasts), U nnz in flight per group, xor-butterfly per dot product;
 //   * the 64 results go through LDS and leave with one coalesced store.
+#include <stdlib.h>
+
 #include "dgs_common.h"
+#include "sddmm_panel.h"
 
 namespace dgs {
 
@@ -37,16 +40,72 @@ __device__ __forceinline__ int wave_incl_scan(int x, int lane) {
   return x;
 }
 
+// Dot products of one staged tile: tile[j] = {col, row} of nnz t0 + j (j < cntn); group g takes nnz g, g+NG, ...,
+// kSdU of them in flight; the results go through `cnt` (LDS) and leave with one coalesced store.
+template <int G, int V, bool MEAN, bool MASK>
+__device__ __forceinline__ void sd_tile_dots(const int2 *tile, int *cnt, int cntn, int t0, int lane, int F, int tiles,
+                                             const int *__restrict__ rowptr, const float *__restrict__ D1,
+                                             const float *__restrict__ D2, const int *__restrict__ E,
+                                             float *__restrict__ out) {
+  constexpr int NG = kWave / G;
+  const int g = lane / G, l = lane % G;
+  // ---- dot products: group g takes nnz g, g+NG, ...; kSdU of them in flight
+  for (int j0 = g; j0 < cntn; j0 += NG * kSdU) {
+    float part[kSdU];
+    int2 cr[kSdU];
+#pragma unroll
+    for (int q = 0; q < kSdU; q++) {
+      part[q] = 0.0f;
+      cr[q] = tile[min(j0 + q * NG, cntn - 1)];
+    }
+    for (int t = 0; t < tiles; t++) {
+      const int f = (t * G + l) * V;
+      if (f < F) {
+        float a[kSdU][V], b[kSdU][V];
+        int m[kSdU][V];
+#pragma unroll
+        for (int q = 0; q < kSdU; q++) {
+          load_vec<V>(D1 + (int64_t)cr[q].y * F + f, a[q]);
+          load_vec<V>(D2 + (int64_t)cr[q].x * F + f, b[q]);
+          if constexpr (MASK) load_vec<V>(E + (int64_t)cr[q].y * F + f, m[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < kSdU; q++)
+#pragma unroll
+          for (int v = 0; v < V; v++) {
+            if constexpr (MASK) {
+              if (m[q][v] == cr[q].x) part[q] = __builtin_fmaf(a[q][v], b[q][v], part[q]);
+            } else {
+              part[q] = __builtin_fmaf(a[q][v], b[q][v], part[q]);
+            }
+          }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kSdU; q++) {
+      float tot = group_allreduce<G>(part[q]);
+      const int j = j0 + q * NG;
+      if (j < cntn && l == 0) {
+        if constexpr (MEAN) {  // sddmm_cuda.cuh:266-272: divide by deg(row(e)) (always > 0 for a stored entry)
+          const int rw = cr[q].y;
+          tot /= (float)(rowptr[rw + 1] - rowptr[rw]);
+        }
+        cnt[j] = __float_as_int(tot);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < cntn) out[t0 + lane] = __int_as_float(cnt[lane]);
+}
+
 template <int G, int V, bool MEAN, bool MASK>
 __global__ __launch_bounds__(kBlock) void sddmm_nnzbal(int M, int F, int tiles, int nnz,
                                                        const int *__restrict__ rowptr, const int *__restrict__ col,
                                                        const float *__restrict__ D1, const float *__restrict__ D2,
                                                        const int *__restrict__ E, float *__restrict__ out) {
-  constexpr int NG = kWave / G;
   __shared__ int2 s_tile[kBlock / kWave][kWave];  // {col, row}
   __shared__ int s_cnt[kBlock / kWave][kWave];    // boundary histogram, then the 64 results (as float bits)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int g = lane / G, l = lane % G;
   int2 *tile = s_tile[wave];
   int *cnt = s_cnt[wave];
   const int nchunks = (nnz + kSdChunk - 1) / kSdChunk;
@@ -101,53 +160,40 @@ __global__ __launch_bounds__(kBlock) void sddmm_nnzbal(int M, int F, int tiles, 
       __builtin_amdgcn_wave_barrier();
       r = __shfl(myrow, cntn - 1, kWave);  // row of the tile's last nnz: where the next tile starts
 
-      // ---- dot products: group g takes nnz g, g+NG, ...; kSdU of them in flight
-      for (int j0 = g; j0 < cntn; j0 += NG * kSdU) {
-        float part[kSdU];
-        int2 cr[kSdU];
-#pragma unroll
-        for (int q = 0; q < kSdU; q++) {
-          part[q] = 0.0f;
-          cr[q] = tile[min(j0 + q * NG, cntn - 1)];
-        }
-        for (int t = 0; t < tiles; t++) {
-          const int f = (t * G + l) * V;
-          if (f < F) {
-            float a[kSdU][V], b[kSdU][V];
-            int m[kSdU][V];
-#pragma unroll
-            for (int q = 0; q < kSdU; q++) {
-              load_vec<V>(D1 + (int64_t)cr[q].y * F + f, a[q]);
-              load_vec<V>(D2 + (int64_t)cr[q].x * F + f, b[q]);
-              if constexpr (MASK) load_vec<V>(E + (int64_t)cr[q].y * F + f, m[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < kSdU; q++)
-#pragma unroll
-              for (int v = 0; v < V; v++) {
-                if constexpr (MASK) {
-                  if (m[q][v] == cr[q].x) part[q] = __builtin_fmaf(a[q][v], b[q][v], part[q]);
-                } else {
-                  part[q] = __builtin_fmaf(a[q][v], b[q][v], part[q]);
-                }
-              }
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < kSdU; q++) {
-          float tot = group_allreduce<G>(part[q]);
-          const int j = j0 + q * NG;
-          if (j < cntn && l == 0) {
-            if constexpr (MEAN) {  // sddmm_cuda.cuh:266-272: divide by deg(row(e)) (always > 0 for a stored entry)
-              const int rw = cr[q].y;
-              tot /= (float)(rowptr[rw + 1] - rowptr[rw]);
-            }
-            cnt[j] = __float_as_int(tot);
-          }
-        }
-      }
+      sd_tile_dots<G, V, MEAN, MASK>(tile, cnt, cntn, t0, lane, F, tiles, rowptr, D1, D2, E, out);
+    }
+  }
+}
+
+// Rows longer than `minlen` only (the column-panel schedule sweeps the others): a block looks at 64 consecutive rows
+// (lane = row), and its four waves share the 64-nnz tiles of every long row among them round-robin.
+template <int G, int V, bool MEAN, bool MASK>
+__global__ __launch_bounds__(kBlock) void sddmm_longrows(int M, int F, int tiles, int minlen,
+                                                         const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                         const float *__restrict__ D1, const float *__restrict__ D2,
+                                                         const int *__restrict__ E, float *__restrict__ out) {
+  __shared__ int2 s_tile[kBlock / kWave][kWave];
+  __shared__ int s_cnt[kBlock / kWave][kWave];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int2 *tile = s_tile[wave];
+  int *cnt = s_cnt[wave];
+  const int r0 = blockIdx.x * kWave;
+  int s = 0, e = 0;
+  if (r0 + lane < M) {
+    s = rowptr[r0 + lane];
+    e = rowptr[r0 + lane + 1];
+  }
+  unsigned long long todo = __ballot(e - s > minlen);
+  while (todo) {
+    const int rl = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int rs = __shfl(s, rl, kWave), re = __shfl(e, rl, kWave);
+    for (int t0 = rs + wave * kWave; t0 < re; t0 += kBlock) {
+      const int cntn = min(kWave, re - t0);
       __builtin_amdgcn_wave_barrier();
-      if (lane < cntn) out[t0 + lane] = __int_as_float(cnt[lane]);
+      tile[lane] = make_int2(lane < cntn ? ld_stream(col + t0 + lane) : 0, r0 + rl);
+      __builtin_amdgcn_wave_barrier();
+      sd_tile_dots<G, V, MEAN, MASK>(tile, cnt, cntn, t0, lane, F, tiles, rowptr, D1, D2, E, out);
     }
   }
 }
@@ -260,6 +306,88 @@ static int dispatch_sddmm(int G, int64_t M, int64_t F, int tiles, int64_t nnz, c
   return DGS_EINVAL;
 }
 
+// ---- column-panel schedule for dense graphs (sddmm_panel.h) ----
+static inline int sd_env_int(const char *k, int dflt) {
+  const char *v = getenv(k);
+  return v ? atoi(v) : dflt;
+}
+static inline int sd_cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+struct SdPanelPlan {
+  bool use;
+  int R, tlong, pcols, npanels, nsb, nwg, lead;
+  size_t lds;
+};
+
+static SdPanelPlan sd_panel_plan(int64_t M, int64_t K, int64_t F, int64_t nnz, int tiles, int G, int V, bool mask) {
+  SdPanelPlan P{};
+  const int force = sd_env_int("DGS_PANEL", -1);
+  if (force == 0 || tiles != 1 || V != 4 || G < 8 || M <= 0 || K <= 0) return P;
+  P.nwg = sd_cu_count();
+  int slots = (int)(kSdPanelBytes / (F * (mask ? 8 : 4)));
+  if (slots > kPanelRMax) slots = kPanelRMax;
+  if (slots < 8) return P;
+  // same rule as the SpMM twin: D2 must overflow the L2s and every panel row must be reused several times per XCD
+  const double reuse = (P.nwg / 8.0) * slots * ((double)nnz / (double)M) / (double)K;
+  if (force != 1 && !((double)K * F * 4.0 >= 32e6 && reuse >= 8.0 && M >= 4096)) return P;
+  P.nsb = (int)((M + (int64_t)P.nwg * slots - 1) / ((int64_t)P.nwg * slots));
+  P.R = (int)((M + (int64_t)P.nwg * P.nsb - 1) / ((int64_t)P.nwg * P.nsb));
+  int64_t pc = (int64_t)sd_env_int("DGS_PANEL_KB", 5120) * 1024 / (F * 4);
+  if (pc < 64) pc = 64;
+  P.pcols = (int)pc;
+  P.npanels = (int)((K + pc - 1) / pc);
+  P.lead = sd_env_int("DGS_PANEL_LEAD", 1);
+  P.tlong = sd_env_int("DGS_PANEL_TLONG", 2048);
+  if (P.tlong < 1) P.tlong = 1;
+  P.lds = (size_t)P.R * F * (mask ? 8 : 4);
+  P.use = true;
+  return P;
+}
+
+template <int G, bool MEAN, bool MASK>
+static int launch_sddmm_panel(const SdPanelPlan &P, int64_t M, int64_t F, const int *rowptr, const int *col,
+                              const float *D1, const float *D2, const int *E, float *out, hipStream_t st) {
+  auto kern = sddmm_panel<G, MEAN, MASK>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kSdPanelBytes) != hipSuccess)
+      return DGS_ELAUNCH;
+    attr_set = true;
+  }
+  int *arrivals = nullptr;
+  if (hipGetSymbolAddress(reinterpret_cast<void **>(&arrivals), HIP_SYMBOL(g_sddmm_arrivals)) != hipSuccess)
+    return DGS_ELAUNCH;
+  if (hipMemsetAsync(arrivals, 0, sizeof(int), st) != hipSuccess) return DGS_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)P.nwg), dim3(kPanelBlock), P.lds, st, (int)M, (int)F, P.R, P.tlong, P.pcols,
+                     P.npanels, P.nsb, P.lead, rowptr, col, D1, D2, E, out, arrivals);
+  // rows longer than tlong: row-driven kernel, the four waves of a block share the tiles of each long row
+  hipLaunchKernelGGL((sddmm_longrows<G, 4, MEAN, MASK>), dim3((unsigned)((M + kWave - 1) / kWave)), dim3(kBlock), 0, st,
+                     (int)M, (int)F, 1, P.tlong, rowptr, col, D1, D2, E, out);
+  return check_launch();
+}
+
+template <bool MEAN, bool MASK>
+static int dispatch_sddmm_panel(int G, const SdPanelPlan &P, int64_t M, int64_t F, const int *rowptr, const int *col,
+                                const float *D1, const float *D2, const int *E, float *out, hipStream_t st) {
+  switch (G) {
+    case 8: return launch_sddmm_panel<8, MEAN, MASK>(P, M, F, rowptr, col, D1, D2, E, out, st);
+    case 16: return launch_sddmm_panel<16, MEAN, MASK>(P, M, F, rowptr, col, D1, D2, E, out, st);
+    case 32: return launch_sddmm_panel<32, MEAN, MASK>(P, M, F, rowptr, col, D1, D2, E, out, st);
+    case 64: return launch_sddmm_panel<64, MEAN, MASK>(P, M, F, rowptr, col, D1, D2, E, out, st);
+  }
+  return DGS_EINVAL;
+}
+
 template <bool MEAN, bool MASK>
 static int run_sddmm(int64_t M, int64_t K, int64_t F, int64_t nnz, const int *rowptr, const int *col, const float *D1,
                      const float *D2, const int *E, float *out, hipStream_t st) {
@@ -270,6 +398,8 @@ static int run_sddmm(int64_t M, int64_t K, int64_t F, int64_t nnz, const int *ro
   if (F == 0) return hipMemsetAsync(out, 0, (size_t)nnz * sizeof(float), st) == hipSuccess ? DGS_OK : DGS_ELAUNCH;
   const bool al = is_aligned16(D1) && is_aligned16(D2) && (!MASK || is_aligned16(E));
   const FeatMap fm = feat_map(F, al);
+  const SdPanelPlan P = sd_panel_plan(M, K, F, nnz, fm.tiles, fm.G, fm.V, MASK);
+  if (P.use) return dispatch_sddmm_panel<MEAN, MASK>(fm.G, P, M, F, rowptr, col, D1, D2, E, out, st);
   if (fm.V == 4) return dispatch_sddmm<4, MEAN, MASK>(fm.G, M, F, fm.tiles, nnz, rowptr, col, D1, D2, E, out, st);
   return dispatch_sddmm<1, MEAN, MASK>(fm.G, M, F, fm.tiles, nnz, rowptr, col, D1, D2, E, out, st);
 }

@@ -33,6 +33,9 @@ if _spec is not None and os.environ.get('DGSPARSE_PY_BINDING', '0') != '1':
 def _t_values(values, csr2csc, has_value):
     if not has_value:
         return None
+    if csr2csc.dtype == torch.int32 and csr2csc.is_cuda and values.dtype == torch.float32:
+        # one pass of the HIP gather over the int32 permutation (index_select wants an int64 copy first)
+        return _capi.gather_rows(values.detach().reshape(-1, 1), csr2csc).view(-1)
     return values.view(-1).index_select(0, csr2csc.long() if csr2csc.dtype != torch.int64 else csr2csc)
 
 

@@ -214,3 +214,43 @@ def test_panel_masked_sum_for_max_min_backward(capi, monkeypatch, N):
         g0 = capi.spmm_mask(dev(colptr), dev(row), dev(tval), dev(G), dev(E)).cpu().numpy()
         np.testing.assert_allclose(gX, g0, rtol=2e-5, atol=1e-5)
 
+
+@pytest.mark.parametrize('F', [32, 64, 96, 128, 256])
+def test_panel_sddmm(capi, monkeypatch, F):
+    """Column-panel SDDMM (csrc/sddmm_panel.h) forced on a small input: D1 rows in LDS, D2 swept in panels, long rows
+    cut into segments, every nnz written exactly once; sum, mean and the arg-masked variant against the oracle and
+    against the nnz-balanced kernel."""
+    M, K = 5000, 2200
+    rp, col = dense_graph(M, K, 0, 100, seed=80 + F, hubs=[(1, 2100), (4000, 900), (4999, 1300)], empty_every=61)
+    rng = np.random.default_rng(81 + F)
+    D1 = (rng.random((M, F), dtype=np.float32) - 0.5).astype(np.float32)
+    D2 = (rng.random((K, F), dtype=np.float32) - 0.5).astype(np.float32)
+    X = rng.integers(-3, 4, size=(K, F)).astype(np.float32)
+    _, E = oracle.spmm('max', rp, col, None, X)
+    for tlong in (4096, 300):  # 300: the hub rows become several segments
+        res = {}
+        for force in ('1', '0'):
+            monkeypatch.setenv('DGS_PANEL', force)
+            monkeypatch.setenv('DGS_PANEL_KB', '8')
+            monkeypatch.setenv('DGS_PANEL_TLONG', str(tlong))
+            res[force] = (capi.sddmm(dev(rp), dev(col), dev(D1), dev(D2)).cpu().numpy(),
+                          capi.sddmm(dev(rp), dev(col), dev(D1), dev(D2), reduce_op=oracle.REDUCE['mean']).cpu().numpy(),
+                          capi.sddmm(dev(rp), dev(col), dev(D1), dev(D2), E=dev(E)).cpu().numpy())
+        ref = (oracle.sddmm(rp, col, D1, D2, 'sum', fma=True), oracle.sddmm(rp, col, D1, D2, 'mean', fma=True),
+               oracle.sddmm_mask(rp, col, D1, D2, E, fma=True))
+        for k, what in enumerate(('sum', 'mean', 'masked')):
+            np.testing.assert_allclose(res['1'][k], ref[k], rtol=1e-5, atol=2e-6, err_msg=f'panel sddmm {what}')
+            np.testing.assert_allclose(res['1'][k], res['0'][k], rtol=1e-5, atol=2e-6, err_msg=f'panel vs nnzbal {what}')
+
+
+def test_panel_sddmm_unsorted_many_superblocks(capi, monkeypatch):
+    M, K, F = 150_000, 900, 256
+    rp, col = dense_graph(M, K, 0, 12, seed=90, sort=False, dup=True)
+    rng = np.random.default_rng(91)
+    D1 = rng.random((M, F), dtype=np.float32)
+    D2 = rng.random((K, F), dtype=np.float32)
+    monkeypatch.setenv('DGS_PANEL', '1')
+    monkeypatch.setenv('DGS_PANEL_KB', '128')
+    got = capi.sddmm(dev(rp), dev(col), dev(D1), dev(D2)).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.sddmm(rp, col, D1, D2, 'sum', fma=True), rtol=1e-5, atol=2e-6)
+
