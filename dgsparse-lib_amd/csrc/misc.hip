@@ -20,6 +20,22 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(int64_t n_ids, int 
   store_vec<V>(dst + i * N + f, x);
 }
 
+// N == 1 (a permutation of a value array, e.g. CSR -> CSC order of the edge values): 4 elements per thread, so that
+// four independent random reads are in flight per lane and the ids / results move as 16-byte vectors.
+__global__ __launch_bounds__(kBlock) void gather_scalar_kernel(int64_t n, const int *__restrict__ ids,
+                                                               const float *__restrict__ src,
+                                                               float *__restrict__ dst) {
+  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const dgs_i4 id = __builtin_nontemporal_load(reinterpret_cast<const dgs_i4 *>(ids + i));
+    const float a = src[id[0]], b = src[id[1]], c = src[id[2]], d = src[id[3]];
+    float o[4] = {a, b, c, d};
+    store_vec_stream<4>(dst + i, o);
+  } else {
+    for (int64_t k = i; k < n; k++) dst[k] = src[ids[k]];
+  }
+}
+
 template <int V>
 __global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(int64_t n_ids, int N, const int *__restrict__ ids,
                                                                   const float *__restrict__ src,
@@ -61,6 +77,12 @@ extern "C" int dgs_gather_rows_f32(int64_t n_ids, int64_t N, const int32_t *ids,
   if (n_ids == 0 || N == 0) return DGS_OK;
   if (!ids || !src || !dst) return DGS_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (N == 1 && is_aligned16(ids) && is_aligned16(dst)) {
+    const int64_t threads = (n_ids + 3) / 4;
+    hipLaunchKernelGGL(gather_scalar_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n_ids,
+                       ids, src, dst);
+    return check_launch();
+  }
   const bool v4 = (N % 4 == 0) && is_aligned16(src) && is_aligned16(dst);
   const int64_t lanes = v4 ? N / 4 : N;
   const dim3 grid((unsigned)((n_ids * lanes + kBlock - 1) / kBlock));
