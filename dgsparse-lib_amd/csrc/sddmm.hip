@@ -357,12 +357,14 @@ template <int G, bool MEAN, bool MASK>
 static int launch_sddmm_panel(const SdPanelPlan &P, int64_t M, int64_t F, const int *rowptr, const int *col,
                               const float *D1, const float *D2, const int *E, float *out, hipStream_t st) {
   auto kern = sddmm_panel<G, MEAN, MASK>;
-  static bool attr_set = false;  // per instantiation
-  if (!attr_set) {
+  static bool attr_set[64] = {};  // per instantiation and device: allow the large dynamic LDS
+  int dev_id = 0;
+  if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) return DGS_ELAUNCH;
+  if (!attr_set[dev_id]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kSdPanelBytes) != hipSuccess)
       return DGS_ELAUNCH;
-    attr_set = true;
+    attr_set[dev_id] = true;
   }
   int *arrivals = nullptr;
   if (hipGetSymbolAddress(reinterpret_cast<void **>(&arrivals), HIP_SYMBOL(g_sddmm_arrivals)) != hipSuccess)

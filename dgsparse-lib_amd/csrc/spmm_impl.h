@@ -900,12 +900,14 @@ static int launch_all(const SpmmArgs &a) {
       hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, tl, a.rowptr, hdr,
                          units);
       auto kern = spmm_panel<G, OP, HAS_VAL>;
-      static bool attr_set = false;  // per instantiation: allow the 128 KiB of dynamic LDS
-      if (!attr_set) {
+      static bool attr_set[64] = {};  // per instantiation and device: allow the large dynamic LDS
+      int dev_id = 0;
+      if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) return DGS_ELAUNCH;
+      if (!attr_set[dev_id]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kPanelAccBytes) != hipSuccess)
           return DGS_ELAUNCH;
-        attr_set = true;
+        attr_set[dev_id] = true;
       }
       hipLaunchKernelGGL(kern, dim3((unsigned)P.nwg), dim3(kPanelBlock), P.lds, a.st, (int)a.M,
                          (int)a.N, P.R, tl, P.pcols, P.npanels, P.nsb, P.lead, a.rowptr, a.col, a.val, a.B, a.C,
