@@ -170,6 +170,38 @@ def test_hip_graph_capture_and_replay():
         assert not torch.equal(out, ref)
 
 
+def test_hip_graph_capture_panel_schedules(monkeypatch):
+    """Same for the column-panel schedules (forced on a mid-size input): memset + classify + panel sweep + unit path,
+    and the SDDMM twin (memset of its barrier counter + panel sweep + long-row kernel), captured and replayed."""
+    from bench import graphgen
+    from dgsparse import _capi
+    monkeypatch.setenv('DGS_PANEL', '1')
+    monkeypatch.setenv('DGS_PANEL_KB', '64')
+    monkeypatch.setenv('DGS_PANEL_TLONG', '512')
+    rp, col, st = graphgen.dataset_shaped('arxiv', seed=1, device='cuda', as_torch=True)
+    assert _capi.spmm_schedule(_capi.SUM, st['M'], st['K'], 64, st['nnz']) == 'panel'
+    val = torch.rand(st['nnz'], device='cuda')
+    X = torch.rand(st['K'], 64, device='cuda')
+    D1 = torch.rand(st['M'], 64, device='cuda')
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            _capi.spmm(_capi.MAX, rp, col, val, X)
+            _capi.sddmm(rp, col, D1, X)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        C, E = _capi.spmm(_capi.MAX, rp, col, val, X)
+        W = _capi.sddmm(rp, col, D1, X)
+    X.mul_(-1.5)
+    g.replay()
+    torch.cuda.synchronize()
+    C2, E2 = _capi.spmm(_capi.MAX, rp, col, val, X)
+    assert torch.equal(C, C2) and torch.equal(E, E2)
+    assert torch.equal(W, _capi.sddmm(rp, col, D1, X))
+
+
 def test_rccl_collectives_single_rank():
     """init_process_group('nccl') + the collective calls of dgsparse/dist.py under torch.distributed.run (1 rank)."""
     import os
