@@ -54,6 +54,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dist', action='store_true', help='run the partitioned code path even with one rank (testing)')
     ap.add_argument('--sweep', action='store_true', help='also time feat=32/128 and max (extra keys)')
+    ap.add_argument('--no-dense', action='store_true', help='skip the Reddit-shaped side measurement (extra key)')
     return ap.parse_args()
 
 
@@ -239,6 +240,24 @@ def main():
             sw[f'{red}_feat{n2}'] = dict(gflops=round(2.0 * nnz_total * n2 / (w2 / 20) / 1e9, 1),
                                          gbs=round(b2 / (e2 / 20) / 1e9, 1), frac=round(b2 / (e2 / 20) / 1e9 / HBM_PEAK_GBS, 4))
         res['sweep'] = sw
+
+    if rank == 0 and not use_dist and not a.no_dense:
+        # side figure (extra key, not the metric): the dense-graph configuration of BASELINE.json (C3), which takes the
+        # column-panel schedule; ~10 s of graph generation on the GPU + 10 timed launches
+        try:
+            rp3, col3, st3 = graphgen.dataset_shaped('reddit', seed=0, device=str(dev), as_torch=True)
+            val3 = torch.rand(st3['nnz'], device=dev)
+            X3 = torch.rand((st3['K'], 128), device=dev)
+            w3, e3 = time_steps(lambda: _capi.spmm(_capi.SUM, rp3, col3, val3, X3), 10, 3, False)
+            b3 = alg_bytes_spmm(st3['M'], st3['K'], 128, st3['nnz'], True, False)
+            res['dense_graph'] = dict(
+                workload=f"Reddit-shaped {st3['M']}x{st3['K']}, nnz {st3['nnz']}, feat 128, sum",
+                schedule=_capi.spmm_schedule(_capi.SUM, st3['M'], st3['K'], 128, st3['nnz']),
+                ms_per_step=round(w3 / 10 * 1e3, 4), gflops=round(2.0 * st3['nnz'] * 128 / (w3 / 10) / 1e9, 1),
+                alg_gbs=round(b3 / (e3 / 10) / 1e9, 1), frac=round(b3 / (e3 / 10) / 1e9 / HBM_PEAK_GBS, 4))
+            del rp3, col3, val3, X3
+        except Exception as e:
+            res['dense_graph'] = dict(error=str(e))
 
     if rank == 0 and not use_dist and not a.no_cpu_baseline:
         try:
