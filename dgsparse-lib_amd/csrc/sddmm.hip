@@ -338,7 +338,7 @@ static SdPanelPlan sd_panel_plan(int64_t M, int64_t K, int64_t F, int64_t nnz, i
   if (slots < 8) return P;
   // same rule as the SpMM twin: D2 must overflow the L2s and every panel row must be reused several times per XCD
   const double reuse = (P.nwg / 8.0) * slots * ((double)nnz / (double)M) / (double)K;
-  if (force != 1 && !((double)K * F * 4.0 >= 32e6 && reuse >= 8.0 && M >= 4096)) return P;
+  if (force != 1 && !((double)K * F * 4.0 >= 16e6 && reuse >= 8.0 && M >= 4096)) return P;
   P.nsb = (int)((M + (int64_t)P.nwg * slots - 1) / ((int64_t)P.nwg * slots));
   P.R = (int)((M + (int64_t)P.nwg * P.nsb - 1) / ((int64_t)P.nwg * P.nsb));
   int64_t pc = (int64_t)sd_env_int("DGS_PANEL_KB", 5120) * 1024 / (F * 4);

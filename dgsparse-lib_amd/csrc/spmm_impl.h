@@ -866,7 +866,7 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
   // several times per sweep: reuse = (rows resident per XCD) * (nnz per row) / K.  Measured crossover ~6 (N = 128).
   const double bbytes = (double)a.K * a.N * 4.0;
   const double reuse = (P.nwg / 8.0) * slots * ((double)a.nnz / (double)a.M) / (double)(a.K > 0 ? a.K : 1);
-  if (force != 1 && !(bbytes >= 32e6 && reuse >= 8.0 && a.M >= 4096)) return P;
+  if (force != 1 && !(bbytes >= 16e6 && reuse >= 8.0 && a.M >= 4096)) return P;
   P.nsb = (int)((a.M + (int64_t)P.nwg * slots - 1) / ((int64_t)P.nwg * slots));
   P.R = (int)((a.M + (int64_t)P.nwg * P.nsb - 1) / ((int64_t)P.nwg * P.nsb));
   const int64_t pbytes = (int64_t)env_int("DGS_PANEL_KB", 5120) * 1024;
