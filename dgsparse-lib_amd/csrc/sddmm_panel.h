@@ -52,6 +52,7 @@ __global__ __launch_bounds__(kPanelBlock) void sddmm_panel(int M, int F, int R, 
   // entry of a batch this lane ends up holding after the transposing butterfly
   const int bidx = ((lig & 1) ? 4 : 0) + ((lig & 2) ? 2 : 0) + ((lig & 4) ? 1 : 0);
 
+  bool giveup = false;  // thread 0 only: soft barrier abandoned after a timed-out wait
   for (int sb = 0; sb < nsb; ++sb) {
     const int64_t row0 = ((int64_t)sb * gridDim.x + blockIdx.x) * R;
     __syncthreads();
@@ -257,9 +258,16 @@ __global__ __launch_bounds__(kPanelBlock) void sddmm_panel(int M, int F, int R, 
         s_ctr = 0;
         if (nv == 0) atomicAdd(arrivals, 1);  // nothing to hand out: signal here
         const int64_t target = ((int64_t)sb * npanels + p + 2 - lead) * gridDim.x;
-        if (target > 0 && !(sb == nsb - 1 && p == npanels - 1)) {
+        if (target > 0 && !giveup && !(sb == nsb - 1 && p == npanels - 1)) {
+          // every poll is a device-scope load (~1-2 us): 256 of them bound a wait to ~0.4 ms.  A wait that runs out means
+          // the other workgroups are not co-resident (CUs taken by another stream, e.g. an overlapped collective): stop
+          // waiting for the rest of the launch instead of paying the timeout at every step.
           int spins = 0;
-          while (dev_load_relaxed(arrivals) < target && spins++ < 4096) __builtin_amdgcn_s_sleep(2);
+          while (dev_load_relaxed(arrivals) < target && spins < 256) {
+            __builtin_amdgcn_s_sleep(2);
+            ++spins;
+          }
+          giveup = spins >= 256;
         }
       }
       __syncthreads();

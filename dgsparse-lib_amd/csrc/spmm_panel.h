@@ -166,6 +166,7 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int R, i
   const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
   const int n4 = N / V;
 
+  bool giveup = false;  // thread 0 only: soft barrier abandoned after a timed-out wait
   for (int sb = 0; sb < nsb; ++sb) {
     const int64_t row0 = ((int64_t)sb * gridDim.x + blockIdx.x) * R;
     __syncthreads();
@@ -259,9 +260,16 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int R, i
       if (tid == 0) {
         s_ctr = 0;
         const int64_t target = ((int64_t)sb * npanels + p + 2 - lead) * gridDim.x;
-        if (target > 0 && !(sb == nsb - 1 && p == npanels - 1)) {
+        if (target > 0 && !giveup && !(sb == nsb - 1 && p == npanels - 1)) {
+          // every poll is a device-scope load (~1-2 us): 256 of them bound a wait to ~0.4 ms.  A wait that runs out means
+          // the other workgroups are not co-resident (CUs taken by another stream, e.g. an overlapped collective): stop
+          // waiting for the rest of the launch instead of paying the timeout at every step.
           int spins = 0;
-          while (dev_load_relaxed(arrivals) < target && spins++ < 4096) __builtin_amdgcn_s_sleep(2);
+          while (dev_load_relaxed(arrivals) < target && spins < 256) {
+            __builtin_amdgcn_s_sleep(2);
+            ++spins;
+          }
+          giveup = spins >= 256;
         }
       }
       __syncthreads();
