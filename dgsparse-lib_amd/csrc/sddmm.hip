@@ -341,7 +341,7 @@ static SdPanelPlan sd_panel_plan(int64_t M, int64_t K, int64_t F, int64_t nnz, i
   if (force != 1 && !((double)K * F * 4.0 >= 16e6 && reuse >= 8.0 && M >= 4096)) return P;
   P.nsb = (int)((M + (int64_t)P.nwg * slots - 1) / ((int64_t)P.nwg * slots));
   P.R = (int)((M + (int64_t)P.nwg * P.nsb - 1) / ((int64_t)P.nwg * P.nsb));
-  int64_t pc = (int64_t)sd_env_int("DGS_PANEL_KB", 5120) * 1024 / (F * 4);
+  int64_t pc = (int64_t)sd_env_int("DGS_PANEL_KB", 6144) * 1024 / (F * 4);
   if (pc < 64) pc = 64;
   P.pcols = (int)pc;
   P.npanels = (int)((K + pc - 1) / pc);

@@ -869,7 +869,7 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
   if (force != 1 && !(bbytes >= 16e6 && reuse >= 8.0 && a.M >= 4096)) return P;
   P.nsb = (int)((a.M + (int64_t)P.nwg * slots - 1) / ((int64_t)P.nwg * slots));
   P.R = (int)((a.M + (int64_t)P.nwg * P.nsb - 1) / ((int64_t)P.nwg * P.nsb));
-  const int64_t pbytes = (int64_t)env_int("DGS_PANEL_KB", 5120) * 1024;
+  const int64_t pbytes = (int64_t)env_int("DGS_PANEL_KB", 6144) * 1024;
   int64_t pc = pbytes / (a.N * (a.reduce_op == kOpMaskSum ? 8 : 4));  // masked sum gathers grad AND arg-id rows
   if (pc < 64) pc = 64;
   P.pcols = (int)pc;
