@@ -254,3 +254,41 @@ def test_panel_sddmm_unsorted_many_superblocks(capi, monkeypatch):
     got = capi.sddmm(dev(rp), dev(col), dev(D1), dev(D2)).cpu().numpy()
     np.testing.assert_allclose(got, oracle.sddmm(rp, col, D1, D2, 'sum', fma=True), rtol=1e-5, atol=2e-6)
 
+
+@pytest.mark.parametrize('reduce', ['sum', 'mean', 'max', 'min'])
+def test_panel_autograd_through_the_public_ops(monkeypatch, reduce):
+    """dgsparse.spmm_* forward + backward with every kernel on its panel schedule (forward SpMM, SpMM on the CSC arrays
+    or masked SpMM, SDDMM or masked SDDMM, HIP gather of the CSC values) against gradients built from the oracle."""
+    import dgsparse
+    monkeypatch.setenv('DGS_PANEL', '1')
+    monkeypatch.setenv('DGS_PANEL_KB', '32')
+    monkeypatch.setenv('DGS_PANEL_TLONG', '400')
+    M = K = 6000
+    N = 64
+    rp, col = dense_graph(M, K, 10, 100, seed=100, hubs=[(5, 1500), (5999, 700)])
+    rng = np.random.default_rng(101)
+    val = (rng.random(col.size, dtype=np.float32) + 0.1).astype(np.float32)
+    X = (rng.random((K, N), dtype=np.float32) - 0.5).astype(np.float32)
+    G = (rng.random((M, N), dtype=np.float32) - 0.5).astype(np.float32)
+    tcsr = torch.sparse_csr_tensor(torch.from_numpy(rp), torch.from_numpy(col), torch.from_numpy(val), size=(M, K),
+                                   device='cuda')
+    A = dgsparse.SparseTensor.from_torch_sparse_csr_tensor(tcsr.clone().detach(), True, requires_grad=True)
+    Xt = dev(X).requires_grad_(True)
+    fn = getattr(dgsparse, 'spmm_' + reduce)
+    out = fn(A, Xt, 0)
+    out.backward(dev(G))
+    Co, Eo = oracle.spmm(reduce, rp, col, val, X, fma=True)
+    colptr, row, tval, _ = oracle.csr2csc(rp, col, val, K)
+    lens = np.diff(rp)
+    if reduce in ('max', 'min'):
+        assert_bitexact(out.detach().cpu().numpy(), Co, 'forward')
+        dX = oracle.spmm_mask(colptr, row, tval, G, Eo, fma=True)
+        dA = oracle.sddmm_mask(rp, col, G, X, Eo, fma=True)
+    else:
+        np.testing.assert_allclose(out.detach().cpu().numpy(), Co, rtol=1e-5, atol=2e-6)
+        Gs = G / np.maximum(lens, 1)[:, None].astype(np.float32) if reduce == 'mean' else G
+        dX, _ = oracle.spmm('sum', colptr, row, tval, Gs, fma=True)
+        dA = oracle.sddmm(rp, col, G, X, reduce, fma=True)
+    np.testing.assert_allclose(Xt.grad.cpu().numpy(), dX, rtol=1e-5, atol=4e-6, err_msg='dX')
+    np.testing.assert_allclose(A.storage._values.grad.cpu().numpy().ravel(), dA, rtol=1e-5, atol=4e-6, err_msg='dA')
+
