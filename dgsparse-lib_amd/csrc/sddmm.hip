@@ -165,15 +165,18 @@ __global__ __launch_bounds__(kBlock) void sddmm_nnzbal(int M, int F, int tiles, 
   }
 }
 
-// Rows longer than `minlen` only (the column-panel schedule sweeps the others): a block looks at 64 consecutive rows
-// (lane = row), and its four waves share the 64-nnz tiles of every long row among them round-robin.
+// Rows longer than `minlen` only (the column-panel schedule sweeps the others): a block of 16 waves looks at 64
+// consecutive rows (lane = row), and the waves share the 64-nnz tiles of every long row among them round-robin
+// (a tile is a chain of dependent loads of ~6 us: a 21 k-nnz row is 330 tiles, 21 per wave).
+constexpr int kLongBlock = 1024;
 template <int G, int V, bool MEAN, bool MASK>
-__global__ __launch_bounds__(kBlock) void sddmm_longrows(int M, int F, int tiles, int minlen,
-                                                         const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                         const float *__restrict__ D1, const float *__restrict__ D2,
-                                                         const int *__restrict__ E, float *__restrict__ out) {
-  __shared__ int2 s_tile[kBlock / kWave][kWave];
-  __shared__ int s_cnt[kBlock / kWave][kWave];
+__global__ __launch_bounds__(kLongBlock) void sddmm_longrows(int M, int F, int tiles, int minlen,
+                                                             const int *__restrict__ rowptr,
+                                                             const int *__restrict__ col, const float *__restrict__ D1,
+                                                             const float *__restrict__ D2, const int *__restrict__ E,
+                                                             float *__restrict__ out) {
+  __shared__ int2 s_tile[kLongBlock / kWave][kWave];
+  __shared__ int s_cnt[kLongBlock / kWave][kWave];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int2 *tile = s_tile[wave];
   int *cnt = s_cnt[wave];
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void sddmm_longrows(int M, int F, int tiles
     const int rl = __ffsll((long long)todo) - 1;
     todo &= todo - 1;
     const int rs = __shfl(s, rl, kWave), re = __shfl(e, rl, kWave);
-    for (int t0 = rs + wave * kWave; t0 < re; t0 += kBlock) {
+    for (int t0 = rs + wave * kWave; t0 < re; t0 += kLongBlock) {
       const int cntn = min(kWave, re - t0);
       __builtin_amdgcn_wave_barrier();
       tile[lane] = make_int2(lane < cntn ? ld_stream(col + t0 + lane) : 0, r0 + rl);
@@ -372,8 +375,8 @@ static int launch_sddmm_panel(const SdPanelPlan &P, int64_t M, int64_t F, const 
   if (hipMemsetAsync(arrivals, 0, sizeof(int), st) != hipSuccess) return DGS_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)P.nwg), dim3(kPanelBlock), P.lds, st, (int)M, (int)F, P.R, P.tlong, P.pcols,
                      P.npanels, P.nsb, P.lead, rowptr, col, D1, D2, E, out, arrivals);
-  // rows longer than tlong: row-driven kernel, the four waves of a block share the tiles of each long row
-  hipLaunchKernelGGL((sddmm_longrows<G, 4, MEAN, MASK>), dim3((unsigned)((M + kWave - 1) / kWave)), dim3(kBlock), 0, st,
+  // rows longer than tlong: row-driven kernel, the 16 waves of a block share the tiles of each long row
+  hipLaunchKernelGGL((sddmm_longrows<G, 4, MEAN, MASK>), dim3((unsigned)((M + kWave - 1) / kWave)), dim3(kLongBlock), 0, st,
                      (int)M, (int)F, 1, P.tlong, rowptr, col, D1, D2, E, out);
   return check_launch();
 }

@@ -22,7 +22,7 @@
 namespace dgs {
 
 constexpr int kSdVMax = kPanelRMax;            // row slots per workgroup
-constexpr int kSdPanelBytes = 112 * 1024;      // LDS for the D1 (+E) rows
+constexpr int kSdPanelBytes = 128 * 1024;      // LDS for the D1 (+E) rows (+ 22 KB of row tables = 150 KB)
 constexpr int kSdPU = 8;                       // D2-row gathers in flight per lane (fixed by the 8-way butterfly)
 
 __device__ int g_sddmm_arrivals;  // soft-barrier counter (zeroed by a memset node before every launch)
