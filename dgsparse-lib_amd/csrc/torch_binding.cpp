@@ -159,6 +159,24 @@ struct SpMM : public torch::autograd::Function<SpMM<OP>> {
     const bool need_v = has_value && ctx->needs_input_grad(2), need_d = ctx->needs_input_grad(6);
     if (OP == DGS_MAX || OP == DGS_MIN) {
       const Tensor &E = saved[7];
+      if (!at::globalContext().deterministicAlgorithms() && (need_v || need_d)) {
+        // one pass over the arg ids, fp32 atomics (not bit-reproducible run to run; the masked kernels below are)
+        const Tensor rp = i32vec(rowptr, "rowptr"), cl = i32vec(col, "col"), Xc = f32mat(dense, "dense");
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(Xc.device());
+        const int64_t M = rp.numel() - 1, nnz = cl.numel(), K = Xc.size(0), N = Xc.size(1);
+        Tensor vkeep;
+        const float *vptr = opt_values(values, has_value, nnz, vkeep);
+        const Tensor Ec = E.contiguous();
+        if (need_d) grad_dense = at::empty({K, N}, Xc.options());
+        Tensor gw = need_v ? at::empty({nnz}, Xc.options()) : Tensor();
+        check_rc(dgs_spmm_arg_backward_f32(M, K, N, nnz, rp.data_ptr<int>(), cl.data_ptr<int>(), vptr, Ec.data_ptr<int>(),
+                                           grad_out.data_ptr<float>(), Xc.data_ptr<float>(),
+                                           need_d ? grad_dense.data_ptr<float>() : nullptr,
+                                           need_v ? gw.data_ptr<float>() : nullptr, cur_stream()),
+                 "spmm_arg_backward");
+        if (need_v) grad_value = gw.view_as(values);
+        return {Tensor(), Tensor(), grad_value, Tensor(), Tensor(), Tensor(), grad_dense, Tensor(), Tensor()};
+      }
       if (need_v) grad_value = sddmm_impl(rowptr, col, grad_out, dense, DGS_SUM, E).view_as(values);
       if (need_d) grad_dense = spmm_mask_impl(colptr, row, t_values(values, csr2csc, has_value), has_value, grad_out, E, dense.size(0));
     } else if (OP == DGS_MEAN) {

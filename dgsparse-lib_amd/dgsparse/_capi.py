@@ -39,6 +39,8 @@ _lib.dgs_spmm_csr_mask_f32.restype = _int
 _lib.dgs_spmm_csr_mask_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
 _lib.dgs_spmm_csr_mask_workspace_bytes.restype = _sz
 _lib.dgs_spmm_csr_mask_workspace_bytes.argtypes = [_i64, _i64, _i64]
+_lib.dgs_spmm_arg_backward_f32.restype = _int
+_lib.dgs_spmm_arg_backward_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
 _lib.dgs_sddmm_csr_f32.restype = _int
 _lib.dgs_sddmm_csr_f32.argtypes = [_int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]
 _lib.dgs_sddmm_csr_mask_f32.restype = _int
@@ -59,7 +61,7 @@ _lib.dgs_scatter_add_rows_f32.restype = _int
 _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
 EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
-           'dgs_spmm_csr_schedule',
+           'dgs_spmm_csr_schedule', 'dgs_spmm_arg_backward_f32',
            'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
            'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'dgs_sddmm_coo_f32', 'dgs_gspmm_csr_workspace_bytes', 'dgs_gspmm_csr_f32', 'gespmmCsrSpMM',
            'spmm_cuda', 'spmm_cuda_no_edge_value', 'sddmm_cuda_csr', 'sddmm_cuda_coo', 'gespmmAlgSel',
@@ -198,6 +200,27 @@ def spmm_mask(ptr, idx, values, grad, E, n_out=None):
         _check(_lib.dgs_spmm_csr_mask_f32(Mo, Mi, N, nnz, _p(ptr), _p(idx), _p(values), _p(grad), _p(E), _p(out),
                                           _p(ws), wsb, _stream(dev)), 'spmm_mask')
     return out
+
+
+def spmm_arg_backward(rowptr, col, values, E, grad, dense, need_dense=True, need_values=True):
+    """Both gradients of spmm_max / spmm_min from the forward's arg ids in one pass (fp32 atomics):
+    returns (grad_dense [K,N] or None, grad_values [nnz] or None)."""
+    dev = _need_gpu(rowptr, col, values, E, grad, dense)
+    rowptr = _i32(rowptr, 'rowptr')
+    col = _i32(col, 'col')
+    grad = _f32mat(grad, 'grad')
+    dense = _f32mat(dense, 'dense')
+    M, nnz, (K, N) = rowptr.numel() - 1, col.numel(), dense.shape
+    if E.dtype != torch.int32 or tuple(E.shape) != (M, N) or tuple(grad.shape) != (M, N):
+        raise TypeError('dgsparse: E must be int32 [M,N] and grad float32 [M,N]')
+    E = E.contiguous()
+    values = _f32vec(values, 'values', nnz)
+    gX = torch.empty((K, N), dtype=torch.float32, device=dev) if need_dense else None
+    gW = torch.empty(nnz, dtype=torch.float32, device=dev) if (need_values and values is not None) else None
+    with _on_device(dev):
+        _check(_lib.dgs_spmm_arg_backward_f32(M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(E), _p(grad), _p(dense),
+                                              _p(gX), _p(gW), _stream(dev)), 'spmm_arg_backward')
+    return gX, gW
 
 
 def sddmm(rowptr, col, D1, D2, reduce_op=SUM, E=None):

@@ -112,6 +112,15 @@ class _SpMMArg(torch.autograd.Function):
         rowptr, col, values, colptr, row, csr2csc, dense, E = ctx.saved_tensors
         grad_out = grad_out.contiguous()
         grad_value = grad_dense = None
+        need_v, need_d = ctx.has_value and ctx.needs_input_grad[2], ctx.needs_input_grad[6]
+        if not torch.are_deterministic_algorithms_enabled() and (need_v or need_d):
+            # one pass over the arg ids with fp32 atomics (csrc/arg_backward.hip); the masked kernels below are the
+            # bit-reproducible route and serve torch.use_deterministic_algorithms(True)
+            grad_dense, gw = _capi.spmm_arg_backward(rowptr, col, values if ctx.has_value else None, E, grad_out,
+                                                     dense, need_dense=need_d, need_values=need_v)
+            if need_v:
+                grad_value = gw.view_as(values)
+            return None, None, grad_value, None, None, None, grad_dense, None, None
         if ctx.has_value and ctx.needs_input_grad[2]:
             grad_value = _capi.sddmm(rowptr, col, grad_out, dense, SUM, E=E).view_as(values)
         if ctx.needs_input_grad[6]:

@@ -111,6 +111,21 @@ int dgs_sddmm_csr_mask_f32(int64_t M, int64_t K, int64_t F, int64_t nnz, const i
                            const int32_t *col, const float *D1, const float *D2, const int32_t *E,
                            float *out, dgsStream_t stream);
 
+/*
+ * Both gradients of SpMM-max/min in one pass over the forward's arg ids (either output may be NULL):
+ *   gX[j,f] = sum_{(i,j) in A} [E[i,f] == j] * A[i,j] * gC[i,f]      (what dgs_spmm_csr_mask_f32 computes from the CSC arrays)
+ *   gW[e]   = sum_f [E[row(e),f] == col(e)] * gC[row(e),f] * X[col(e),f]        (what dgs_sddmm_csr_mask_f32 computes)
+ * Replaces: the pair spmm_cuda_with_mask() + sddmm_cuda_csr_with_mask(), src/cuda/spmm_cuda.cu:255-303,363-382, as
+ *           they are called from SpMMMax/SpMMMin::backward, src/spmm.cpp:100-214.
+ * Every (i,f) has one arg column, so both sums are scatters with M*N sources (instead of nnz*N gathered row pairs);
+ * needs only the CSR arrays.  gX [K,N] and gW [nnz] are zeroed inside.  Accumulation uses fp32 atomics: results
+ * agree with the masked kernels to rounding but are not bit-reproducible from run to run - callers that need
+ * determinism use the two masked entry points above.
+ */
+int dgs_spmm_arg_backward_f32(int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,
+                              const int32_t *col, const float *val, const int32_t *E, const float *gC,
+                              const float *X, float *gX, float *gW, dgsStream_t stream);
+
 /* Generalised SpMM of the reference's gspmm-fp demo module (src/gspmm-fp/gspmm.cc:9-28, GSpMM_u_e / GSpMM_u):
  *   C[r,:] = reduce_p compute(val[p], B[col[p],:]),  compute_op: 0 ADD a+b, 1 SUB b-a, 2 MUL a*b, 3 DIV b/a
  * (enum COMPUTEOP, src/gspmm-fp/gspmm.h:16); val == NULL means weight 1 (GSpMM_u).  No arg output.  MUL+sum/mean runs

@@ -45,6 +45,31 @@ def test_forward_backward_like_reference_tests(name, reduce):
     assert_close(dcsr.storage._values.grad.cpu().numpy(), g[f'{reduce}_dA'], RTOL, ATOL, 'dA')
 
 
+def test_max_backward_single_pass_and_deterministic_mode():
+    """spmm_max/min backward: by default one pass over the arg ids with fp32 atomics (csrc/arg_backward.hip); under
+    torch.use_deterministic_algorithms(True) the two masked kernels, which are bit-reproducible.  Both agree with the
+    golden gradients."""
+    import dgsparse
+    g = load_golden('powerlaw4k_signed_grad_N8')
+    G = torch.from_numpy(g['G']).cuda()
+    grads = {}
+    for det in (False, True):
+        torch.use_deterministic_algorithms(det)
+        try:
+            runs = []
+            for _ in range(2):
+                dcsr, X = make(g)
+                dgsparse.spmm_max(dcsr, X, 0).backward(G)
+                runs.append((X.grad.clone(), dcsr.storage._values.grad.clone()))
+        finally:
+            torch.use_deterministic_algorithms(False)
+        grads[det] = runs
+        assert_close(runs[0][0].cpu().numpy(), g['max_dX'], RTOL, ATOL, f'dX deterministic={det}')
+        assert_close(runs[0][1].cpu().numpy(), g['max_dA'], RTOL, ATOL, f'dA deterministic={det}')
+    assert torch.equal(grads[True][0][0], grads[True][1][0]) and torch.equal(grads[True][0][1], grads[True][1][1])
+    assert torch.allclose(grads[True][0][0], grads[False][0][0], rtol=1e-5, atol=2e-6)
+
+
 def test_algorithm_is_a_hint_and_has_value_false():
     import dgsparse
     g = load_golden('cora_shaped_N32')

@@ -477,3 +477,37 @@ def test_min_max_nan_products_on_split_rows(capi, N, big):
     assert_bitexact(C, Co, 'min values (NaN, no edge values)')
     assert_bitexact(E, Eo, 'min E (NaN, no edge values)')
 
+
+@pytest.mark.parametrize('N', [1, 7, 32, 64, 100, 256, 300])
+def test_arg_backward_single_pass(capi, N):
+    """dgs_spmm_arg_backward_f32: both gradients of max/min from the forward's arg ids in one pass (scatter with M*N
+    sources, fp32 atomics) against the oracle's masked SpMM / masked SDDMM - with duplicate columns (every duplicate
+    of the arg column contributes), unsorted rows, empty rows, hub rows and hub columns, and without edge values."""
+    M, K = 3000, 700
+    rp, col, st = graphgen.powerlaw_csr(M, 60000, K=K, alpha=1.8, dmax=2500, seed=200 + N, dedup=False)
+    rng = np.random.default_rng(N)
+    for r in rng.integers(0, M, 50):
+        rng.shuffle(col[rp[r]:rp[r + 1]])
+    val = graphgen.weights(col.shape[0], 'signed', N)
+    X = (rng.integers(-3, 4, (K, N)) / 4).astype(np.float32)   # many ties
+    G = (rng.random((M, N), dtype=np.float32) - 0.5).astype(np.float32)
+    colptr, row, tval, perm = oracle.csr2csc(rp, col, val, K)
+    for reduce in ('max', 'min'):
+        for v in (val, None):
+            _, E = oracle.spmm(reduce, rp, col, v, X)
+            gX, gW = capi.spmm_arg_backward(dev(rp), dev(col), None if v is None else dev(v), dev(E), dev(G), dev(X))
+            tv = tval if v is not None else np.ones_like(tval)
+            refX = oracle.spmm_mask(colptr, row, tv, G, E, fma=True)
+            lens = np.diff(colptr)
+            assert_sum_parity(gX.cpu().numpy(), refX, oracle.spmm_mask_f64(colptr, row, tv, G, E),
+                              oracle.spmm_mask_f64(colptr, row, tv, G, E, absval=True), RTOL, ATOL, 'gX', lens=lens)
+            if v is not None:
+                assert_close(gW.cpu().numpy(), oracle.sddmm_mask(rp, col, G, X, E, fma=True), RTOL, ATOL, 'gW')
+            else:
+                assert gW is None
+    # only one of the two outputs
+    _, E = oracle.spmm('max', rp, col, val, X)
+    gX, gW = capi.spmm_arg_backward(dev(rp), dev(col), dev(val), dev(E), dev(G), dev(X), need_dense=False)
+    assert gX is None
+    assert_close(gW.cpu().numpy(), oracle.sddmm_mask(rp, col, G, X, E, fma=True), RTOL, ATOL, 'gW only')
+
