@@ -73,6 +73,15 @@ def one_case(rng, it):
         assert_sum_parity(gX, ref, oracle.spmm_mask_f64(colptr, row, tval, D1, Emax),
                           oracle.spmm_mask_f64(colptr, row, tval, D1, Emax, absval=True), 1e-5, 2e-6, tag + ' spmm_mask',
                           lens=np.diff(colptr))
+        # the single-pass backward (scatter over the arg ids) must give the same two gradients
+        aX, aW = capi.spmm_arg_backward(drp, dcol, dval, dev(Emax), dD1, dX)
+        tv = tval if val is not None else np.ones_like(tval)
+        assert_sum_parity(aX.cpu().numpy(), ref, oracle.spmm_mask_f64(colptr, row, tv, D1, Emax),
+                          oracle.spmm_mask_f64(colptr, row, tv, D1, Emax, absval=True), 1e-5, 2e-6,
+                          tag + ' arg_backward gX', lens=np.diff(colptr))
+        if val is not None:
+            assert_close(aW.cpu().numpy(), oracle.sddmm_mask(rp, col, D1, X, Emax, fma=True), 1e-5, 1e-5,
+                         tag + ' arg_backward gW')
     return tag
 
 
