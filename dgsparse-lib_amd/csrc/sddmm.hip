@@ -413,6 +413,12 @@ static int run_sddmm(int64_t M, int64_t K, int64_t F, int64_t nnz, const int *ro
 
 using namespace dgs;
 
+extern "C" int dgs_sddmm_csr_schedule(int64_t M, int64_t K, int64_t F, int64_t nnz, int masked) {
+  if (M <= 0 || K <= 0 || F <= 0 || nnz <= 0) return DGS_SCHED_ROWS;
+  const FeatMap fm = feat_map(F, true);
+  return sd_panel_plan(M, K, F, nnz, fm.tiles, fm.G, fm.V, masked != 0).use ? DGS_SCHED_PANEL : DGS_SCHED_ROWS;
+}
+
 extern "C" int dgs_sddmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t F, int64_t nnz, const int32_t *rowptr,
                                  const int32_t *col, const float *D1, const float *D2, float *out,
                                  dgsStream_t stream) {

@@ -58,6 +58,15 @@ std::vector<Tensor> spmm_fwd(int op, const Tensor &rowptr_, const Tensor &col_, 
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(dense.device());
   const int64_t M = rowptr.numel() - 1, nnz = col.numel(), K = dense.size(0), N = dense.size(1);
   TORCH_CHECK(M >= 0, "dgsparse: rowptr must have at least one element");
+  if (N % 4 && N > 4 && dgs_spmm_csr_schedule(op, M, K, (N + 3) & ~int64_t(3), nnz) == DGS_SCHED_PANEL) {
+    // dense graph, feature width not a multiple of 4 (e.g. 41 classes): the column-panel schedule needs 16-byte lane
+    // vectors, and two small copies buy it.  Feature columns are independent chains: the visible ones are unchanged.
+    const Tensor padded = at::constant_pad_nd(dense, {0, ((N + 3) & ~int64_t(3)) - N}, 0);
+    auto r = spmm_fwd(op, rowptr, col, values, padded, has_value, algorithm);
+    r[0] = r[0].narrow(1, 0, N).contiguous();
+    if (r[1].defined()) r[1] = r[1].narrow(1, 0, N).contiguous();
+    return r;
+  }
   Tensor vkeep;
   const float *vptr = opt_values(values, has_value, nnz, vkeep);
   Tensor out = at::empty({M, N}, dense.options());
@@ -77,6 +86,13 @@ Tensor sddmm_impl(const Tensor &rowptr_, const Tensor &col_, const Tensor &D1_, 
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(D1.device());
   const int64_t M = rowptr.numel() - 1, nnz = col.numel(), F = D1.size(1);
   TORCH_CHECK(D2.size(1) == F && D1.size(0) >= M, "dgsparse: sddmm shape mismatch");
+  if (F % 4 && F > 4 &&
+      dgs_sddmm_csr_schedule(M, D2.size(0), (F + 3) & ~int64_t(3), nnz, E.defined() ? 1 : 0) == DGS_SCHED_PANEL) {
+    // same trick as in spmm_fwd: zero feature columns add exact zeros to every dot product
+    const int64_t pad = ((F + 3) & ~int64_t(3)) - F;
+    Tensor Ep = E.defined() ? at::constant_pad_nd(E, {0, pad}, -1) : Tensor();
+    return sddmm_impl(rowptr, col, at::constant_pad_nd(D1, {0, pad}, 0), at::constant_pad_nd(D2, {0, pad}, 0), op, Ep);
+  }
   Tensor out = at::empty({nnz}, D1.options());
   if (E.defined()) {
     TORCH_CHECK(E.scalar_type() == at::kInt && E.sizes() == D1.sizes(), "dgsparse: E must be int32 with the shape of D1");

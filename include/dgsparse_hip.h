@@ -101,6 +101,11 @@ int dgs_sddmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t F, int64_t nn
                       const int32_t *rowptr, const int32_t *col, const float *D1, const float *D2,
                       float *out, dgsStream_t stream);
 
+/* Which schedule dgs_sddmm_csr_f32 / dgs_sddmm_csr_mask_f32 (masked != 0) take for these sizes with 16-byte aligned
+ * operands: DGS_SCHED_ROWS (nnz-balanced kernel) or DGS_SCHED_PANEL (column-panel sweep, dense graphs).  Introspection,
+ * no reference counterpart; see dgs_spmm_csr_schedule. */
+int dgs_sddmm_csr_schedule(int64_t M, int64_t K, int64_t F, int64_t nnz, int masked);
+
 /*
  * Masked SDDMM = backward of max/min w.r.t. the sparse values:
  *   out[e] = sum_k [E[row(e),k] == col(e)] * D1[row(e),k] * D2[col(e),k]

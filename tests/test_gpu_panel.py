@@ -292,3 +292,32 @@ def test_panel_autograd_through_the_public_ops(monkeypatch, reduce):
     np.testing.assert_allclose(Xt.grad.cpu().numpy(), dX, rtol=1e-5, atol=4e-6, err_msg='dX')
     np.testing.assert_allclose(A.storage._values.grad.cpu().numpy().ravel(), dA, rtol=1e-5, atol=4e-6, err_msg='dA')
 
+
+@pytest.mark.parametrize('N', [41, 121])
+def test_panel_odd_feature_width_is_padded(capi, monkeypatch, N):
+    """A feature width that is not a multiple of 4 cannot use 16-byte lane vectors; when the padded width would take the
+    panel schedule the bindings pad the dense operand with zero columns and slice the result.  Feature columns are
+    independent chains, so max/min stay bit-exact and sum matches the sequential oracle on panel-owned rows."""
+    for k in ('DGS_PANEL', 'DGS_PANEL_KB', 'DGS_PANEL_LEAD', 'DGS_PANEL_TLONG'):
+        monkeypatch.delenv(k, raising=False)
+    M = K = 40_000 if N > 100 else 100_000   # the dense operand must exceed 16 MB for the panel schedule
+    rp, col = dense_graph(M, K, 150, 400, seed=300 + N, dup=True)
+    assert capi.spmm_schedule(oracle.REDUCE['sum'], M, K, N, col.size) == 'rows'
+    assert capi.spmm_schedule(oracle.REDUCE['sum'], M, K, (N + 3) & ~3, col.size) == 'panel'
+    rng = np.random.default_rng(301)
+    val = rng.random(col.size, dtype=np.float32)
+    X = (rng.random((K, N), dtype=np.float32) - 0.5).astype(np.float32)
+    for reduce in ('sum', 'max'):
+        C, E = run(capi, reduce, rp, col, val, X)
+        Co, Eo = oracle.spmm(reduce, rp, col, val, X, fma=True)
+        assert C.shape == (M, N)
+        assert_bitexact(C, Co, f'{reduce} (padded to a multiple of 4)')
+        if reduce == 'max':
+            assert_bitexact(E, Eo, 'E')
+    D1 = (rng.random((M, N), dtype=np.float32) - 0.5).astype(np.float32)
+    got = capi.sddmm(dev(rp), dev(col), dev(D1), dev(X)).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.sddmm(rp, col, D1, X, 'sum', fma=True), rtol=1e-5, atol=2e-6)
+    _, Eo = oracle.spmm('max', rp, col, val, X)
+    got = capi.sddmm(dev(rp), dev(col), dev(D1), dev(X), E=dev(Eo)).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.sddmm_mask(rp, col, D1, X, Eo, fma=True), rtol=1e-5, atol=2e-6)
+
