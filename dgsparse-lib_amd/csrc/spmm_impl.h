@@ -856,28 +856,29 @@ static inline int env_int(const char *k, int dflt) {
 static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
   PanelPlan P{};
   const int force = env_int("DGS_PANEL", -1);
-  if (force == 0 || !a.ws || tiles != 1 || G < 8 || a.N % 4 || a.M <= 0) return P;
+  if (force == 0 || !a.ws || (tiles != 1 && G != 64) || G < 8 || a.N % 4 || a.M <= 0) return P;
   P.nwg = cu_count();
   const bool arg = (a.reduce_op == DGS_MAX || a.reduce_op == DGS_MIN);
-  int slots = (int)(kPanelAccBytes / (a.N * (arg ? 8 : 4)));
+  const int64_t W = a.N < 256 ? a.N : 256;  // feature tile per launch (wider operands: one sweep per 256 features)
+  int slots = (int)(kPanelAccBytes / (W * (arg ? 8 : 4)));
   if (slots > kPanelRMax) slots = kPanelRMax;
   if (slots < 8) return P;
   // Worth it when (a) the dense operand overflows the L2s and (b) an XCD's 32 workgroups touch every panel row
   // several times per sweep: reuse = (rows resident per XCD) * (nnz per row) / K.  Measured crossover ~6 (N = 128).
-  const double bbytes = (double)a.K * a.N * 4.0;
+  const double bbytes = (double)a.K * W * 4.0;
   const double reuse = (P.nwg / 8.0) * slots * ((double)a.nnz / (double)a.M) / (double)(a.K > 0 ? a.K : 1);
   if (force != 1 && !(bbytes >= 16e6 && reuse >= 8.0 && a.M >= 4096)) return P;
   P.nsb = (int)((a.M + (int64_t)P.nwg * slots - 1) / ((int64_t)P.nwg * slots));
   P.R = (int)((a.M + (int64_t)P.nwg * P.nsb - 1) / ((int64_t)P.nwg * P.nsb));
   const int64_t pbytes = (int64_t)env_int("DGS_PANEL_KB", 6144) * 1024;
-  int64_t pc = pbytes / (a.N * (a.reduce_op == kOpMaskSum ? 8 : 4));  // masked sum gathers grad AND arg-id rows
+  int64_t pc = pbytes / (W * (a.reduce_op == kOpMaskSum ? 8 : 4));  // masked sum gathers grad AND arg-id rows
   if (pc < 64) pc = 64;
   P.pcols = (int)pc;
   P.npanels = (int)((a.K + pc - 1) / pc);
   if (P.npanels < 1) P.npanels = 1;
   P.lead = env_int("DGS_PANEL_LEAD", 1);
   P.tlong = env_int("DGS_PANEL_TLONG", 4096);
-  P.lds = (size_t)P.R * a.N * (arg ? 8 : 4);
+  P.lds = (size_t)P.R * W * (arg ? 8 : 4);
   P.use = true;
   return P;
 }
@@ -909,14 +910,18 @@ static int launch_all(const SpmmArgs &a) {
           return DGS_ELAUNCH;
         attr_set[dev_id] = true;
       }
-      hipLaunchKernelGGL(kern, dim3((unsigned)P.nwg), dim3(kPanelBlock), P.lds, a.st, (int)a.M,
-                         (int)a.N, P.R, tl, P.pcols, P.npanels, P.nsb, P.lead, a.rowptr, a.col, a.val, a.B, a.C,
-                         a.E, &hdr->arrivals);
+      for (int64_t fb = 0; fb < a.N; fb += 256) {  // one sweep per 256-feature tile, counter re-zeroed in between
+        const int W = (int)(a.N - fb < 256 ? a.N - fb : 256);
+        if (fb && hipMemsetAsync(&hdr->arrivals, 0, sizeof(int), a.st) != hipSuccess) return DGS_ELAUNCH;
+        hipLaunchKernelGGL(kern, dim3((unsigned)P.nwg), dim3(kPanelBlock), P.lds, a.st, (int)a.M, W, (int)a.N, P.R, tl,
+                           P.pcols, P.npanels, P.nsb, P.lead, a.rowptr, a.col, a.val, a.B + fb, a.C + fb,
+                           a.E ? a.E + fb : nullptr, &hdr->arrivals);
+      }
       const int nbu = 1024;
-      hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)nbu, 1), dim3(kBlock), 0, a.st, (int)a.M,
+      hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)nbu, (unsigned)a.tiles), dim3(kBlock), 0, a.st, (int)a.M,
                          (int)a.N, L.ch, nbu, a.rowptr, a.col, a.val, a.B, a.C, a.E, hdr, units, part, parte);
       const int64_t cb = (L.max_units + 255) / 256;
-      const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), 1);
+      const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
       hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B,
                          a.C, a.E, hdr, units, part, parte);
       return check_launch();

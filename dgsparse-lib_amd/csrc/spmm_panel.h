@@ -52,11 +52,14 @@ struct PanelLds {  // the small arrays; the accumulators follow in dynamic LDS
   int *deg, *order, *cur, *rend, *nextc;
 };
 
+// N is the width of the feature tile this launch covers (<= 256, the LDS row length); ld is the row stride of B, C
+// and E in memory (the full feature count: wider operands are swept one 256-feature tile per launch, with the
+// pointers advanced by the caller).
 // One visit: fold the in-panel prefix of the chunk (c,w) loaded at cur[r] into acc[r].  Masked sum (kOpMaskSum: Em =
 // saved arg ids, orow = this output row) gathers the arg-id row next to the grad row and gates the fma.  Groups without a row pass
 // r = -1 and c = INT_MAX everywhere (cnt = 0).  All 64 lanes must call it together.
 template <int G, int OP, bool HAS_VAL>
-__device__ __forceinline__ void panel_visit(int r, int c, float w, int pend, int N, int lig, int gbase, int f0,
+__device__ __forceinline__ void panel_visit(int r, int c, float w, int pend, int N, int ld, int lig, int gbase, int f0,
                                             bool active, uint64_t gmask, const PanelLds &L, float *acc, int *acce,
                                             const int *__restrict__ col, const float *__restrict__ val,
                                             const float *__restrict__ B, const int *__restrict__ Em, int orow) {
@@ -94,8 +97,8 @@ __device__ __forceinline__ void panel_visit(int r, int c, float w, int pend, int
         if constexpr (HAS_VAL) wj[u] = __shfl(w, src);
         else wj[u] = 1.f;
         if (j + u < cnt && active) {
-          load_vec<V>(B + (int64_t)cj[u] * N + f0, x[u]);
-          if constexpr (OP == kOpMaskSum) load_vec<V>(Em + (int64_t)cj[u] * N + f0, mk[u]);
+          load_vec<V>(B + (int64_t)cj[u] * ld + f0, x[u]);
+          if constexpr (OP == kOpMaskSum) load_vec<V>(Em + (int64_t)cj[u] * ld + f0, mk[u]);
         } else if constexpr (!ARG) {  // sum: a padded step is fma(0, 0, a) = a
           wj[u] = 0.f;
 #pragma unroll
@@ -145,7 +148,7 @@ __device__ __forceinline__ void panel_visit(int r, int c, float w, int pend, int
 }
 
 template <int G, int OP, bool HAS_VAL>
-__global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int R, int tlong, int pcols, int npanels,
+__global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int ld, int R, int tlong, int pcols, int npanels,
                                                           int nsb, int lead, const int *__restrict__ rowptr,
                                                           const int *__restrict__ col, const float *__restrict__ val,
                                                           const float *__restrict__ B, float *__restrict__ C,
@@ -248,11 +251,11 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int R, i
       grab(r0, c0, w0);
       for (;;) {
         grab(r1, c1, w1);
-        panel_visit<G, OP, HAS_VAL>(r0, c0, w0, pend, N, lig, gbase, f0, active, gmask, L, acc, acce, col, val, B, E,
+        panel_visit<G, OP, HAS_VAL>(r0, c0, w0, pend, N, ld, lig, gbase, f0, active, gmask, L, acc, acce, col, val, B, E,
                                     (int)row0 + r0);
         if (!__any(r1 >= 0)) break;
         grab(r0, c0, w0);
-        panel_visit<G, OP, HAS_VAL>(r1, c1, w1, pend, N, lig, gbase, f0, active, gmask, L, acc, acce, col, val, B, E,
+        panel_visit<G, OP, HAS_VAL>(r1, c1, w1, pend, N, ld, lig, gbase, f0, active, gmask, L, acc, acce, col, val, B, E,
                                     (int)row0 + r1);
         if (!__any(r0 >= 0)) break;
       }
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int R, i
 #pragma unroll
             for (int v = 0; v < V; v++) o[v] = 0.f;
           }
-          store_vec_stream<V>(E + row * N + (int64_t)(i - r * n4) * V, oe);
+          store_vec_stream<V>(E + row * ld + (int64_t)(i - r * n4) * V, oe);
         }
         if constexpr (OP == DGS_MEAN) {
           const int dg = s_deg[r];
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int R, i
             for (int v = 0; v < V; v++) o[v] /= d;
           }
         }
-        store_vec_stream<V>(C + row * N + (int64_t)(i - r * n4) * V, o);
+        store_vec_stream<V>(C + row * ld + (int64_t)(i - r * n4) * V, o);
       }
     }
   }

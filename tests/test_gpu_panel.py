@@ -86,7 +86,7 @@ def check(capi, monkeypatch, reduce, rp, col, val, X, tlong, kb=4, lead=1, cross
 
 
 @pytest.mark.parametrize('reduce', ['sum', 'mean', 'max', 'min'])
-@pytest.mark.parametrize('N', [32, 64, 96, 128, 256])
+@pytest.mark.parametrize('N', [32, 64, 96, 128, 256, 260, 320, 512])  # > 256: one sweep per 256-feature tile
 def test_panel_widths(capi, monkeypatch, reduce, N):
     M, K = 5000, 3000
     rp, col = dense_graph(M, K, 20, 120, seed=N, empty_every=97)
