@@ -334,24 +334,25 @@ struct SdPanelPlan {
 static SdPanelPlan sd_panel_plan(int64_t M, int64_t K, int64_t F, int64_t nnz, int tiles, int G, int V, bool mask) {
   SdPanelPlan P{};
   const int force = sd_env_int("DGS_PANEL", -1);
-  if (force == 0 || tiles != 1 || V != 4 || G < 8 || M <= 0 || K <= 0) return P;
+  if (force == 0 || (tiles != 1 && G != 64) || V != 4 || G < 8 || M <= 0 || K <= 0) return P;
   P.nwg = sd_cu_count();
-  int slots = (int)(kSdPanelBytes / (F * (mask ? 8 : 4)));
+  const int64_t W = F < 256 ? F : 256;  // feature tile per launch
+  int slots = (int)(kSdPanelBytes / (W * (mask ? 8 : 4)));
   if (slots > kPanelRMax) slots = kPanelRMax;
   if (slots < 8) return P;
   // same rule as the SpMM twin: D2 must overflow the L2s and every panel row must be reused several times per XCD
   const double reuse = (P.nwg / 8.0) * slots * ((double)nnz / (double)M) / (double)K;
-  if (force != 1 && !((double)K * F * 4.0 >= 16e6 && reuse >= 8.0 && M >= 4096)) return P;
+  if (force != 1 && !((double)K * W * 4.0 >= 16e6 && reuse >= 8.0 && M >= 4096)) return P;
   P.nsb = (int)((M + (int64_t)P.nwg * slots - 1) / ((int64_t)P.nwg * slots));
   P.R = (int)((M + (int64_t)P.nwg * P.nsb - 1) / ((int64_t)P.nwg * P.nsb));
-  int64_t pc = (int64_t)sd_env_int("DGS_PANEL_KB", 6144) * 1024 / (F * 4);
+  int64_t pc = (int64_t)sd_env_int("DGS_PANEL_KB", 6144) * 1024 / (W * 4);
   if (pc < 64) pc = 64;
   P.pcols = (int)pc;
   P.npanels = (int)((K + pc - 1) / pc);
   P.lead = sd_env_int("DGS_PANEL_LEAD", 1);
   P.tlong = sd_env_int("DGS_PANEL_TLONG", 2048);
   if (P.tlong < 1) P.tlong = 1;
-  P.lds = (size_t)P.R * F * (mask ? 8 : 4);
+  P.lds = (size_t)P.R * W * (mask ? 8 : 4);
   P.use = true;
   return P;
 }
@@ -372,12 +373,17 @@ static int launch_sddmm_panel(const SdPanelPlan &P, int64_t M, int64_t F, const 
   int *arrivals = nullptr;
   if (hipGetSymbolAddress(reinterpret_cast<void **>(&arrivals), HIP_SYMBOL(g_sddmm_arrivals)) != hipSuccess)
     return DGS_ELAUNCH;
-  if (hipMemsetAsync(arrivals, 0, sizeof(int), st) != hipSuccess) return DGS_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3((unsigned)P.nwg), dim3(kPanelBlock), P.lds, st, (int)M, (int)F, P.R, P.tlong, P.pcols,
-                     P.npanels, P.nsb, P.lead, rowptr, col, D1, D2, E, out, arrivals);
+  for (int64_t fb = 0; fb < F; fb += 256) {  // one sweep per 256-feature tile; later tiles add to out[]
+    const int W = (int)(F - fb < 256 ? F - fb : 256);
+    const int pass = (fb ? 1 : 0) | (fb + 256 >= F ? 2 : 0);
+    if (hipMemsetAsync(arrivals, 0, sizeof(int), st) != hipSuccess) return DGS_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)P.nwg), dim3(kPanelBlock), P.lds, st, (int)M, W, (int)F, pass, P.R, P.tlong,
+                       P.pcols, P.npanels, P.nsb, P.lead, rowptr, col, D1 + fb, D2 + fb, E ? E + fb : nullptr, out,
+                       arrivals);
+  }
   // rows longer than tlong: row-driven kernel, the 16 waves of a block share the tiles of each long row
   hipLaunchKernelGGL((sddmm_longrows<G, 4, MEAN, MASK>), dim3((unsigned)((M + kWave - 1) / kWave)), dim3(kLongBlock), 0, st,
-                     (int)M, (int)F, 1, P.tlong, rowptr, col, D1, D2, E, out);
+                     (int)M, (int)F, (int)((F + 255) / 256), P.tlong, rowptr, col, D1, D2, E, out);
   return check_launch();
 }
 

@@ -15,6 +15,7 @@
 //   reduce the 8 partial sums over the G lanes with a transposing butterfly (8+log2(G)-3 shuffles instead of
 //   8*log2(G)) and store the 8 results; then advance the cursor.
 //   soft barrier between panels exactly as in spmm_panel.h.
+// F is the width of the feature tile of this launch (<= 256, the LDS row length), ld the row stride of D1, D2 and E.
 #pragma once
 #include "dgs_common.h"
 #include "spmm_panel.h"
@@ -28,7 +29,8 @@ constexpr int kSdPU = 8;                       // D2-row gathers in flight per l
 __device__ int g_sddmm_arrivals;  // soft-barrier counter (zeroed by a memset node before every launch)
 
 template <int G, bool MEAN, bool MASK>
-__global__ __launch_bounds__(kPanelBlock) void sddmm_panel(int M, int F, int R, int tlong, int pcols, int npanels,
+__global__ __launch_bounds__(kPanelBlock) void sddmm_panel(int M, int F, int ld, int pass, int R, int tlong, int pcols,
+                                                           int npanels,
                                                            int nsb, int lead, const int *__restrict__ rowptr,
                                                            const int *__restrict__ col, const float *__restrict__ D1,
                                                            const float *__restrict__ D2, const int *__restrict__ E,
@@ -63,8 +65,8 @@ __global__ __launch_bounds__(kPanelBlock) void sddmm_panel(int M, int F, int R, 
       float4 t = make_float4(0, 0, 0, 0);
       int4 te = make_int4(-1, -1, -1, -1);
       if (row < M) {
-        t = *reinterpret_cast<const float4 *>(D1 + row * F + (int64_t)(i - r * n4) * V);
-        if constexpr (MASK) te = *reinterpret_cast<const int4 *>(E + row * F + (int64_t)(i - r * n4) * V);
+        t = *reinterpret_cast<const float4 *>(D1 + row * ld + (int64_t)(i - r * n4) * V);
+        if constexpr (MASK) te = *reinterpret_cast<const int4 *>(E + row * ld + (int64_t)(i - r * n4) * V);
       }
       reinterpret_cast<float4 *>(d1)[i] = t;
       if constexpr (MASK) reinterpret_cast<int4 *>(em)[i] = te;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(kPanelBlock) void sddmm_panel(int M, int F, int R, 
             for (int u = 0; u < kSdPU; u++) {
               cj[u] = __shfl(c, gbase + ((j + u) & (G - 1)));
               if (j + u < cnt && active) {
-                load_vec<V>(D2 + (int64_t)cj[u] * F + f0, x[u]);
+                load_vec<V>(D2 + (int64_t)cj[u] * ld + f0, x[u]);
               } else {
 #pragma unroll
                 for (int v = 0; v < V; v++) x[u][v] = 0.f;
@@ -217,7 +219,12 @@ __global__ __launch_bounds__(kPanelBlock) void sddmm_panel(int M, int F, int R, 
 #pragma unroll
             for (int m = 8; m < G; m <<= 1) tot += __shfl_xor(tot, m, 64);
             if (lig < 8 && j + bidx < cnt) {
-              if constexpr (MEAN) tot /= (float)dg;
+              // operands wider than 256 features are swept one tile per launch: pass bit 0 = add to the partial sum
+              // of the earlier tiles, bit 1 = last tile (the MEAN division happens once, on the full dot product)
+              if (pass & 1) tot += out[pos + j + bidx];
+              if constexpr (MEAN) {
+                if (pass & 2) tot /= (float)dg;
+              }
               // uncounted store (dgs_common.h): a counted one would make hipcc drain vmcnt(0) - and with it the chunk
               // prefetch and the next batch of gathers - at every batch
               const float o1[1] = {tot};

@@ -215,7 +215,7 @@ def test_panel_masked_sum_for_max_min_backward(capi, monkeypatch, N):
         np.testing.assert_allclose(gX, g0, rtol=2e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize('F', [32, 64, 96, 128, 256])
+@pytest.mark.parametrize('F', [32, 64, 96, 128, 256, 260, 320, 512])  # > 256: one sweep per 256-feature tile
 def test_panel_sddmm(capi, monkeypatch, F):
     """Column-panel SDDMM (csrc/sddmm_panel.h) forced on a small input: D1 rows in LDS, D2 swept in panels, long rows
     cut into segments, every nnz written exactly once; sum, mean and the arg-masked variant against the oracle and
@@ -238,9 +238,10 @@ def test_panel_sddmm(capi, monkeypatch, F):
                           capi.sddmm(dev(rp), dev(col), dev(D1), dev(D2), E=dev(E)).cpu().numpy())
         ref = (oracle.sddmm(rp, col, D1, D2, 'sum', fma=True), oracle.sddmm(rp, col, D1, D2, 'mean', fma=True),
                oracle.sddmm_mask(rp, col, D1, D2, E, fma=True))
+        atol = 2e-6 * max(1.0, F / 128)  # dot products of F signed terms around zero: the absolute error grows with F
         for k, what in enumerate(('sum', 'mean', 'masked')):
-            np.testing.assert_allclose(res['1'][k], ref[k], rtol=1e-5, atol=2e-6, err_msg=f'panel sddmm {what}')
-            np.testing.assert_allclose(res['1'][k], res['0'][k], rtol=1e-5, atol=2e-6, err_msg=f'panel vs nnzbal {what}')
+            np.testing.assert_allclose(res['1'][k], ref[k], rtol=1e-5, atol=atol, err_msg=f'panel sddmm {what}')
+            np.testing.assert_allclose(res['1'][k], res['0'][k], rtol=1e-5, atol=atol, err_msg=f'panel vs nnzbal {what}')
 
 
 def test_panel_sddmm_unsorted_many_superblocks(capi, monkeypatch):
