@@ -70,6 +70,37 @@ def test_max_backward_single_pass_and_deterministic_mode():
     assert torch.allclose(grads[True][0][0], grads[False][0][0], rtol=1e-5, atol=2e-6)
 
 
+def test_permuted_values_cache_tracks_in_place_updates():
+    """The backward keeps the last `values[csr2csc]`; an in-place update of the edge values (what an optimizer step does)
+    must be seen by the next backward, and a different tensor at a recycled address must never alias."""
+    import dgsparse
+    g = load_golden('small_weighted_N64')
+    G = torch.from_numpy(g['G']).cuda() if 'G' in g else None
+    dcsr, X = make(g)
+    if G is None:
+        G = torch.rand(g['rowptr'].shape[0] - 1, X.shape[1], device='cuda')
+
+    def dX():
+        X.grad = None
+        dgsparse.spmm_sum(dcsr, X, 0).backward(G)
+        return X.grad.clone()
+
+    first = dX()
+    assert torch.equal(first, dX())  # second call may hit the cache: identical
+    with torch.no_grad():
+        dcsr.storage._values.mul_(2.0)  # in place: same tensor object, version counter bumped
+    assert torch.allclose(dX(), 2.0 * first, rtol=1e-6, atol=0)
+    # a fresh values tensor (possibly at the same address) with the same version must not hit
+    for scale in (3.0, 5.0):
+        d2, _ = make(g)
+        with torch.no_grad():
+            d2.storage._values.copy_(torch.from_numpy(g['val']).cuda().view_as(d2.storage._values) * scale)
+        X.grad = None
+        dgsparse.spmm_sum(d2, X, 0).backward(G)
+        assert torch.allclose(X.grad, scale * first, rtol=1e-6, atol=1e-6)
+        del d2
+
+
 def test_algorithm_is_a_hint_and_has_value_false():
     import dgsparse
     g = load_golden('cora_shaped_N32')
