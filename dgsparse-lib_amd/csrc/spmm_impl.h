@@ -39,6 +39,11 @@
 //   reads at a ~30% L2 hit rate on the 1M x 1M power-law graph); see DESIGN.md for the ladder that led here.
 //
 //   spmm_small: inputs up to 2^18 nnz / 2^16 rows take ONE launch (row blocks only, long rows reduced in place).
+//
+//   spmm_panel (spmm_panel.h): dense graphs whose dense operand overflows the L2s take a column-panel sweep with the
+//   accumulators resident in LDS instead of K1's row blocks (panel_plan() below decides; rows longer than 4096 nnz
+//   still go through K0 -> unit blocks -> K2).  MIN over NaN products is order-dependent: the split paths detect it
+//   and redo the affected elements sequentially (seq_redo).
 #pragma once
 #include <stdlib.h>
 
