@@ -47,6 +47,7 @@ def main():
         ('C2 arxiv-shaped SpMM-sum', 'arxiv', 'sum', 64),
         ('C3 reddit-shaped SpMM-sum', 'reddit', 'sum', 128),
         ('C3 reddit-shaped SpMM-max', 'reddit', 'max', 128),
+        ('C3 reddit-shaped SDDMM', 'reddit', 'sddmm', 64),
         ('C4 products-shaped SDDMM', 'products', 'sddmm', 64),
         ('NS synth-1M SpMM-sum', 'synth1m', 'sum', 32),
         ('NS synth-1M SpMM-sum', 'synth1m', 'sum', 64),
