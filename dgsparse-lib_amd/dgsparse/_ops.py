@@ -13,6 +13,7 @@ An extra op ``dgsparse_spmm::sddmm`` exposes SDDMM directly (SURVEY.md R3).
 """
 import importlib.machinery
 import os
+import weakref
 
 import torch
 
@@ -30,13 +31,27 @@ if _spec is not None and os.environ.get('DGSPARSE_PY_BINDING', '0') != '1':
     NATIVE_BINDING = True
 
 
+_TV_CACHE = {}  # last `values[csr2csc]`: (weakref to the values tensor, its version, permutation address) -> tensor
+
+
 def _t_values(values, csr2csc, has_value):
+    """Edge values in CSC order.  The last result is kept (same rule as csrc/torch_binding.cpp: same tensor OBJECT via a
+    weak reference, unchanged version counter, same permutation; never while a stream is being captured), because all
+    layers that share an adjacency - and, with fixed weights, all iterations - ask for the same permuted values."""
     if not has_value:
         return None
-    if csr2csc.dtype == torch.int32 and csr2csc.is_cuda and values.dtype == torch.float32:
-        # one pass of the HIP gather over the int32 permutation (index_select wants an int64 copy first)
-        return _capi.gather_rows(values.detach().reshape(-1, 1), csr2csc).view(-1)
-    return values.view(-1).index_select(0, csr2csc.long() if csr2csc.dtype != torch.int64 else csr2csc)
+    if not (csr2csc.dtype == torch.int32 and csr2csc.is_cuda and values.dtype == torch.float32):
+        return values.view(-1).index_select(0, csr2csc.long() if csr2csc.dtype != torch.int64 else csr2csc)
+    capturing = torch.cuda.is_current_stream_capturing()
+    hit = _TV_CACHE.get('last')
+    if (not capturing and hit is not None and hit[0]() is values and hit[1] == values._version
+            and hit[2] == csr2csc.data_ptr() and hit[3].numel() == csr2csc.numel()):
+        return hit[3]
+    # one pass of the HIP gather over the int32 permutation (index_select wants an int64 copy first)
+    out = _capi.gather_rows(values.detach().reshape(-1, 1), csr2csc).view(-1)
+    if not capturing:
+        _TV_CACHE['last'] = (weakref.ref(values), values._version, csr2csc.data_ptr(), out)
+    return out
 
 
 def _pad_rows(g, n):
