@@ -865,7 +865,8 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
   P.nwg = cu_count();
   const bool arg = (a.reduce_op == DGS_MAX || a.reduce_op == DGS_MIN);
   const int64_t W = a.N < 256 ? a.N : 256;  // feature tile per launch (wider operands: one sweep per 256 features)
-  int slots = (int)(kPanelAccBytes / (W * (arg ? 8 : 4)));
+  const int ebytes = a.reduce_op == DGS_MAX ? 6 : (arg ? 8 : 4);  // fp32 value (+ 16-bit arg position | 32-bit arg id)
+  int slots = (int)(kPanelAccBytes / (W * ebytes)) & ~1;
   if (slots > kPanelRMax) slots = kPanelRMax;
   if (slots < 8) return P;
   // Worth it when (a) the dense operand overflows the L2s and (b) an XCD's 32 workgroups touch every panel row
@@ -883,7 +884,7 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
   if (P.npanels < 1) P.npanels = 1;
   P.lead = env_int("DGS_PANEL_LEAD", 1);
   P.tlong = env_int("DGS_PANEL_TLONG", 4096);
-  P.lds = (size_t)P.R * W * (arg ? 8 : 4);
+  P.lds = (size_t)P.R * W * ebytes;
   P.use = true;
   return P;
 }

@@ -9,7 +9,7 @@
 // of rows -- and the panel loop runs inside the kernel with the accumulators resident.
 //
 //   workgroup = 1024 threads = 16 waves, one workgroup per CU, owns R = 32768/N consecutive rows of the super-block:
-//     acc[R][N] fp32 in LDS (128 KiB; max/min: R = 16384/N rows of value + arg id),
+//     acc[R][N] fp32 in LDS (128 KiB; max: value + 16-bit arg position, R = 21845/N rows; min: + 32-bit arg id),
 //     cur[r] = cursor into the row's CSR segment, nextc[r] = column at the cursor
 //   for each panel p (columns < pend = (p+1)*pcols) the lane groups (G lanes x 4 floats = one row, as in the
 //   row-stream kernels) take row VISITS from an LDS counter, longest rows first:
@@ -44,12 +44,13 @@ constexpr int kPanelRMax = 1024;          // R <= 32768 / N <= 1024 (N >= 32)
 #endif
 constexpr int kPU = DGS_PU;  // B-row gathers in flight per lane inside a visit
 
+
 __device__ __forceinline__ int dev_load_relaxed(const int *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 struct PanelLds {  // the small arrays; the accumulators follow in dynamic LDS
-  int *deg, *order, *cur, *rend, *nextc;
+  int *deg, *order, *cur, *rend, *nextc, *rbeg;
 };
 
 // N is the width of the feature tile this launch covers (<= 256, the LDS row length); ld is the row stride of B, C
@@ -60,22 +61,37 @@ struct PanelLds {  // the small arrays; the accumulators follow in dynamic LDS
 // r = -1 and c = INT_MAX everywhere (cnt = 0).  All 64 lanes must call it together.
 template <int G, int OP, bool HAS_VAL>
 __device__ __forceinline__ void panel_visit(int r, int c, float w, int pend, int N, int ld, int lig, int gbase, int f0,
-                                            bool active, uint64_t gmask, const PanelLds &L, float *acc, int *acce,
+                                            bool active, uint64_t gmask, const PanelLds &L, float *acc, unsigned short *acce,
                                             const int *__restrict__ col, const float *__restrict__ val,
                                             const float *__restrict__ B, const int *__restrict__ Em, int orow) {
   constexpr int V = 4;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
+  constexpr int PU = kPU;
   const bool have = r >= 0;
   float a[V] = {0.f, 0.f, 0.f, 0.f};
-  int ae[V] = {-1, -1, -1, -1};
+  // max: the arg is kept as the POSITION of the winning nnz inside its row (16 bits: rows swept here have at most
+  // tlong < 65535 nnz; 0xFFFF = none yet), 6 bytes per element instead of 8, and becomes a column id at write-out.
+  // min keeps the 32-bit column id: its step holds two compare results per element and the 16-bit packing on top
+  // costs ~50 spilled VGPRs at the 128-register budget (measured: 4.1 -> 10 ms; fewer gathers in flight: 5.8-6.4 ms).
+  constexpr bool E16 = (OP == DGS_MAX);
+  int ae[V];
+#pragma unroll
+  for (int v = 0; v < V; v++) ae[v] = E16 ? 0xFFFF : -1;
   float4 *ap = reinterpret_cast<float4 *>(acc + (size_t)(have ? r : 0) * N + f0);
-  int4 *ep = reinterpret_cast<int4 *>(acce + (size_t)(have ? r : 0) * N + f0);
+  uint2 *ep = reinterpret_cast<uint2 *>(acce + (size_t)(have ? r : 0) * N + f0);
+  int4 *ep32 = reinterpret_cast<int4 *>(reinterpret_cast<int *>(acce) + (size_t)(have ? r : 0) * N + f0);
+  const int rb = (E16 && have) ? L.rbeg[r] : 0;
   if (have && active) {
     const float4 t = *ap;
     a[0] = t.x; a[1] = t.y; a[2] = t.z; a[3] = t.w;
     if constexpr (ARG) {
-      const int4 te = *ep;
-      ae[0] = te.x; ae[1] = te.y; ae[2] = te.z; ae[3] = te.w;
+      if constexpr (E16) {
+        const uint2 te = *ep;
+        ae[0] = te.x & 0xFFFF; ae[1] = te.x >> 16; ae[2] = te.y & 0xFFFF; ae[3] = te.y >> 16;
+      } else {
+        const int4 te = *ep32;
+        ae[0] = te.x; ae[1] = te.y; ae[2] = te.z; ae[3] = te.w;
+      }
     }
   }
   int pos = have ? L.cur[r] : 0;
@@ -85,13 +101,13 @@ __device__ __forceinline__ void panel_visit(int r, int c, float w, int pend, int
   do {
     const uint64_t bal = __ballot(c < pend);
     cnt = __popcll((bal >> gbase) & gmask);
-    for (int j = 0; __any(j < cnt); j += kPU) {
-      float x[kPU][V];
-      float wj[kPU];
-      int cj[kPU];
-      int mk[kPU][V];
+    for (int j = 0; __any(j < cnt); j += PU) {
+      float x[PU][V];
+      float wj[PU];
+      int cj[PU];
+      int mk[PU][V];
 #pragma unroll
-      for (int u = 0; u < kPU; u++) {
+      for (int u = 0; u < PU; u++) {
         const int src = gbase + ((j + u) & (G - 1));
         cj[u] = __shfl(c, src);
         if constexpr (HAS_VAL) wj[u] = __shfl(w, src);
@@ -106,11 +122,12 @@ __device__ __forceinline__ void panel_visit(int r, int c, float w, int pend, int
         }
       }
 #pragma unroll
-      for (int u = 0; u < kPU; u++) {
+      for (int u = 0; u < PU; u++) {
         if constexpr (ARG) {
           if (j + u < cnt && active) {
 #pragma unroll
-            for (int v = 0; v < V; v++) reduce_step<OP>(a[v], ae[v], wj[u], x[u][v], cj[u]);
+            for (int v = 0; v < V; v++)
+              reduce_step<OP>(a[v], ae[v], wj[u], x[u][v], E16 ? pos + j + u - rb : cj[u]);
           }
         } else if constexpr (OP == kOpMaskSum) {
           if (j + u < cnt && active) {
@@ -142,7 +159,8 @@ __device__ __forceinline__ void panel_visit(int r, int c, float w, int pend, int
     }
     if (active) {
       *ap = make_float4(a[0], a[1], a[2], a[3]);
-      if constexpr (ARG) *ep = make_int4(ae[0], ae[1], ae[2], ae[3]);
+      if constexpr (E16) *ep = make_uint2((unsigned)ae[0] | ((unsigned)ae[1] << 16), (unsigned)ae[2] | ((unsigned)ae[3] << 16));
+      else if constexpr (ARG) *ep32 = make_int4(ae[0], ae[1], ae[2], ae[3]);
     }
   }
 }
@@ -155,12 +173,13 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int ld, 
                                                           int *__restrict__ E, int *arrivals) {
   constexpr int V = 4;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
-  __shared__ int s_deg[kPanelRMax], s_order[kPanelRMax], s_cur[kPanelRMax], s_rend[kPanelRMax], s_nextc[kPanelRMax];
+  __shared__ int s_deg[kPanelRMax], s_order[kPanelRMax], s_cur[kPanelRMax], s_rend[kPanelRMax], s_nextc[kPanelRMax],
+      s_rbeg[kPanelRMax];
   __shared__ int s_ctr;
   extern __shared__ __align__(16) char panel_dyn[];
   float *acc = reinterpret_cast<float *>(panel_dyn);        // [R][N]
-  int *acce = reinterpret_cast<int *>(acc + (size_t)R * N);  // [R][N] arg ids (max/min only)
-  const PanelLds L{s_deg, s_order, s_cur, s_rend, s_nextc};
+  unsigned short *acce = reinterpret_cast<unsigned short *>(acc + (size_t)R * N);  // [R][N] arg positions (max/min)
+  const PanelLds L{s_deg, s_order, s_cur, s_rend, s_nextc, s_rbeg};
 
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int lig = lane & (G - 1), gbase = lane & ~(G - 1);
@@ -176,7 +195,8 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int ld, 
     for (int i = tid; i < R * n4; i += kPanelBlock) {
       const float z = reduce_init<OP>();
       reinterpret_cast<float4 *>(acc)[i] = make_float4(z, z, z, z);
-      if constexpr (ARG) reinterpret_cast<int4 *>(acce)[i] = make_int4(-1, -1, -1, -1);
+      if constexpr (OP == DGS_MAX) reinterpret_cast<uint2 *>(acce)[i] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+      else if constexpr (ARG) reinterpret_cast<int4 *>(acce)[i] = make_int4(-1, -1, -1, -1);
     }
     // ---- per-row state; rank the workgroup's rows by length (longest first; absent / too-long rows last) ----
     if (tid < R) {
@@ -195,6 +215,7 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int ld, 
       }
       s_deg[tid] = d;
       s_cur[tid] = s;
+      s_rbeg[tid] = s;
       s_rend[tid] = e;
       s_nextc[tid] = c;
     }
@@ -285,8 +306,16 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int ld, 
         const float4 t = reinterpret_cast<float4 *>(acc)[i];
         float o[V] = {t.x, t.y, t.z, t.w};
         if constexpr (ARG) {
-          const int4 te = reinterpret_cast<int4 *>(acce)[i];
-          int oe[V] = {te.x, te.y, te.z, te.w};
+          int oe[V];
+          if constexpr (OP == DGS_MAX) {
+            const uint2 te = reinterpret_cast<uint2 *>(acce)[i];
+            const unsigned pe[V] = {te.x & 0xFFFF, te.x >> 16, te.y & 0xFFFF, te.y >> 16};
+#pragma unroll
+            for (int v = 0; v < V; v++) oe[v] = (pe[v] == 0xFFFF) ? -1 : col[s_rbeg[r] + (int)pe[v]];
+          } else {
+            const int4 te = reinterpret_cast<int4 *>(acce)[i];
+            oe[0] = te.x; oe[1] = te.y; oe[2] = te.z; oe[3] = te.w;
+          }
           if (s_deg[r] == 0) {  // empty row: 0, not the identity (include/cuda/spmm_cuda.cuh:32,49-51)
 #pragma unroll
             for (int v = 0; v < V; v++) o[v] = 0.f;
