@@ -903,7 +903,8 @@ static int launch_all(const SpmmArgs &a) {
       int *parte = reinterpret_cast<int *>(w + L.off_parte);
       if (hipMemsetAsync(hdr, 0, sizeof(SpmmWs), a.st) != hipSuccess) return DGS_ELAUNCH;
       const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
-      const int tl = P.tlong > L.ch ? P.tlong : L.ch;  // every long row has >= 2 units => all go through combine
+      int tl = P.tlong > L.ch ? P.tlong : L.ch;  // every long row has >= 2 units => all go through combine
+      if (tl > 65534) tl = 65534;  // max keeps 16-bit arg positions (unit lengths never exceed 32768: still >= 2 units)
       hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, tl, a.rowptr, hdr,
                          units);
       auto kern = spmm_panel<G, OP, HAS_VAL>;
