@@ -73,16 +73,33 @@ __global__ __launch_bounds__(kBlock) void arg_backward_rows(int M, int N, const 
   {
     // ---- sorted row: lower_bound of every arg id, then its run of duplicates (no cross-lane traffic in here) ----
     if (sorted && on) {
+      // the V searches of a lane advance together: V independent loads per step instead of V chains back to back
+      int lo[V], hi[V];
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        lo[v] = s;
+        hi[v] = (e[v] >= 0) ? t : s;
+      }
+      bool more = true;
+      while (more) {
+        more = false;
+        int cm[V];
+#pragma unroll
+        for (int v = 0; v < V; v++) cm[v] = (lo[v] < hi[v]) ? col[(lo[v] + hi[v]) >> 1] : 0;
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+          if (lo[v] < hi[v]) {
+            const int mid = (lo[v] + hi[v]) >> 1;
+            if (cm[v] < e[v]) lo[v] = mid + 1;
+            else hi[v] = mid;
+            more |= lo[v] < hi[v];
+          }
+        }
+      }
 #pragma unroll
       for (int v = 0; v < V; v++) {
         if (e[v] < 0) continue;
-        int lo = s, hi = t;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (col[mid] < e[v]) lo = mid + 1;
-          else hi = mid;
-        }
-        for (int q = lo; q < t && col[q] == e[v]; q++) {
+        for (int q = lo[v]; q < t && col[q] == e[v]; q++) {
           ws[v] += val ? val[q] : 1.0f;
           if (gW) unsafeAtomicAdd(gW + q, gx[v]);  // hardware fp32 atomic (device memory), no CAS loop
         }
