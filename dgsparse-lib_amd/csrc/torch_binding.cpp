@@ -142,7 +142,9 @@ struct TValuesCache {
   const void *perm = nullptr;
   Tensor out;
 };
-static TValuesCache g_tv;
+// heap-allocated and never destroyed: a static Tensor would be freed by a static destructor at process exit, after the
+// HIP runtime and the caching allocator may already be gone
+static TValuesCache &g_tv = *new TValuesCache();
 static std::mutex g_tv_mu;
 
 Tensor t_values(const Tensor &values, const Tensor &csr2csc, bool has_value) {
