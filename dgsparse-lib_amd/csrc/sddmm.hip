@@ -340,13 +340,17 @@ static SdPanelPlan sd_panel_plan(int64_t M, int64_t K, int64_t F, int64_t nnz, i
   int slots = (int)(kSdPanelBytes / (W * (mask ? 8 : 4)));
   if (slots > kPanelRMax) slots = kPanelRMax;
   if (slots < 8) return P;
-  // same rule as the SpMM twin: D2 must overflow the L2s and every panel row must be reused several times per XCD
-  const double reuse = (P.nwg / 8.0) * slots * ((double)nnz / (double)M) / (double)K;
-  if (force != 1 && !((double)K * W * 4.0 >= 16e6 && reuse >= 8.0 && M >= 4096)) return P;
-  P.nsb = (int)((M + (int64_t)P.nwg * slots - 1) / ((int64_t)P.nwg * slots));
-  P.R = (int)((M + (int64_t)P.nwg * P.nsb - 1) / ((int64_t)P.nwg * P.nsb));
+  // same rule as the SpMM twin (spmm_impl.h panel_plan): D2 must overflow the L2s, every panel row must be reused
+  // several times per XCD and a row visit must still hold a handful of nnz
+  const double deg = (double)nnz / (double)M;
+  const double reuse = (P.nwg / 8.0) * slots * deg / (double)K;
   int64_t pc = (int64_t)sd_env_int("DGS_PANEL_KB", 6144) * 1024 / (W * 4);
   if (pc < 64) pc = 64;
+  const double visit = deg * (double)pc / (double)K;
+  const bool pays = reuse >= 5.5 || (reuse >= 4.0 && visit >= 10.0);
+  if (force != 1 && !((double)K * W * 4.0 >= 16e6 && pays && M >= 4096)) return P;
+  P.nsb = (int)((M + (int64_t)P.nwg * slots - 1) / ((int64_t)P.nwg * slots));
+  P.R = (int)((M + (int64_t)P.nwg * P.nsb - 1) / ((int64_t)P.nwg * P.nsb));
   P.pcols = (int)pc;
   P.npanels = (int)((K + pc - 1) / pc);
   P.lead = sd_env_int("DGS_PANEL_LEAD", 1);

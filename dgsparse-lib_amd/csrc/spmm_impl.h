@@ -869,16 +869,22 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
   int slots = (int)(kPanelAccBytes / (W * ebytes)) & ~1;
   if (slots > kPanelRMax) slots = kPanelRMax;
   if (slots < 8) return P;
-  // Worth it when (a) the dense operand overflows the L2s and (b) an XCD's 32 workgroups touch every panel row
-  // several times per sweep: reuse = (rows resident per XCD) * (nnz per row) / K.  Measured crossover ~6 (N = 128).
+  // Worth it when (a) the dense operand overflows the L2s and (b) an XCD's workgroups touch every panel row several
+  // times per sweep: reuse = (rows resident per XCD) * (nnz per row) / K = gathered bytes / re-fetched panel bytes, and
+  // a row visit still holds a handful of nnz: visit = (nnz per row) * (panel rows) / K.  Measured on MI355X (233 k
+  // rows): reuse 6.8 / visit 10 wins 1.13x, 5.6 / 8.4 wins 1.05x, 4.5 / 6.7 loses 1.13x, 4.3 / 13 (min, N = 256) wins
+  // 1.22x, 2.8 / 4.2 ties.
   const double bbytes = (double)a.K * W * 4.0;
-  const double reuse = (P.nwg / 8.0) * slots * ((double)a.nnz / (double)a.M) / (double)(a.K > 0 ? a.K : 1);
-  if (force != 1 && !(bbytes >= 16e6 && reuse >= 8.0 && a.M >= 4096)) return P;
-  P.nsb = (int)((a.M + (int64_t)P.nwg * slots - 1) / ((int64_t)P.nwg * slots));
-  P.R = (int)((a.M + (int64_t)P.nwg * P.nsb - 1) / ((int64_t)P.nwg * P.nsb));
+  const double deg = (double)a.nnz / (double)a.M;
+  const double reuse = (P.nwg / 8.0) * slots * deg / (double)(a.K > 0 ? a.K : 1);
   const int64_t pbytes = (int64_t)env_int("DGS_PANEL_KB", 6144) * 1024;
   int64_t pc = pbytes / (W * (a.reduce_op == kOpMaskSum ? 8 : 4));  // masked sum gathers grad AND arg-id rows
   if (pc < 64) pc = 64;
+  const double visit = deg * (double)pc / (double)(a.K > 0 ? a.K : 1);
+  const bool pays = reuse >= 5.5 || (reuse >= 4.0 && visit >= 10.0);
+  if (force != 1 && !(bbytes >= 16e6 && pays && a.M >= 4096)) return P;
+  P.nsb = (int)((a.M + (int64_t)P.nwg * slots - 1) / ((int64_t)P.nwg * slots));
+  P.R = (int)((a.M + (int64_t)P.nwg * P.nsb - 1) / ((int64_t)P.nwg * P.nsb));
   P.pcols = (int)pc;
   P.npanels = (int)((a.K + pc - 1) / pc);
   if (P.npanels < 1) P.npanels = 1;

@@ -131,3 +131,33 @@ def test_read_mtx_reference_fixture():
     nrow, ncol, rp, col = dio.read_mtx(path)
     r2, c2, rp2, col2 = oracle.ref_read_mtx(path)
     assert (nrow, ncol) == (r2, c2) and np.array_equal(rp, rp2) and np.array_equal(col, col2)
+
+
+def test_schedule_queries_need_no_gpu(monkeypatch):
+    """dgs_spmm_csr_schedule / dgs_sddmm_csr_schedule are pure functions of the sizes (and of the DGS_PANEL overrides):
+    the headline graph stays on the row-stream schedule, the Reddit-shaped one takes the column-panel sweep, odd
+    feature widths only after padding, small inputs take the single launch."""
+    from dgsparse import _capi
+    for k in ('DGS_PANEL', 'DGS_PANEL_KB', 'DGS_PANEL_LEAD', 'DGS_PANEL_TLONG'):
+        monkeypatch.delenv(k, raising=False)
+    M1, nnz1 = 1 << 20, 16_108_469            # bench.py headline: 16 nnz per row
+    Mr, nnzr = 232_965, 114_609_723           # Reddit-shaped: 492 nnz per row
+    assert _capi.spmm_schedule(_capi.SUM, 2708, 2708, 32, 10_556) == 'small'
+    assert _capi.spmm_schedule(_capi.SUM, M1, M1, 64, nnz1) == 'rows'
+    for op in (_capi.SUM, _capi.MEAN, _capi.MAX, _capi.MIN):
+        for n in (32, 64, 128, 256, 512):  # max/min at 256+ hold few rows per sweep but still qualify (long visits)
+            assert _capi.spmm_schedule(op, Mr, Mr, n, nnzr) == 'panel', (op, n)
+    assert _capi.spmm_schedule(_capi.SUM, Mr, Mr, 16, nnzr) == 'rows'      # 4 lanes per row: not a panel shape
+    assert _capi.spmm_schedule(_capi.SUM, Mr, Mr, 41, nnzr) == 'rows'      # not a multiple of 4 ...
+    assert _capi.spmm_schedule(_capi.SUM, Mr, Mr, 44, nnzr) == 'panel'     # ... the bindings pad to this
+    assert _capi.spmm_schedule(_capi.SUM, Mr, Mr, 128, Mr * 64) == 'rows'  # 64 nnz per row: too little reuse
+    assert _capi.spmm_schedule(_capi.SUM, Mr, Mr, 128, Mr * 128) == 'rows'  # reuse 4.5 but only 6.7 nnz per visit
+    assert _capi.spmm_schedule(_capi.SUM, Mr, Mr, 128, Mr * 160) == 'panel'  # reuse 5.6
+    lib = _capi._lib
+    assert lib.dgs_sddmm_csr_schedule(Mr, Mr, 64, nnzr, 0) == 2 and lib.dgs_sddmm_csr_schedule(Mr, Mr, 64, nnzr, 1) == 2
+    assert lib.dgs_sddmm_csr_schedule(M1, M1, 64, nnz1, 0) == 1
+    monkeypatch.setenv('DGS_PANEL', '0')
+    assert _capi.spmm_schedule(_capi.SUM, Mr, Mr, 128, nnzr) == 'rows'
+    monkeypatch.setenv('DGS_PANEL', '1')
+    assert _capi.spmm_schedule(_capi.SUM, M1, M1, 64, nnz1) == 'panel'
+
