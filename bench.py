@@ -9,11 +9,18 @@ graph with inputs resident in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--feat 64] [--reduce sum] [--cols powerlaw|uniform]
 
-For N>1 launch under torch.distributed.run (one rank per GPU); rank 0 prints ONE JSON line.
+``--gpus N`` with N > 1 from a bare shell re-launches itself under ``python -m torch.distributed.run`` (one rank per
+GPU, rendezvous on 127.0.0.1); under an existing launcher (WORLD_SIZE set) it just joins.  Rank 0 prints ONE JSON line.
+
+Protocol: W warm-ups + K timed steps between barrier+synchronize (the contract's number); beside it
+the median of 5 repeats of the same K launches between HIP events on the launch stream, a unit-weight run, and seeds
+1..4 of the same generator (extra keys; --no-protocol skips them).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,11 +28,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, 'dgsparse-lib_amd')):
     if _p not in sys.path:
         sys.path.insert(0, _p)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-from bench import graphgen  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 
@@ -51,15 +53,31 @@ def parse():
     ap.add_argument('--dmax', type=int, default=1 << 16, help='degree cap')
     ap.add_argument('--ncols', type=int, default=0, help='columns of A / rows of the dense operand (0 = square)')
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--plan', type=int, default=-1, help='1/0: force the cached locality plan on/off (default: auto)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-protocol', action='store_true', help='skip median-of-5 / unit-weight / seeds 1..4 extras')
+    ap.add_argument('--no-worst-case', action='store_true', help='N>1: skip the uniform-columns, locality-0 second run')
     ap.add_argument('--force-dist', action='store_true', help='run the partitioned code path even with one rank (testing)')
     ap.add_argument('--sweep', action='store_true', help='also time feat=32/128 and max (extra keys)')
     ap.add_argument('--no-dense', action='store_true', help='skip the Reddit-shaped side measurement (extra key)')
     return ap.parse_args()
 
 
+def self_spawn(n):
+    """`python bench.py --gpus N` from a bare shell: become N ranks under torch.distributed.run and relay its exit code."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def time_steps(fn, steps, warmup, dist_on):
     """W untimed warm-ups, then exactly K steps between barrier+synchronize; also HIP-event time on the stream."""
+    import torch
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -80,21 +98,47 @@ def time_steps(fn, steps, warmup, dist_on):
     return wall, ev0.elapsed_time(ev1) / 1e3
 
 
-def cpu_baseline(rp, col, val, X, flops):
+def event_ms(fn, steps):
+    """Average per-launch time of `steps` launches between two HIP events on the launch stream (no barrier)."""
+    import torch
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(steps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / steps
+
+
+def cpu_baseline(rp, col, val, X, flops, C_gpu=None):
     """The reference's own single-threaded CPU loop (oracle/_ref: spmm_reference_host, sp_util.hpp:63-84) when it
-    was built, else the C restatement; plus the OpenMP restatement on all host cores.  Bounded: one pass each."""
+    was built, else the C restatement; plus the OpenMP restatement on all host cores.  Bounded: one pass each.
+    The pass also yields the sequential fp32 result of EVERY row, so the GPU result of the timed tensors is compared
+    against it here (the checker leg; never part of the timed region)."""
+    import numpy as np
     import oracle
     out = {}
     M = rp.shape[0] - 1
-    # bounded sample: the first `rows` rows such that the work is <= ~2^24 nnz (the whole 1M-row graph)
     kind = 'reference' if oracle.have_ref() else 'port'
     fn = (lambda: oracle.ref_spmm_sum(rp, col, val, X)) if kind == 'reference' else \
-         (lambda: oracle.spmm('sum', rp, col, val, X, threads=1))
+         (lambda: oracle.spmm('sum', rp, col, val, X, threads=1)[0])
     t0 = time.perf_counter()
-    fn()
+    Cseq = fn()
     t1 = time.perf_counter() - t0
     out['cpu_baseline'] = dict(value=round(flops / t1 / 1e9, 3), unit='GFLOP/s', cores=1, kind=kind,
                                sample=f'whole workload, 1 pass ({M} rows, {col.shape[0]} nnz, N={X.shape[1]}), {t1:.2f} s')
+    if C_gpu is not None and Cseq is not None:
+        Cseq = np.asarray(Cseq).reshape(C_gpu.shape)
+        rel = np.abs(C_gpu.astype(np.float64) - Cseq) / np.maximum(np.abs(Cseq), 1e-6)
+        lens = np.diff(rp)
+        short = lens <= 64
+        out['parity'] = dict(
+            oracle=('reference spmm_reference_host (sequential fp32, no fma)' if kind == 'reference'
+                    else 'oracle sequential fp32'), rows_checked=int(M),
+            max_rel_err_vs_sequential=float(rel.max()),
+            max_rel_err_rows_le_64nnz=float(rel[short].max()) if short.any() else 0.0,
+            max_rel_err_rows_gt_64nnz=float(rel[~short].max()) if (~short).any() else 0.0,
+            longest_row_nnz=int(lens.max()), within_1e_5=bool(rel.max() <= 1e-5))
     nthr = min(os.cpu_count() or 1, oracle.max_threads())
     best = 1e30
     for _ in range(2):
@@ -108,21 +152,29 @@ def cpu_baseline(rp, col, val, X, flops):
 
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_spawn(a.gpus))
+
+    import numpy as np
+    import torch
+
+    from bench import graphgen
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist_on = world > 1
     if a.gpus != world and dist_on:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
-    if a.gpus > 1 and not dist_on:
-        raise SystemExit('for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...')
+    if not torch.cuda.is_available() or local_rank >= torch.cuda.device_count():
+        raise SystemExit(f'bench.py needs {max(a.gpus, 1)} GPU(s); visible: {torch.cuda.device_count()}')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if dist_on:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.distributed.init_process_group('nccl', device_id=dev)
 
-    import dgsparse
+    import dgsparse  # noqa: F401
     from dgsparse import _capi
 
     Mloc = 1 << a.rows_log2
@@ -130,22 +182,36 @@ def main():
     op = {'sum': _capi.SUM, 'mean': _capi.MEAN, 'max': _capi.MAX, 'min': _capi.MIN}[a.reduce]
     extra = {}
 
+    def make_graph(seed):
+        rp_, col_, st_ = graphgen.powerlaw_csr(Mloc, Mloc * a.deg, K=(a.ncols or None), alpha=a.alpha, dmax=a.dmax,
+                                               cols=a.cols, seed=seed, device=str(dev), as_torch=True)
+        g_ = torch.Generator(device=dev)
+        g_.manual_seed(seed + 1)
+        val_ = torch.rand(st_['nnz'], generator=g_, device=dev)
+        X_ = torch.rand((st_['K'], N), generator=g_, device=dev)
+        return rp_, col_, st_, val_, X_
+
+    def make_step(rp_, col_, val_, X_):
+        """One SpMM through the C ABI; with a plan (Storage-cached locality plan, built once outside the timed region)
+        when the library offers one for this shape."""
+        plan = None
+        if a.plan != 0 and hasattr(_capi, 'spmm_plan'):
+            plan = _capi.spmm_plan(rp_, col_, X_.shape[0], N, force=(a.plan == 1))
+        if plan is not None:
+            return (lambda: _capi.spmm(op, rp_, col_, val_, X_, plan=plan)), True
+        return (lambda: _capi.spmm(op, rp_, col_, val_, X_)), False
+
     use_dist = dist_on or a.force_dist
+    C_check = None
     if not use_dist:
-        rp, col, st = graphgen.powerlaw_csr(Mloc, Mloc * a.deg, K=(a.ncols or None), alpha=a.alpha, dmax=a.dmax, cols=a.cols, seed=a.seed,
-                                            device=str(dev), as_torch=True)
+        rp, col, st, val, X = make_graph(a.seed)
         K = st['K']
-        g = torch.Generator(device=dev)
-        g.manual_seed(a.seed + 1)
-        val = torch.rand(st['nnz'], generator=g, device=dev)
-        X = torch.rand((K, N), generator=g, device=dev)
         nnz_total = st['nnz']
+        step, planned = make_step(rp, col, val, X)
 
-        def step():
-            return _capi.spmm(op, rp, col, val, X)
-
-        # parity spot-check on the exact tensors being timed: 2048 sampled rows (always including the longest)
-        # against an fp64 torch gather-sum; the full parity suite is tests/ -m gpu
+        # parity spot-check on the exact tensors being timed: sampled rows (always including the longest) against an
+        # fp64 torch gather-sum; every row is checked against the sequential reference in the cpu_baseline leg below,
+        # and the full parity suite is tests/ -m gpu
         C, _ = step()
         if a.reduce in ('sum', 'mean'):
             deg = (rp[1:] - rp[:-1]).long()
@@ -162,12 +228,15 @@ def main():
                     ref = ref / (e0 - s0)
                 worst = max(worst, ((C[r].double() - ref).abs() / ref.abs().clamp_min(1e-6)).max().item())
             assert worst < 1e-5, f'bench self-check failed: rel err {worst}'
-            extra['self_check_max_rel_err'] = worst
+            extra['self_check_max_rel_err_vs_fp64'] = worst
+        if a.reduce == 'sum' and not a.no_cpu_baseline:
+            C_check = C.cpu().numpy()
         del C
         b_alg = alg_bytes_spmm(Mloc, K, N, nnz_total, True, a.reduce in ('max', 'min'))
         parallelism = 'single'
         workload = f'synthetic power-law CSR {Mloc}x{K}, nnz={nnz_total} (~{nnz_total / Mloc:.1f}/row, alpha={a.alpha}, ' \
                    f'max_deg={st["max_deg"]}), cols={a.cols}, SpMM-{a.reduce} feat={N}, fp32 values'
+        extra['schedule'] = _capi.spmm_schedule(op, Mloc, K, N, nnz_total) + ('+plan' if planned else '')
     else:
         from dgsparse import dist as ddist
         part = ddist.synthetic_partition(rank, world, Mloc, a.deg, cols=a.cols, locality=a.locality, seed=a.seed,
@@ -186,7 +255,8 @@ def main():
         K = Mloc * world
         b_alg = alg_bytes_spmm(Mloc, Mloc + eng.n_halo, N, part.nnz, True, a.reduce in ('max', 'min'))
         parallelism = f'rowpart{world}+halo-alltoallv'
-        extra['halo'] = dict(rows_per_gpu=int(eng.n_halo), bytes_per_gpu=int(eng.n_halo) * N * 4, locality=a.locality)
+        extra['halo'] = dict(rows_per_gpu=int(eng.n_halo), bytes_per_gpu=int(eng.n_halo) * N * 4, locality=a.locality,
+                             cols=a.cols)
         workload = f'synthetic power-law CSR {K}x{K} ({Mloc} rows/GPU, ~{a.deg}/row), cols={a.cols}, ' \
                    f'locality={a.locality}, SpMM-{a.reduce} feat={N}, 1-D row partition + halo all-to-all-v'
 
@@ -216,26 +286,76 @@ def main():
         'config': {'workload': workload, 'rows_per_gpu': Mloc, 'nnz_total': int(nnz_total), 'feat': N,
                    'reduce': a.reduce, 'cols': a.cols, 'seed': a.seed, 'parallelism': parallelism},
         'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'traffic_source': None,
                      'alg_bytes_per_launch': int(b_alg), 'kernel_us': round(kern_s * 1e6, 2)},
     }
     res.update(extra)
+    # roofline.traffic is NOT measured by this process (PMC passes cannot run beside the timed region): it is the
+    # figure of the committed rocprofv3 counter passes for this very configuration, with its provenance next to it
     tf = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
     if os.path.exists(tf) and not use_dist:
         try:
             tj = json.load(open(tf))
-            key = f'{a.reduce}_feat{N}_{a.cols}'
+            key = f'{a.reduce}_feat{N}_{a.cols}' + ('_plan' if res.get('schedule', '').endswith('+plan') else '')
             if key in tj:
                 res['roofline']['traffic'] = tj[key]
+                res['roofline']['traffic_source'] = f"profiles/hbm_traffic.json[{key}] <- {tj.get('_source', {}).get(key, 'see profiles/README.md')}"
         except Exception:
             pass
+
+    if not a.no_protocol and not use_dist:
+        # median of 5 repeats of K launches between HIP events; unit weights; seeds 1..4
+        reps = sorted(event_ms(step, a.steps) for _ in range(5))
+        prot = {'repeats_ms': [round(x, 5) for x in reps], 'median_ms': round(reps[2], 5),
+                'median_frac': round(b_alg / (reps[2] / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
+        ones = torch.ones_like(val)
+        step1, _ = make_step(rp, col, ones, X)
+        step1()
+        prot['unit_weights_ms'] = round(sorted(event_ms(step1, max(10, a.steps // 5)) for _ in range(3))[1], 5)
+        del ones, step1
+        seeds = {}
+        for s in range(5):
+            if s == a.seed:
+                seeds[str(s)] = dict(ms=prot['median_ms'], nnz=int(nnz_total))
+                continue
+            rp2, col2, st2, val2, X2 = make_graph(s)
+            st2p, _ = make_step(rp2, col2, val2, X2)
+            st2p()
+            seeds[str(s)] = dict(ms=round(sorted(event_ms(st2p, max(10, a.steps // 5)) for _ in range(3))[1], 5),
+                                 nnz=int(st2['nnz']))
+            del rp2, col2, val2, X2, st2p
+        prot['seeds'] = seeds
+        res['protocol'] = prot
+
+    if dist_on and not a.no_worst_case:
+        # the same step on the exchange's worst case: uniform random columns, no locality (every edge leaves its
+        # partition with probability (N-1)/N); extra keys, not the metric
+        from dgsparse import dist as ddist
+        del eng
+        part_w = ddist.synthetic_partition(rank, world, Mloc, a.deg, cols='uniform', locality=1.0 / world, seed=a.seed,
+                                           device=dev)
+        eng_w = ddist.DistSpMM(part_w, N)
+        Xw = eng_w.local_features()
+        Xw.copy_(torch.rand((Mloc, N), device=dev))
+        ws, ww = max(5, a.steps // 5), 3
+        wall_w, _ = time_steps(lambda: eng_w.spmm(Xw, a.reduce), ws, ww, True)
+        tw = torch.tensor([wall_w, float(eng_w.n_halo)], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
+        res['worst_case'] = dict(cols='uniform', locality=round(1.0 / world, 4), steps=ws,
+                                 ms_per_step=round(tw[0].item() / ws * 1e3, 4),
+                                 value=round(2.0 * eng_w.global_nnz * N / (tw[0].item() / ws) / 1e9, 2), unit='GFLOP/s',
+                                 halo_rows_per_gpu_max=int(tw[1].item()),
+                                 halo_bytes_per_gpu_max=int(tw[1].item()) * N * 4)
+        del eng_w, part_w
 
     if a.sweep and not use_dist and rank == 0:
         sw = {}
         for n2, red in ((32, 'sum'), (128, 'sum'), (64, 'max'), (64, 'mean')):
             X2 = torch.rand((K, n2), device=dev)
             o2 = {'sum': _capi.SUM, 'max': _capi.MAX, 'mean': _capi.MEAN}[red]
-            w2, e2 = time_steps(lambda: _capi.spmm(o2, rp, col, val, X2), 20, 3, False)
+            plan2 = _capi.spmm_plan(rp, col, K, n2) if (a.plan != 0 and hasattr(_capi, 'spmm_plan')) else None
+            kw = dict(plan=plan2) if plan2 is not None else {}
+            w2, e2 = time_steps(lambda: _capi.spmm(o2, rp, col, val, X2, **kw), 20, 3, False)
             b2 = alg_bytes_spmm(Mloc, K, n2, nnz_total, True, red == 'max')
             sw[f'{red}_feat{n2}'] = dict(gflops=round(2.0 * nnz_total * n2 / (w2 / 20) / 1e9, 1),
                                          gbs=round(b2 / (e2 / 20) / 1e9, 1), frac=round(b2 / (e2 / 20) / 1e9 / HBM_PEAK_GBS, 4))
@@ -261,7 +381,8 @@ def main():
 
     if rank == 0 and not use_dist and not a.no_cpu_baseline:
         try:
-            res.update(cpu_baseline(rp.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy(), X.cpu().numpy(), flops))
+            res.update(cpu_baseline(rp.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy(), X.cpu().numpy(), flops,
+                                    C_check))
         except Exception as e:  # the baseline is a reported side figure; never lose the GPU line over it
             res['cpu_baseline'] = dict(value=None, unit='GFLOP/s', cores=0, kind='port', sample=f'failed: {e}')
     if rank == 0:

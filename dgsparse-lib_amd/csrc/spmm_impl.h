@@ -83,12 +83,25 @@ struct SpmmWs {       // workspace header (zeroed every call with one 16-byte me
   int n_units;        // K0 -> fused/K2: number of unit descriptors
   int n_pslots;       // partial-row slots handed out (multi-unit rows only)
   int arrivals;       // spmm_panel: panel steps finished, summed over workgroups (soft barrier)
-  int pad;
+  int n_long;         // K0 -> K2: number of multi-unit rows (entries of the long-row table)
+};
+
+// Unit tables, as the kernels see them.  Two producers: spmm_classify (plan-free call: tables in the workspace, rebuilt
+// every call) and the cached plan (spmm_plan.hip: tables built once per matrix, units of hub rows cut at column-slice
+// boundaries and sorted by (slice, first column), one slice per XCD).
+//   unit     {row, first nnz, nnz in the unit, partial-row slot | -1 when the unit is the whole row}
+//   longrow  {row, first partial slot, units in the row, -}           (multi-unit rows only: what spmm_combine folds)
+struct UnitTab {
+  const int *n_units;
+  const int *n_long;
+  const int *xcd_start;  // [9] first unit of each XCD's share, or nullptr = equal eighths of the table
+  const int4 *units;
+  const int4 *longrows;
 };
 
 struct WsLayout {
-  size_t off_units, off_part, off_parte, total;
-  int64_t max_units, max_pslots;
+  size_t off_units, off_long, off_part, off_parte, total;
+  int64_t max_units, max_pslots, max_long;
   int ch;
 };
 
@@ -105,12 +118,46 @@ static inline WsLayout ws_layout(int reduce_op, int64_t N, int64_t nnz) {
   L.ch = unit_len(nnz);
   L.max_units = nnz / kT2 + nnz / L.ch + 2;          // sum over long rows of ceil(len/ch) <= nnz/ch + #long rows
   L.max_pslots = 2 * (nnz / L.ch) + 2;               // same sum over rows longer than ch only (they need partials)
+  L.max_long = nnz / L.ch + 2;                       // rows longer than ch
   L.off_units = up(sizeof(SpmmWs));
-  L.off_part = L.off_units + up((size_t)L.max_units * sizeof(int4));
+  L.off_long = L.off_units + up((size_t)L.max_units * sizeof(int4));
+  L.off_part = L.off_long + up((size_t)L.max_long * sizeof(int4));
   const size_t prow = up((size_t)L.max_pslots * N * sizeof(float));  // one partial row per unit of a multi-unit row
   L.off_parte = L.off_part + prow;
   const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
   L.total = L.off_parte + (arg ? prow : 0) + 256;
+  return L;
+}
+
+// With a cached plan the workspace only holds the partial rows of the multi-unit rows.
+static inline WsLayout ws_layout_plan(int reduce_op, int64_t N, int64_t pslots) {
+  auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+  WsLayout L{};
+  L.max_pslots = pslots;
+  L.off_part = 0;
+  const size_t prow = up((size_t)(pslots > 0 ? pslots : 1) * N * sizeof(float));
+  L.off_parte = prow;
+  const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
+  L.total = prow + (arg ? prow : 0) + 256;
+  return L;
+}
+// plan buffer: [256-byte header][units: max_units int4][long rows: max_long int4][pcol: nnz int32]; the capacities
+// (and so the offsets) are a pure function of nnz, the actual counts live in the header
+constexpr int kPlanCh = 256;          // unit length of the plan's unit table
+constexpr int kPlanSliceMin = 128;    // smallest row length that may be cut at column-slice boundaries
+struct PlanLayout {
+  int64_t max_units, max_long;
+  size_t off_units, off_long, off_pcol, total;
+};
+static inline PlanLayout plan_layout(int64_t nnz) {
+  auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+  PlanLayout L;
+  L.max_units = nnz / kT1 + 8 * (nnz / kPlanSliceMin) + nnz / kPlanCh + 16;
+  L.max_long = nnz / kPlanSliceMin + nnz / kPlanCh + 2;
+  L.off_units = 256;
+  L.off_long = L.off_units + up((size_t)L.max_units * sizeof(int4));
+  L.off_pcol = L.off_long + up((size_t)L.max_long * sizeof(int4));
+  L.total = L.off_pcol + up((size_t)nnz * sizeof(int)) + 256;
   return L;
 }
 
@@ -232,25 +279,25 @@ __device__ __forceinline__ void seq_redo(unsigned mask, int rs, int re, int N, i
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K0: scan rowptr once and cut every long row (len > T2) into units of <= ch nnz: unit = {row, k, first partial slot of
-// the row, units in the row}.  Each thread looks at kK0Rows rows, a block-level exclusive scan turns the per-thread
-// unit counts into offsets, and ONE atomicAdd per block reserves the block's range of the table (same-address
-// atomics cost ~12 ns each when they serialise at L2; per-row atomics made this kernel 44 us, per-block ones ~5).
-// Only the position of a row's units in the table depends on the atomics, never a value.
+// K0: scan rowptr once and cut every long row (len > tlong) into units of <= ch nnz; multi-unit rows also get an entry
+// of the long-row table (what spmm_combine folds).  Each thread looks at kK0Rows rows, a block-level exclusive scan
+// turns the per-thread counts into offsets, and ONE 64-bit atomicAdd per block reserves the block's range of the unit
+// table and of the partial slots (same-address atomics cost ~12 ns each when they serialise at L2; per-row atomics
+// made this kernel 44 us, per-block ones ~5); blocks that own multi-unit rows add one more for the long-row table.
+// Only the position of a row's entries in the tables depends on the atomics, never a value.
 constexpr int kK0Rows = 16;
 static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, int tlong,
                                                                const int *__restrict__ rowptr,
-                                                               SpmmWs *__restrict__ hdr, int4 *__restrict__ units) {
-  __shared__ int s_wsum[kBlock / kWave];
-  __shared__ int s_base;
-  __shared__ int s_psum[kBlock / kWave];
-  __shared__ int s_pbase;
+                                                               SpmmWs *__restrict__ hdr, int4 *__restrict__ units,
+                                                               int4 *__restrict__ longrows) {
+  __shared__ int s_wsum[kBlock / kWave], s_psum[kBlock / kWave], s_lsum[kBlock / kWave];
+  __shared__ int s_base, s_pbase, s_lbase;
   // block b owns the CONTIGUOUS rows [b*4096, (b+1)*4096): its units form one run of the table that covers
   // neighbouring rows, which is what lets the unit path give each XCD rows that share columns (see spmm_units_body)
   const int nthreads = kBlock;
   const int tid = blockIdx.x * kBlock * kK0Rows + threadIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int mine = 0, pmine = 0;  // units of this thread's rows; of which units that need a partial-row slot
+  int mine = 0, pmine = 0, lmine = 0;  // units of this thread's rows; units that need a partial slot; multi-unit rows
   unsigned hugemask = 0;
 #pragma unroll
   for (int i = 0; i < kK0Rows; i++) {
@@ -260,35 +307,43 @@ static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, in
       if (len > tlong) {
         const int nch = (len + ch - 1) / ch;
         mine += nch;
-        if (nch > 1) pmine += nch;
+        if (nch > 1) {
+          pmine += nch;
+          lmine++;
+        }
         hugemask |= 1u << i;
       }
     }
   }
-  int incl = mine, pincl = pmine;
+  int incl = mine, pincl = pmine, lincl = lmine;
 #pragma unroll
   for (int d = 1; d < kWave; d <<= 1) {
     const int t = __shfl_up(incl, d, kWave);
     const int tp = __shfl_up(pincl, d, kWave);
+    const int tl = __shfl_up(lincl, d, kWave);
     if (lane >= d) {
       incl += t;
       pincl += tp;
+      lincl += tl;
     }
   }
   if (lane == kWave - 1) {
     s_wsum[wave] = incl;
     s_psum[wave] = pincl;
+    s_lsum[wave] = lincl;
   }
   __syncthreads();
-  int woff = 0, total = 0, pwoff = 0, ptotal = 0;
+  int woff = 0, total = 0, pwoff = 0, ptotal = 0, lwoff = 0, ltotal = 0;
 #pragma unroll
   for (int w = 0; w < kBlock / kWave; w++) {
     if (w < wave) {
       woff += s_wsum[w];
       pwoff += s_psum[w];
+      lwoff += s_lsum[w];
     }
     total += s_wsum[w];
     ptotal += s_psum[w];
+    ltotal += s_lsum[w];
   }
   if (threadIdx.x == 0) {
     // both counters with ONE 64-bit atomic (n_units low word, n_pslots high word; the header is 16-byte aligned):
@@ -299,21 +354,28 @@ static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, in
                       (unsigned long long)(unsigned)total | ((unsigned long long)(unsigned)ptotal << 32));
     s_base = (int)(unsigned)(old & 0xffffffffull);
     s_pbase = (int)(unsigned)(old >> 32);
+    s_lbase = ltotal ? atomicAdd(&hdr->n_long, ltotal) : 0;
   }
   __syncthreads();
   if (!mine) return;
   int off = s_base + woff + incl - mine;
   int poff = s_pbase + pwoff + pincl - pmine;
+  int loff = s_lbase + lwoff + lincl - lmine;
   while (hugemask) {
     const int i = __ffs((int)hugemask) - 1;
     hugemask &= hugemask - 1;
     const int r = i * nthreads + tid;
-    const int len = rowptr[r + 1] - rowptr[r];
-    const int nch = (len + ch - 1) / ch;
-    // unit = {row, index in row, first partial slot of the row (-1: single unit, writes C directly), units in row}
-    for (int k = 0; k < nch; k++) units[off + k] = make_int4(r, k, nch > 1 ? poff : -1, nch);
+    const int rs = rowptr[r], re = rowptr[r + 1];
+    const int nch = (re - rs + ch - 1) / ch;
+    for (int k = 0; k < nch; k++) {
+      const int p0 = rs + k * ch;
+      units[off + k] = make_int4(r, p0, min(ch, re - p0), nch > 1 ? poff + k : -1);
+    }
     off += nch;
-    if (nch > 1) poff += nch;
+    if (nch > 1) {
+      longrows[loff++] = make_int4(r, poff, nch, 0);
+      poff += nch;
+    }
   }
 }
 
@@ -601,11 +663,10 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
 // ---------------------------------------------------------------------------------------------------------
 // K2: one wave per unit (<= ch nnz of a long row).
 template <int G, int V, int OP, bool HAS_VAL>
-__device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &lds, int N, int ch,
+__device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &lds, int N,
                                                 const int *__restrict__ rowptr, const int *__restrict__ col,
                                                 const float *__restrict__ val, const float *__restrict__ B,
-                                                float *__restrict__ C, int *__restrict__ E,
-                                                const SpmmWs *__restrict__ hdr, const int4 *__restrict__ units,
+                                                float *__restrict__ C, int *__restrict__ E, const UnitTab &ut,
                                                 float *__restrict__ part, int *__restrict__ parte) {
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -613,15 +674,16 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
   int2 *tile = lds.tile[wave];
   const int f0 = (blockIdx.y * G + l) * V;
   const bool fl = f0 < N;
-  const int n_units = hdr->n_units;
-  // XCD-aware unit mapping (speed hint only): block b runs on XCD b % 8 (observed), so the unit blocks of one XCD
-  // walk one contiguous eighth of the table = a few runs of neighbouring rows (spmm_classify), whose gathers share an L2.
+  const int n_units = *ut.n_units;
+  // XCD-aware unit mapping (speed hint only): block b runs on XCD b % 8 (observed), so the unit blocks of one XCD walk
+  // one contiguous share of the table: a few runs of neighbouring rows (spmm_classify), or - with a plan - the units of
+  // ONE COLUMN SLICE in column order, so that an XCD's L2 only ever sees an eighth of the dense operand.
   int u, uend, wstride;
 #if DGS_XCD_REMAP
   if ((nblocks & 7) == 0) {
     const int x = bid & 7, wx = (nblocks >> 3) * (kBlock / kWave);
-    const int lo = (int)(((long long)n_units * x) >> 3);
-    uend = (int)(((long long)n_units * (x + 1)) >> 3);
+    const int lo = ut.xcd_start ? ut.xcd_start[x] : (int)(((long long)n_units * x) >> 3);
+    uend = ut.xcd_start ? ut.xcd_start[x + 1] : (int)(((long long)n_units * (x + 1)) >> 3);
     u = lo + (bid >> 3) * (kBlock / kWave) + wave;
     wstride = wx;
   } else
@@ -632,10 +694,9 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
     wstride = nblocks * (kBlock / kWave);
   }
   for (; u < uend; u += wstride) {
-    const int4 d = units[u];  // {row, unit index in row, partial slot base, units in row}
-    const int rs = rowptr[d.x], re = rowptr[d.x + 1];
-    const int p0 = rs + d.y * ch;
-    const int p1 = min(p0 + ch, re);
+    const int4 d = ut.units[u];  // {row, first nnz, nnz in the unit, partial slot | -1}
+    const int p0 = d.y, p1 = d.y + d.z;
+    const bool whole = d.w < 0;
     float acc[V];
     int ei[V], ep[V], el[V];
 #pragma unroll
@@ -651,8 +712,8 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
     if constexpr (OP == DGS_MIN) {
       const unsigned nm = nan_flags<G, V>(nf);
       if (nm && g == 0 && fl) {
-        if (d.w == 1) {
-          seq_redo<V, OP>(nm, rs, re, N, f0, col, HAS_VAL ? val : nullptr, B, acc, ei);
+        if (whole) {
+          seq_redo<V, OP>(nm, p0, p1, N, f0, col, HAS_VAL ? val : nullptr, B, acc, ei);
         } else {  // tell the combine kernel to redo these elements of the row
 #pragma unroll
           for (int v = 0; v < V; v++)
@@ -661,16 +722,16 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
       }
     }
     if (g == 0 && fl) {
-      if (d.w == 1) {  // the whole row was this unit: final result
+      if (whole) {  // the whole row was this unit: final result
         if constexpr (OP == DGS_MEAN) {
-          const float dg = (float)(re - rs);
+          const float dg = (float)d.z;
 #pragma unroll
           for (int v = 0; v < V; v++) acc[v] /= dg;
         }
         store_vec_stream<V>(C + (int64_t)d.x * N + f0, acc);
         if constexpr (ARG) store_vec_stream<V>(E + (int64_t)d.x * N + f0, ei);
       } else {
-        const int64_t slot = (int64_t)(d.z + d.y) * N + f0;
+        const int64_t slot = (int64_t)d.w * N + f0;
         store_vec<V>(part + slot, acc);
         if constexpr (ARG) store_vec<V>(parte + slot, ei);
       }
@@ -683,16 +744,14 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
 // each own 4 x 64 consecutive rows.  Unit blocks come first so that the longest-running work starts first; the
 // two kinds of work share the CUs, so the fabric-bound unit gathers overlap the row kernel's latency phases.
 template <int G, int V, int OP, bool HAS_VAL>
-__global__ __launch_bounds__(kBlock) void spmm_fused(int M, int N, int ch, int nbu, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(kBlock) void spmm_fused(int M, int N, int nbu, const int *__restrict__ rowptr,
                                                      const int *__restrict__ col, const float *__restrict__ val,
                                                      const float *__restrict__ B, float *__restrict__ C,
-                                                     int *__restrict__ E, const SpmmWs *__restrict__ hdr,
-                                                     const int4 *__restrict__ units, float *__restrict__ part,
+                                                     int *__restrict__ E, const UnitTab ut, float *__restrict__ part,
                                                      int *__restrict__ parte) {
   __shared__ RowsLds lds;
   if ((int)blockIdx.x < nbu)
-    spmm_units_body<G, V, OP, HAS_VAL>(blockIdx.x, nbu, lds, N, ch, rowptr, col, val, B, C, E, hdr, units, part,
-                                       parte);
+    spmm_units_body<G, V, OP, HAS_VAL>(blockIdx.x, nbu, lds, N, rowptr, col, val, B, C, E, ut, part, parte);
   else {
     // XCD-aware row mapping: workgroups are dealt round-robin to the 8 XCDs (observed: block b -> XCD b % 8), each
     // with a private L2.  Give every XCD a CONTIGUOUS eighth of the row blocks, so that neighbouring rows - which
@@ -721,15 +780,13 @@ __global__ __launch_bounds__(kBlock) void spmm_small(int M, int N, int rpw, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K3: waves stride over the unit table; the wave that meets the FIRST unit of a multi-unit row folds that row's
-// partial rows in unit order (groups take interleaved units, 4 independent partial loads in flight per lane,
-// then the fixed cross-group tree).
+// K3: one wave per entry of the long-row table folds that row's partial rows in unit order (groups take interleaved
+// units, 4 independent partial loads in flight per lane, then the fixed cross-group tree).
 template <int G, int V, int OP>
 __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restrict__ rowptr,
                                                        const int *__restrict__ col, const float *__restrict__ val,
                                                        const float *__restrict__ B, float *__restrict__ C,
-                                                       int *__restrict__ E,
-                                                       const SpmmWs *__restrict__ hdr, const int4 *__restrict__ units,
+                                                       int *__restrict__ E, const UnitTab ut,
                                                        const float *__restrict__ part,
                                                        const int *__restrict__ parte) {
   constexpr int NG = kWave / G;
@@ -739,20 +796,11 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
   const int g = lane / G, l = lane % G;
   const int f0 = (blockIdx.y * G + l) * V;
   const bool fl = f0 < N;
-  const int n_units = hdr->n_units;
-  const int wstride = gridDim.x * (kBlock / kWave) * kWave;
-  for (int i0 = (blockIdx.x * (kBlock / kWave) + wave) * kWave; i0 < n_units; i0 += wstride) {
-   // 64 descriptors per wave-load; rows to fold = first unit of a multi-unit row
-   int4 dl = make_int4(0, 1, 0, 0);
-   if (i0 + lane < n_units) dl = units[i0 + lane];  // {row, unit index in row, first partial slot of the row, units in row}
-   unsigned long long todo = __ballot(dl.y == 0 && dl.w > 1);
-   while (todo) {
-    const int src = __ffsll((long long)todo) - 1;
-    todo &= todo - 1;
-    int4 d;
-    d.x = __shfl(dl.x, src, 64);
-    d.z = __shfl(dl.z, src, 64);
-    d.w = __shfl(dl.w, src, 64);
+  const int n_long = *ut.n_long;
+  const int wstride = gridDim.x * (kBlock / kWave);
+  for (int i = blockIdx.x * (kBlock / kWave) + wave; i < n_long; i += wstride) {
+    const int4 d = ut.longrows[i];  // {row, first partial slot, units in the row, -}
+    {
     float acc[V];
     int ei[V], ep[V], el[V];
     unsigned nm = 0;  // MIN: elements whose partials met a NaN product
@@ -763,20 +811,20 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
       ep[v] = INT_MAX;
       el[v] = -1;
     }
-    for (int k = g; k < d.w; k += NG * UP) {
+    for (int k = g; k < d.z; k += NG * UP) {
       float x[UP][V];
       int xe[UP][V];
 #pragma unroll
       for (int q = 0; q < UP; q++) {
-        if (k + q * NG < d.w && fl) {
-          const int64_t slot = (int64_t)(d.z + k + q * NG) * N + f0;
+        if (k + q * NG < d.z && fl) {
+          const int64_t slot = (int64_t)(d.y + k + q * NG) * N + f0;
           load_vec<V>(part + slot, x[q]);
           if constexpr (ARG) load_vec<V>(parte + slot, xe[q]);
         }
       }
 #pragma unroll
       for (int q = 0; q < UP; q++) {
-        if (k + q * NG < d.w && fl) {
+        if (k + q * NG < d.z && fl) {
 #pragma unroll
           for (int v = 0; v < V; v++) {
             if constexpr (OP == DGS_MIN) {
@@ -824,7 +872,7 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
       store_vec_stream<V>(C + (int64_t)d.x * N + f0, acc);
       if constexpr (ARG) store_vec_stream<V>(E + (int64_t)d.x * N + f0, ei);
     }
-   }
+    }
   }
 }
 
@@ -839,7 +887,24 @@ struct SpmmArgs {
   void *ws;  // nullptr => single-kernel path
   hipStream_t st;
   int reduce_op;
+  // cached plan (dgs_spmm_plan_build): device tables + the counts the host needs to size grids and the workspace
+  const struct PlanHdr *plan = nullptr;
+  int plan_units = 0, plan_long = 0, plan_pslots = 0;
 };
+
+// Device-resident header of a cached plan, followed by the tables (all offsets in bytes from the header).
+constexpr int kPlanMagic = 0x64677350;  // "dgsP"
+struct PlanHdr {
+  int magic, version;
+  int M, nnz, K;
+  int n_units, n_long, n_pslots;
+  int ch, t1, tslice;
+  int xcd_start[9];     // first unit of each XCD's share of the (sorted) unit table
+  int slice_bound[9];   // column-slice boundaries (slice x = columns [b[x], b[x+1]))
+  int hot_thr[4];       // reference-count thresholds of the hot classes stored in pcol bits 28..30
+  int has_pcol;
+};
+static_assert(sizeof(PlanHdr) <= 256, "plan header must fit its 256-byte slot");
 
 static inline int cu_count() {
   static int n = 0;
@@ -905,14 +970,16 @@ static int launch_all(const SpmmArgs &a) {
       char *w = static_cast<char *>(a.ws);
       SpmmWs *hdr = reinterpret_cast<SpmmWs *>(w);
       int4 *units = reinterpret_cast<int4 *>(w + L.off_units);
+      int4 *longrows = reinterpret_cast<int4 *>(w + L.off_long);
       float *part = reinterpret_cast<float *>(w + L.off_part);
       int *parte = reinterpret_cast<int *>(w + L.off_parte);
+      const UnitTab ut{&hdr->n_units, &hdr->n_long, nullptr, units, longrows};
       if (hipMemsetAsync(hdr, 0, sizeof(SpmmWs), a.st) != hipSuccess) return DGS_ELAUNCH;
       const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
       int tl = P.tlong > L.ch ? P.tlong : L.ch;  // every long row has >= 2 units => all go through combine
       if (tl > 65534) tl = 65534;  // max keeps 16-bit arg positions (unit lengths never exceed 32768: still >= 2 units)
       hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, tl, a.rowptr, hdr,
-                         units);
+                         units, longrows);
       auto kern = spmm_panel<G, OP, HAS_VAL>;
       static bool attr_set[64] = {};  // per instantiation and device: allow the large dynamic LDS
       int dev_id = 0;
@@ -932,11 +999,11 @@ static int launch_all(const SpmmArgs &a) {
       }
       const int nbu = 1024;
       hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)nbu, (unsigned)a.tiles), dim3(kBlock), 0, a.st, (int)a.M,
-                         (int)a.N, L.ch, nbu, a.rowptr, a.col, a.val, a.B, a.C, a.E, hdr, units, part, parte);
-      const int64_t cb = (L.max_units + 255) / 256;
+                         (int)a.N, nbu, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
+      const int64_t cb = (L.max_long + 3) / 4;
       const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
       hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B,
-                         a.C, a.E, hdr, units, part, parte);
+                         a.C, a.E, ut, part, parte);
       return check_launch();
     }
   }
@@ -951,31 +1018,58 @@ static int launch_all(const SpmmArgs &a) {
                        a.rowptr, a.col, a.val, a.B, a.C, a.E);
     return check_launch();
   }
+  const int rows_per_block = (kBlock / kWave) * kRowsPerWave;
+  const int64_t nbr = (a.M + rows_per_block - 1) / rows_per_block;
+#ifndef DGS_NBU
+#define DGS_NBU 1024
+#endif
+  if (a.plan) {
+    // cached plan: the unit tables already exist (hub rows cut at column-slice boundaries, sorted by slice and first
+    // column, one slice per XCD), so the call is fused + combine; the workspace only holds the partial rows
+    const char *pb = reinterpret_cast<const char *>(a.plan);
+    const WsLayout L = ws_layout_plan(a.reduce_op, a.N, a.plan_pslots);
+    char *w = static_cast<char *>(a.ws);
+    float *part = reinterpret_cast<float *>(w + L.off_part);
+    int *parte = reinterpret_cast<int *>(w + L.off_parte);
+    const PlanHdr *ph = a.plan;
+    const PlanLayout PL = plan_layout(a.nnz);
+    const UnitTab ut{&ph->n_units, &ph->n_long, ph->xcd_start, reinterpret_cast<const int4 *>(pb + PL.off_units),
+                     reinterpret_cast<const int4 *>(pb + PL.off_long)};
+    int64_t ub = ((int64_t)a.plan_units + 3) / 4;
+    ub = (ub + 7) & ~int64_t(7);  // a multiple of 8 so that the XCD mapping of the unit blocks applies
+    const int nbu = (int)(ub < DGS_NBU ? (ub < 8 ? 8 : ub) : DGS_NBU);
+    hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
+                       a.st, (int)a.M, (int)a.N, nbu, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
+    if (a.plan_long > 0) {
+      const int64_t cb = ((int64_t)a.plan_long + 3) / 4;
+      const dim3 g3((unsigned)(cb < 2048 ? cb : 2048), (unsigned)a.tiles);
+      hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B,
+                         a.C, a.E, ut, part, parte);
+    }
+    return check_launch();
+  }
   const WsLayout L = ws_layout(a.reduce_op, a.N, a.nnz);
   char *w = static_cast<char *>(a.ws);
   SpmmWs *hdr = reinterpret_cast<SpmmWs *>(w);
   int4 *units = reinterpret_cast<int4 *>(w + L.off_units);
+  int4 *longrows = reinterpret_cast<int4 *>(w + L.off_long);
   float *part = reinterpret_cast<float *>(w + L.off_part);
   int *parte = reinterpret_cast<int *>(w + L.off_parte);
+  const UnitTab ut{&hdr->n_units, &hdr->n_long, nullptr, units, longrows};
   if (hipMemsetAsync(hdr, 0, sizeof(SpmmWs), a.st) != hipSuccess) return DGS_ELAUNCH;
   const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
-  hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, kT2, a.rowptr, hdr, units);
+  hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, kT2, a.rowptr, hdr, units,
+                     longrows);
   // unit / multi counts live on the device: a bounded number of persistent unit blocks stride over the table
-  const int rows_per_block = (kBlock / kWave) * kRowsPerWave;
-  const int64_t nbr = (a.M + rows_per_block - 1) / rows_per_block;
   const int64_t ub = (L.max_units + 3) / 4;
-#ifndef DGS_NBU
-#define DGS_NBU 1024
-#endif
   const int nbu = (int)(ub < DGS_NBU ? (ub < 1 ? 1 : ub) : DGS_NBU);
   hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
-                     a.st, (int)a.M, (int)a.N, L.ch, nbu, a.rowptr, a.col, a.val, a.B, a.C, a.E, hdr, units, part,
-                     parte);
-  // combine: one 64-descriptor chunk per wave is plenty of parallelism for its short dependent chains
-  const int64_t cb = (L.max_units + 255) / 256;
+                     a.st, (int)a.M, (int)a.N, nbu, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
+  // combine: one wave per multi-unit row
+  const int64_t cb = (L.max_long + 3) / 4;
   const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
   hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B, a.C,
-                     a.E, hdr, units, part, parte);
+                     a.E, ut, part, parte);
   return check_launch();
 }
 

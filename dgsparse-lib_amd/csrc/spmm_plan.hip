@@ -1,0 +1,363 @@
+// spmm_plan.hip -- the cached locality plan of the row-stream SpMM schedule (built once per matrix, same lifetime as
+// the CSC view a Storage keeps; new design, no reference counterpart: the reference has no per-matrix state at all).
+//
+// Why: on a 1M x 1M power-law graph the fused kernel moves 4.8x the algorithmic bytes over the L2-miss path, which is
+// the bound (7.3 TB/s of 128-B fabric reads whatever the table size, experiments/gather_sizes.cpp); the only lever is
+// fewer misses.  58 % of that graph's nnz sit in rows longer than 64 nnz, which the schedule already cuts into units
+// whose partial rows are folded by spmm_combine.  Since the partials are paid for anyway, the units can be cut and
+// ordered for the memory system instead of in row order:
+//   * rows longer than `tslice` nnz are cut at COLUMN-SLICE boundaries (8 slices with equal reference counts, found
+//     from a column histogram), then into chunks of <= 256 nnz; every unit is keyed (slice, first column);
+//   * the unit table is sorted by that key and XCD x walks slice x front to back: its 4 MiB L2 only ever sees an
+//     eighth of the dense operand, and the units in flight on it at any time cover a narrow column window.
+// Values never depend on the plan beyond the (deterministic, fixed-tree) split of long rows, which the plan-free
+// schedule has as well; max/min (value, E) stay bit-exact because partials are still folded in position order.
+// Rows whose columns are not sorted are left whole-chunked (the cut needs sorted columns; any cut is CORRECT).
+//
+// Build = a handful of launches + three rocPRIM primitives on the caller's stream, in caller-provided memory.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "spmm_impl.h"
+
+namespace dgs {
+
+struct PlanWs {  // build-time counters (zeroed by the first memset)
+  int n_longlist;
+  int pad[3];
+};
+
+struct PlanWsLayout {
+  size_t off_cnt, off_cum, off_list, off_info, off_scan, off_keys_in, off_keys_out, off_units_in, off_tmp, tmp_bytes, total;
+  int64_t cap_long;
+};
+
+struct I4Plus {
+  __host__ __device__ int4 operator()(const int4 &a, const int4 &b) const {
+    return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+};
+
+static PlanWsLayout plan_ws_layout(int64_t K, int64_t nnz) {
+  auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+  const PlanLayout PL = plan_layout(nnz);
+  PlanWsLayout L;
+  L.cap_long = nnz / kT1 + 2;
+  size_t t1 = 0, t2 = 0, t3 = 0;
+  int *ip = nullptr;
+  int4 *i4 = nullptr;
+  unsigned long long *kp = nullptr;
+  (void)rocprim::exclusive_scan(nullptr, t1, ip, ip, 0, (size_t)(K + 1), rocprim::plus<int>(), nullptr, false);
+  (void)rocprim::exclusive_scan(nullptr, t2, i4, i4, make_int4(0, 0, 0, 0), (size_t)L.cap_long, I4Plus(), nullptr, false);
+  (void)rocprim::radix_sort_pairs(nullptr, t3, kp, kp, i4, i4, (size_t)PL.max_units, 0, 36, nullptr, false);
+  L.tmp_bytes = t1 > t2 ? (t1 > t3 ? t1 : t3) : (t2 > t3 ? t2 : t3);
+  size_t o = up(sizeof(PlanWs));
+  L.off_cnt = o;          o += up((size_t)(K + 1) * 4);
+  L.off_cum = o;          o += up((size_t)(K + 1) * 4);
+  L.off_list = o;         o += up((size_t)L.cap_long * 4);
+  L.off_info = o;         o += up((size_t)L.cap_long * 16);
+  L.off_scan = o;         o += up((size_t)L.cap_long * 16);
+  L.off_keys_in = o;      o += up((size_t)PL.max_units * 8);
+  L.off_keys_out = o;     o += up((size_t)PL.max_units * 8);
+  L.off_units_in = o;     o += up((size_t)PL.max_units * 16);
+  L.off_tmp = o;          o += up(L.tmp_bytes);
+  L.total = o + 256;
+  return L;
+}
+
+// ---- kernels ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void plan_hist(int nnz, const int *__restrict__ col, int *__restrict__ cnt) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  for (int p = i; p < nnz; p += gridDim.x * kBlock) atomicAdd(&cnt[col[p]], 1);
+}
+
+// slice boundaries: first column c with (references to columns < c) >= x * nnz / 8
+__global__ void plan_bounds(int K, int nnz, const int *__restrict__ cum, PlanHdr *__restrict__ hdr, int M, int ch, int t1,
+                            int tslice) {
+  const int x = threadIdx.x;
+  if (x == 0) {
+    hdr->magic = kPlanMagic;
+    hdr->version = 1;
+    hdr->M = M;
+    hdr->nnz = nnz;
+    hdr->K = K;
+    hdr->ch = ch;
+    hdr->t1 = t1;
+    hdr->tslice = tslice;
+    hdr->has_pcol = 0;
+  }
+  if (x > 8) return;
+  int b;
+  if (x == 0) b = 0;
+  else if (x == 8) b = INT_MAX;
+  else {
+    const long long tgt = (long long)nnz * x / 8;
+    int lo = 0, hi = K;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cum[mid] < tgt) lo = mid + 1; else hi = mid;
+    }
+    b = lo;
+  }
+  hdr->slice_bound[x] = b;
+}
+
+// rows longer than t1: appended to a list (order irrelevant: the unit table is sorted later)
+__global__ __launch_bounds__(kBlock) void plan_longlist(int M, int t1, const int *__restrict__ rowptr,
+                                                        PlanWs *__restrict__ pw, int *__restrict__ list) {
+  __shared__ int s_wsum[kBlock / kWave];
+  __shared__ int s_base;
+  const int r = blockIdx.x * kBlock + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool is_long = r < M && (rowptr[r + 1] - rowptr[r]) > t1;
+  const unsigned long long m = __ballot(is_long);
+  const int before = __popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) s_wsum[wave] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < kBlock / kWave; w++) tot += s_wsum[w];
+    s_base = tot ? atomicAdd(&pw->n_longlist, tot) : 0;
+  }
+  __syncthreads();
+  if (!is_long) return;
+  int off = s_base + before;
+  for (int w = 0; w < wave; w++) off += s_wsum[w];
+  list[off] = r;
+}
+
+// position of the first entry of sorted row segment [rs,re) with column >= bound
+__device__ __forceinline__ int seg_lower_bound(const int *__restrict__ col, int rs, int re, int bound) {
+  int lo = rs, hi = re;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (col[mid] < bound) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// One wave per long row: is it cut at slice boundaries (long enough AND sorted)?  how many units?
+// info[i] = {units, units that need a partial slot (0 for a single-unit row), 1 if multi-unit, sliced flag}
+__global__ __launch_bounds__(kBlock) void plan_rowunits(int ch, int tslice, const int *__restrict__ rowptr,
+                                                        const int *__restrict__ col, const PlanWs *__restrict__ pw,
+                                                        const PlanHdr *__restrict__ hdr, const int *__restrict__ list,
+                                                        int4 *__restrict__ info) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = pw->n_longlist;
+  for (int i = blockIdx.x * (kBlock / kWave) + wave; i < n; i += gridDim.x * (kBlock / kWave)) {
+    const int r = list[i];
+    const int rs = rowptr[r], re = rowptr[r + 1];
+    bool sliced = (re - rs) > tslice;
+    if (sliced) {
+      bool ok = true;
+      for (int p = rs + lane; p + 1 < re; p += kWave) ok &= col[p] <= col[p + 1];
+      sliced = __ballot(!ok) == 0ull;
+    }
+    int nu;
+    if (sliced) {
+      int mine = 0;
+      if (lane < 8) {
+        const int a = lane == 0 ? rs : seg_lower_bound(col, rs, re, hdr->slice_bound[lane]);
+        const int b = lane == 7 ? re : seg_lower_bound(col, rs, re, hdr->slice_bound[lane + 1]);
+        mine = (b - a + ch - 1) / ch;
+      }
+      for (int d = 1; d < 8; d <<= 1) mine += __shfl_xor(mine, d, 64);
+      nu = __shfl(mine, 0, 64);
+    } else {
+      nu = (re - rs + ch - 1) / ch;
+    }
+    if (lane == 0) info[i] = make_int4(nu, nu > 1 ? nu : 0, nu > 1 ? 1 : 0, sliced ? 1 : 0);
+  }
+}
+
+__global__ void plan_totals(const PlanWs *__restrict__ pw, const int4 *__restrict__ info, const int4 *__restrict__ scan,
+                            PlanHdr *__restrict__ hdr) {
+  const int n = pw->n_longlist;
+  int4 t = make_int4(0, 0, 0, 0);
+  if (n > 0) t = I4Plus()(scan[n - 1], info[n - 1]);
+  hdr->n_units = t.x;
+  hdr->n_pslots = t.y;
+  hdr->n_long = t.z;
+}
+
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+
+// One wave per long row: write its units (+ sort keys) and, for a multi-unit row, its long-row entry.
+__global__ __launch_bounds__(kBlock) void plan_emit(int ch, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                    const PlanWs *__restrict__ pw, const PlanHdr *__restrict__ hdr,
+                                                    const int *__restrict__ list, const int4 *__restrict__ info,
+                                                    const int4 *__restrict__ scan, int4 *__restrict__ units,
+                                                    unsigned long long *__restrict__ keys, int4 *__restrict__ longrows) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = pw->n_longlist;
+  for (int i = blockIdx.x * (kBlock / kWave) + wave; i < n; i += gridDim.x * (kBlock / kWave)) {
+    const int r = list[i];
+    const int4 inf = info[i], sc = scan[i];  // sc = {first unit, first partial slot, long-row index, -}
+    const int rs = rowptr[r], re = rowptr[r + 1];
+    const int nu = inf.x;
+    if (lane == 0 && nu > 1) longrows[sc.z] = make_int4(r, sc.y, nu, 0);
+    if (inf.w) {
+      // segment s = [a_s, b_s); units of segment s start at unit index ub_s (exclusive prefix of the per-segment counts)
+      int a = 0, cntu = 0;
+      if (lane < 8) {
+        a = lane == 0 ? rs : seg_lower_bound(col, rs, re, hdr->slice_bound[lane]);
+        const int b = lane == 7 ? re : seg_lower_bound(col, rs, re, hdr->slice_bound[lane + 1]);
+        cntu = (b - a + ch - 1) / ch;
+      }
+      int incl = cntu;
+      for (int d = 1; d < 8; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+      }
+      const int excl = incl - cntu;
+      int sa8[9], ex8[8], cn8[8];  // every lane holds all eight segments (shuffles need all lanes active)
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        sa8[q] = __shfl(a, q, 64);
+        ex8[q] = __shfl(excl, q, 64);
+        cn8[q] = __shfl(cntu, q, 64);
+      }
+      sa8[8] = re;
+      for (int k = lane; k < nu; k += kWave) {
+        int seg = 0;  // the segment that holds unit k: the last one with units and a first unit <= k
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          if (cn8[q] > 0 && ex8[q] <= k) seg = q;
+        int sa = sa8[0], sb = sa8[1], se = ex8[0];
+#pragma unroll
+        for (int q = 1; q < 8; q++)
+          if (seg == q) {
+            sa = sa8[q];
+            sb = sa8[q + 1];
+            se = ex8[q];
+          }
+        const int p0 = sa + (k - se) * ch;
+        const int len = min(ch, sb - p0);
+        units[sc.x + k] = make_int4(r, p0, len, nu > 1 ? sc.y + k : -1);
+        keys[sc.x + k] = ((unsigned long long)seg << 32) | (unsigned)col[p0];
+      }
+    } else {
+      for (int k = lane; k < nu; k += kWave) {
+        const int p0 = rs + k * ch;
+        units[sc.x + k] = make_int4(r, p0, min(ch, re - p0), nu > 1 ? sc.y + k : -1);
+        keys[sc.x + k] = ((unsigned long long)(hash32((unsigned)r * 31u + (unsigned)k) & 7u) << 32) | (unsigned)col[p0];
+      }
+    }
+  }
+}
+
+__global__ void plan_xcd(const unsigned long long *__restrict__ keys, PlanHdr *__restrict__ hdr) {
+  const int x = threadIdx.x;
+  if (x > 8) return;
+  const int n = hdr->n_units;
+  int lo = 0, hi = n;  // first unit whose slice >= x
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((keys[mid] >> 32) < (unsigned long long)x) lo = mid + 1; else hi = mid;
+  }
+  hdr->xcd_start[x] = lo;
+}
+
+}  // namespace dgs
+
+using namespace dgs;
+
+static int plan_tslice() {
+  int t = env_int("DGS_PLAN_TSLICE", 256);
+  if (t < kPlanSliceMin) t = kPlanSliceMin;
+  return t;
+}
+
+extern "C" size_t dgs_spmm_plan_bytes(int64_t M, int64_t K, int64_t nnz) {
+  (void)M;
+  (void)K;
+  if (nnz <= 0) return 256;
+  return plan_layout(nnz).total;
+}
+
+extern "C" size_t dgs_spmm_plan_workspace_bytes(int64_t M, int64_t K, int64_t nnz) {
+  (void)M;
+  if (nnz <= 0 || K <= 0) return 256;
+  return plan_ws_layout(K, nnz).total;
+}
+
+extern "C" int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                                   void *plan, size_t plan_bytes, void *workspace, size_t workspace_bytes,
+                                   dgsSpmmPlanInfo *info, dgsStream_t stream) {
+  if (M <= 0 || K <= 0 || nnz <= 0 || !rowptr || !col || !plan || !workspace) return DGS_EINVAL;
+  if (M >= INT32_MAX || K >= INT32_MAX || nnz >= INT32_MAX) return DGS_ERANGE;
+  const PlanLayout PL = plan_layout(nnz);
+  const PlanWsLayout WL = plan_ws_layout(K, nnz);
+  if (plan_bytes < PL.total || workspace_bytes < WL.total) return DGS_EWORKSPACE;
+  if (!is_aligned16(plan) || !is_aligned16(workspace)) return DGS_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char *pb = static_cast<char *>(plan), *ws = static_cast<char *>(workspace);
+  PlanHdr *hdr = reinterpret_cast<PlanHdr *>(pb);
+  int4 *units = reinterpret_cast<int4 *>(pb + PL.off_units);
+  int4 *longrows = reinterpret_cast<int4 *>(pb + PL.off_long);
+  PlanWs *pw = reinterpret_cast<PlanWs *>(ws);
+  int *cnt = reinterpret_cast<int *>(ws + WL.off_cnt);
+  int *cum = reinterpret_cast<int *>(ws + WL.off_cum);
+  int *list = reinterpret_cast<int *>(ws + WL.off_list);
+  int4 *rinfo = reinterpret_cast<int4 *>(ws + WL.off_info);
+  int4 *rscan = reinterpret_cast<int4 *>(ws + WL.off_scan);
+  unsigned long long *keys_in = reinterpret_cast<unsigned long long *>(ws + WL.off_keys_in);
+  unsigned long long *keys_out = reinterpret_cast<unsigned long long *>(ws + WL.off_keys_out);
+  int4 *units_in = reinterpret_cast<int4 *>(ws + WL.off_units_in);
+  void *tmp = ws + WL.off_tmp;
+  const int ch = kPlanCh, tslice = plan_tslice();
+
+  if (hipMemsetAsync(hdr, 0, 256, st) != hipSuccess) return DGS_ELAUNCH;
+  if (hipMemsetAsync(ws, 0, WL.off_list, st) != hipSuccess) return DGS_ELAUNCH;           // counters, cnt, cum
+  if (hipMemsetAsync(rinfo, 0, (size_t)WL.cap_long * 16, st) != hipSuccess) return DGS_ELAUNCH;
+  if (hipMemsetAsync(keys_in, 0xFF, (size_t)PL.max_units * 8, st) != hipSuccess) return DGS_ELAUNCH;  // unused = last
+  if (hipMemsetAsync(units_in, 0, (size_t)PL.max_units * 16, st) != hipSuccess) return DGS_ELAUNCH;
+
+  hipLaunchKernelGGL(plan_hist, dim3(2048), dim3(kBlock), 0, st, (int)nnz, col, cnt);
+  size_t tb = WL.tmp_bytes;
+  if (rocprim::exclusive_scan(tmp, tb, cnt, cum, 0, (size_t)(K + 1), rocprim::plus<int>(), st, false) != hipSuccess)
+    return DGS_ELAUNCH;
+  hipLaunchKernelGGL(plan_bounds, dim3(1), dim3(64), 0, st, (int)K, (int)nnz, cum, hdr, (int)M, ch, kT1, tslice);
+  hipLaunchKernelGGL(plan_longlist, dim3((unsigned)((M + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int)M, kT1, rowptr,
+                     pw, list);
+  hipLaunchKernelGGL(plan_rowunits, dim3(1024), dim3(kBlock), 0, st, ch, tslice, rowptr, col, pw, hdr, list, rinfo);
+  tb = WL.tmp_bytes;
+  if (rocprim::exclusive_scan(tmp, tb, rinfo, rscan, make_int4(0, 0, 0, 0), (size_t)WL.cap_long, I4Plus(), st, false) !=
+      hipSuccess)
+    return DGS_ELAUNCH;
+  hipLaunchKernelGGL(plan_totals, dim3(1), dim3(1), 0, st, pw, rinfo, rscan, hdr);
+  hipLaunchKernelGGL(plan_emit, dim3(1024), dim3(kBlock), 0, st, ch, rowptr, col, pw, hdr, list, rinfo, rscan, units_in,
+                     keys_in, longrows);
+  tb = WL.tmp_bytes;
+  if (rocprim::radix_sort_pairs(tmp, tb, keys_in, keys_out, units_in, units, (size_t)PL.max_units, 0, 36, st, false) !=
+      hipSuccess)
+    return DGS_ELAUNCH;
+  hipLaunchKernelGGL(plan_xcd, dim3(1), dim3(64), 0, st, keys_out, hdr);
+  if (check_launch() != DGS_OK) return DGS_ELAUNCH;
+  if (info) {  // the counts the host needs to size grids and the partial-row workspace: one blocking copy, once per plan
+    PlanHdr h;
+    if (hipMemcpyAsync(&h, hdr, sizeof(PlanHdr), hipMemcpyDeviceToHost, st) != hipSuccess) return DGS_ELAUNCH;
+    if (hipStreamSynchronize(st) != hipSuccess) return DGS_ELAUNCH;
+    info->n_units = h.n_units;
+    info->n_long = h.n_long;
+    info->n_pslots = h.n_pslots;
+    info->has_pcol = h.has_pcol;
+    info->tslice = h.tslice;
+    for (int x = 0; x < 9; x++) info->xcd_start[x] = h.xcd_start[x];
+  }
+  return DGS_OK;
+}
+
+extern "C" size_t dgs_spmm_csr_plan_workspace_bytes(int reduce_op, int64_t M, int64_t N, int64_t nnz,
+                                                    const dgsSpmmPlanInfo *info) {
+  if (M <= 0 || N <= 0 || nnz <= 0 || !info) return 0;
+  return ws_layout_plan(reduce_op, N, info->n_pslots).total;
+}

@@ -49,6 +49,34 @@ extern "C" int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, 
   return run(fm, a);
 }
 
+// SpMM over a cached plan (spmm_plan.hip).  Shapes that do not take the row-stream schedule ignore the plan.
+extern "C" int dgs_spmm_csr_plan_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,
+                                     const int32_t *col, const float *val, const float *B, float *C, int32_t *E,
+                                     const void *plan, const dgsSpmmPlanInfo *info, void *workspace,
+                                     size_t workspace_bytes, dgsStream_t stream) {
+  if (reduce_op < DGS_SUM || reduce_op > DGS_MEAN || M < 0 || K < 0 || N < 0 || nnz < 0) return DGS_EINVAL;
+  if (M >= INT32_MAX || K >= INT32_MAX || N >= INT32_MAX || nnz >= INT32_MAX) return DGS_ERANGE;
+  if (!plan || !info || M == 0 || N == 0 || nnz == 0 || tiny_problem(M, nnz) ||
+      dgs_spmm_csr_schedule(reduce_op, M, K, N, nnz) != DGS_SCHED_ROWS)
+    return DGS_EINVAL;  // callers route such shapes to dgs_spmm_csr_f32
+  const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
+  if (!rowptr || !C || !col || !B || (arg && !E)) return DGS_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (E && !arg) {
+    if (hipMemsetAsync(E, 0xFF, (size_t)M * N * sizeof(int32_t), st) != hipSuccess) return DGS_ELAUNCH;
+  }
+  const size_t need = dgs_spmm_csr_plan_workspace_bytes(reduce_op, M, N, nnz, info);
+  if (!workspace || workspace_bytes < need) return DGS_EWORKSPACE;
+  const bool al = is_aligned16(B) && is_aligned16(C) && (!arg || is_aligned16(E)) && is_aligned16(workspace);
+  const FeatMap fm = feat_map(N, al);
+  SpmmArgs a{M, K, N, nnz, rowptr, col, val, B, C, arg ? E : nullptr, fm.tiles, workspace, st, reduce_op};
+  a.plan = static_cast<const PlanHdr *>(plan);
+  a.plan_units = info->n_units;
+  a.plan_long = info->n_long;
+  a.plan_pslots = info->n_pslots;
+  return run(fm, a);
+}
+
 // Masked SpMM (max/min backward w.r.t. the dense operand) on the CSC arrays: same launcher, internal op kOpMaskSum.
 extern "C" size_t dgs_spmm_csr_mask_workspace_bytes(int64_t Mout, int64_t N, int64_t nnz) {
   return dgs_spmm_csr_workspace_bytes(DGS_SUM, Mout, N, nnz);

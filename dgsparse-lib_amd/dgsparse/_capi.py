@@ -35,6 +35,26 @@ _lib.dgs_spmm_csr_schedule.restype = _int
 _lib.dgs_spmm_csr_schedule.argtypes = [_int, _i64, _i64, _i64, _i64]
 _lib.dgs_spmm_csr_f32.restype = _int
 _lib.dgs_spmm_csr_f32.argtypes = [_int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _sz, _vp]
+
+
+class PlanInfo(ctypes.Structure):
+    """dgsSpmmPlanInfo (include/dgsparse_hip.h)."""
+    _fields_ = [('n_units', ctypes.c_int32), ('n_long', ctypes.c_int32), ('n_pslots', ctypes.c_int32),
+                ('has_pcol', ctypes.c_int32), ('tslice', ctypes.c_int32), ('xcd_start', ctypes.c_int32 * 9),
+                ('reserved', ctypes.c_int32 * 2)]
+
+
+_lib.dgs_spmm_plan_bytes.restype = _sz
+_lib.dgs_spmm_plan_bytes.argtypes = [_i64, _i64, _i64]
+_lib.dgs_spmm_plan_workspace_bytes.restype = _sz
+_lib.dgs_spmm_plan_workspace_bytes.argtypes = [_i64, _i64, _i64]
+_lib.dgs_spmm_plan_build.restype = _int
+_lib.dgs_spmm_plan_build.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp, _sz, ctypes.POINTER(PlanInfo), _vp]
+_lib.dgs_spmm_csr_plan_workspace_bytes.restype = _sz
+_lib.dgs_spmm_csr_plan_workspace_bytes.argtypes = [_int, _i64, _i64, _i64, ctypes.POINTER(PlanInfo)]
+_lib.dgs_spmm_csr_plan_f32.restype = _int
+_lib.dgs_spmm_csr_plan_f32.argtypes = [_int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                       ctypes.POINTER(PlanInfo), _vp, _sz, _vp]
 _lib.dgs_spmm_csr_mask_f32.restype = _int
 _lib.dgs_spmm_csr_mask_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
 _lib.dgs_spmm_csr_mask_workspace_bytes.restype = _sz
@@ -63,6 +83,8 @@ _lib.dgs_scatter_add_rows_f32.restype = _int
 _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
 EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
+           'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes', 'dgs_spmm_plan_build',
+           'dgs_spmm_csr_plan_workspace_bytes', 'dgs_spmm_csr_plan_f32',
            'dgs_spmm_csr_schedule', 'dgs_spmm_arg_backward_f32', 'dgs_sddmm_csr_schedule',
            'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
            'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'dgs_sddmm_coo_f32', 'dgs_gspmm_csr_workspace_bytes', 'dgs_gspmm_csr_f32', 'gespmmCsrSpMM',
@@ -159,8 +181,47 @@ def _pad4(t):
     return out
 
 
-def spmm(reduce_op, rowptr, col, values, dense, algorithm=0, want_E=None):
-    """C = reduce(A (*) dense).  Returns (C, E) with E=None unless max/min (or want_E)."""
+class SpmmPlan:
+    """A cached locality plan (csrc/spmm_plan.hip): device tables + the host-side counts.  Depends on (rowptr, col)
+    only; never written by a call."""
+    __slots__ = ('buf', 'info', 'M', 'K', 'nnz', 'rowptr_ptr', 'col_ptr')
+
+    def __init__(self, buf, info, M, K, nnz, rowptr_ptr, col_ptr):
+        self.buf, self.info, self.M, self.K, self.nnz = buf, info, M, K, nnz
+        self.rowptr_ptr, self.col_ptr = rowptr_ptr, col_ptr
+
+    def __repr__(self):
+        i = self.info
+        return (f'SpmmPlan(M={self.M}, nnz={self.nnz}, units={i.n_units}, long_rows={i.n_long}, pslots={i.n_pslots}, '
+                f'tslice={i.tslice}, xcd_start={list(i.xcd_start)})')
+
+
+def spmm_plan(rowptr, col, K, N=64, force=False):
+    """Builds the locality plan of (rowptr, col) for a [K, N] dense operand, or returns None when the call would not
+    use one (small inputs take one launch, dense graphs the column-panel sweep; DGS_PLAN=0 disables plans).  Once per
+    matrix: ~10 launches + one host sync."""
+    dev = _need_gpu(rowptr, col)
+    rowptr = _i32(rowptr, 'rowptr')
+    col = _i32(col, 'col')
+    M, nnz = rowptr.numel() - 1, col.numel()
+    if os.environ.get('DGS_PLAN', '1') == '0' and not force:
+        return None
+    if M <= 0 or nnz <= 0 or _lib.dgs_spmm_csr_schedule(SUM, M, int(K), int(N), nnz) != 1:
+        return None
+    with _on_device(dev):
+        pb = _lib.dgs_spmm_plan_bytes(M, int(K), nnz)
+        wb = _lib.dgs_spmm_plan_workspace_bytes(M, int(K), nnz)
+        buf = torch.empty(pb, dtype=torch.uint8, device=dev)
+        ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+        info = PlanInfo()
+        _check(_lib.dgs_spmm_plan_build(M, int(K), nnz, _p(rowptr), _p(col), _p(buf), pb, _p(ws), wb,
+                                        ctypes.byref(info), _stream(dev)), 'spmm_plan_build')
+    return SpmmPlan(buf, info, M, int(K), nnz, rowptr.data_ptr(), col.data_ptr())
+
+
+def spmm(reduce_op, rowptr, col, values, dense, algorithm=0, want_E=None, plan=None):
+    """C = reduce(A (*) dense).  Returns (C, E) with E=None unless max/min (or want_E).  ``plan``: a SpmmPlan of
+    exactly these (rowptr, col) arrays (shapes that do not take the row-stream schedule ignore it)."""
     dev = _need_gpu(rowptr, col, values, dense)
     rowptr = _i32(rowptr, 'rowptr')
     col = _i32(col, 'col')
@@ -178,7 +239,17 @@ def spmm(reduce_op, rowptr, col, values, dense, algorithm=0, want_E=None):
     arg = reduce_op in (MAX, MIN) if want_E is None else want_E
     out = torch.empty((M, N), dtype=torch.float32, device=dev)
     E = torch.empty((M, N), dtype=torch.int32, device=dev) if arg else None
+    if plan is not None and (plan.M != M or plan.nnz != nnz or plan.col_ptr != col.data_ptr() or
+                             plan.rowptr_ptr != rowptr.data_ptr()):
+        raise ValueError('dgsparse: the plan was built for other (rowptr, col) arrays')
     with _on_device(dev):
+        if plan is not None and _lib.dgs_spmm_csr_schedule(int(reduce_op), M, K, N, nnz) == 1:
+            wsb = _lib.dgs_spmm_csr_plan_workspace_bytes(reduce_op, M, N, nnz, ctypes.byref(plan.info))
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            _check(_lib.dgs_spmm_csr_plan_f32(reduce_op, M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(dense),
+                                              _p(out), _p(E), _p(plan.buf), ctypes.byref(plan.info), _p(ws), wsb,
+                                              _stream(dev)), 'spmm_plan')
+            return out, E
         wsb = _lib.dgs_spmm_csr_workspace_bytes(reduce_op, M, N, nnz)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
         _check(_lib.dgs_spmm_csr_f32(reduce_op, M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(dense), _p(out),

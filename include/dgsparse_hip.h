@@ -77,6 +77,42 @@ int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz
 int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz);
 
 /*
+ * Cached locality plan of the row-stream schedule (new; the reference keeps no per-matrix state - the closest thing is
+ * the CSC view dgsparse/storage.py:159-174 computes once per Storage, and the plan has the same lifetime).
+ * dgs_spmm_plan_build() analyses the sparsity pattern once (column histogram -> 8 column slices with equal reference
+ * counts; rows longer than 256 nnz are cut at slice boundaries; the unit table is sorted by (slice, first column)) and
+ * dgs_spmm_csr_plan_f32() then runs the SAME kernels as dgs_spmm_csr_f32 over the plan's tables: XCD x walks column
+ * slice x, so its L2 sees an eighth of the dense operand, and the call needs no classify pass and no memset.
+ * The plan depends on (rowptr, col) only - not on values, N or the reduce op - and is never written by a call, so one
+ * plan may serve concurrent calls on different streams.  Results obey the same contract as the plan-free call (the
+ * split points of long rows differ, so sum/mean of rows > 64 nnz may differ in the last bits between the two; max/min
+ * values and E are identical).  Graphs that take the SMALL or PANEL schedule ignore the plan.
+ *   plan       dgs_spmm_plan_bytes() bytes of device memory, 256-B aligned, owned by the caller;
+ *   workspace  dgs_spmm_plan_workspace_bytes() bytes, only during the build;
+ *   info       host struct filled by the build (it blocks on `stream` once for that); pass it back to the calls.
+ */
+typedef struct dgsSpmmPlanInfo {
+  int32_t n_units;      /* entries of the unit table */
+  int32_t n_long;       /* multi-unit rows */
+  int32_t n_pslots;     /* partial rows a call needs in its workspace */
+  int32_t has_pcol;     /* 1 when the plan carries hot-column classes for the row stream */
+  int32_t tslice;       /* rows longer than this were cut at column-slice boundaries */
+  int32_t xcd_start[9]; /* first unit of each XCD's share */
+  int32_t reserved[2];
+} dgsSpmmPlanInfo;
+size_t dgs_spmm_plan_bytes(int64_t M, int64_t K, int64_t nnz);
+size_t dgs_spmm_plan_workspace_bytes(int64_t M, int64_t K, int64_t nnz);
+int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int32_t *rowptr, const int32_t *col, void *plan,
+                        size_t plan_bytes, void *workspace, size_t workspace_bytes, dgsSpmmPlanInfo *info,
+                        dgsStream_t stream);
+size_t dgs_spmm_csr_plan_workspace_bytes(int reduce_op, int64_t M, int64_t N, int64_t nnz,
+                                         const dgsSpmmPlanInfo *info);
+int dgs_spmm_csr_plan_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,
+                          const int32_t *col, const float *val, const float *B, float *C, int32_t *E,
+                          const void *plan, const dgsSpmmPlanInfo *info, void *workspace, size_t workspace_bytes,
+                          dgsStream_t stream);
+
+/*
  * Masked SpMM = backward of max/min w.r.t. the dense operand, run on the CSC arrays of A:
  *   out[j,:] = sum_{p in [ptr[j],ptr[j+1])} [E[idx[p],:] == j] * val[p] * G[idx[p],:]
  * Replaces: spmm_cuda_with_mask(), src/cuda/spmm_cuda.cu:255-303 /
