@@ -28,7 +28,12 @@ warnings.filterwarnings('ignore', message='Sparse CSR tensor support is in beta'
 OPS = {'sum': dgsparse.spmm_sum, 'max': dgsparse.spmm_max, 'min': dgsparse.spmm_min, 'mean': dgsparse.spmm_mean}
 
 
-def clock(fn, warm=10, iters=100):
+ITERS = 100
+
+
+def clock(fn, warm=10, iters=None):
+    iters = ITERS if iters is None else iters
+    warm = min(warm, iters)
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -44,7 +49,11 @@ def main():
     ap.add_argument('--datasets', nargs='+', default=['cora', 'citeseer', 'pubmed', 'ppi0'])
     ap.add_argument('--feats', nargs='+', type=int, default=[32, 64, 128])
     ap.add_argument('--json', default='')
+    ap.add_argument('--iters', type=int, default=100, help='timed iterations (the reference uses 100)')
+    ap.add_argument('--no-baseline', action='store_true', help='skip the torch.sparse.mm (hipSPARSE) comparison')
     a = ap.parse_args()
+    global ITERS
+    ITERS = a.iters
     rows = []
     for name in a.datasets:
         rp, col, st = graphgen.dataset_shaped(name, seed=0, device='cuda', as_torch=True)
@@ -65,10 +74,12 @@ def main():
 
                 bwd = clock(fb)
                 row = dict(dataset=name, nodes=st['M'], nnz=st['nnz'], feat=N, reduce=red,
-                           dgsparse_fwd_s_per_100=round(fwd, 6), dgsparse_fwdbwd_s_per_100=round(bwd, 6))
-                if red == 'sum':
+                           iters=ITERS,
+                           dgsparse_fwd_s_per_100=round(fwd * 100 / ITERS, 6),
+                           dgsparse_fwdbwd_s_per_100=round(bwd * 100 / ITERS, 6))
+                if red == 'sum' and not a.no_baseline:
                     Xd = X.detach()
-                    row['torch_sparse_mm_fwd_s_per_100'] = round(clock(lambda: torch.sparse.mm(tcsr, Xd)), 6)
+                    row['torch_sparse_mm_fwd_s_per_100'] = round(clock(lambda: torch.sparse.mm(tcsr, Xd)) * 100 / ITERS, 6)
                 rows.append(row)
                 print(json.dumps(row), flush=True)
     if a.json:

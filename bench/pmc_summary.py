@@ -14,15 +14,19 @@ def main(dirs):
         for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
             per_dispatch = defaultdict(float)
             names = {}
+            dur = {}
             for row in csv.DictReader(open(f)):
                 k = row.get('Kernel_Name', '')
                 if 'dgs::' not in k:
                     continue
                 key = (row['Dispatch_Id'], row['Counter_Name'])
                 per_dispatch[key] += float(row['Counter_Value'])
-                names[row['Dispatch_Id']] = k.split('(')[0].replace('void ', '')
+                names[row['Dispatch_Id']] = k.split('(')[0].replace('void ', '') + f"  [grid {row.get('Grid_Size', '?')}]"
+                dur[row['Dispatch_Id']] = (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3
             for (did, cn), v in per_dispatch.items():
                 acc[names[did]][cn].append(v)
+            for did, us in dur.items():
+                acc[names[did]]['~duration_us(profiled)'].append(us)
     for k in sorted(acc):
         print(k)
         for cn in sorted(acc[k]):

@@ -141,20 +141,25 @@ static inline WsLayout ws_layout_plan(int reduce_op, int64_t N, int64_t pslots) 
   L.total = prow + (arg ? prow : 0) + 256;
   return L;
 }
-// plan buffer: [256-byte header][units: max_units int4][long rows: max_long int4][pcol: nnz int32]; the capacities
+// plan buffer: [256-byte header][column grid: 129 ints][units: max_units int4][long rows: max_long int4][pcol: nnz
+// int32]; the capacities
 // (and so the offsets) are a pure function of nnz, the actual counts live in the header
 constexpr int kPlanCh = 256;          // unit length of the plan's unit table
-constexpr int kPlanSliceMin = 128;    // smallest row length that may be cut at column-slice boundaries
+constexpr int kPlanSliceMin = 128;    // smallest row length that may be cut on the column grid
+constexpr int kPlanUnitMin = 16;      // smallest nnz-per-cell target of a cut row
+constexpr int kPlanCells = 128;       // finest column grid: 8 slices (one per XCD) x 16 cells
 struct PlanLayout {
   int64_t max_units, max_long;
-  size_t off_units, off_long, off_pcol, total;
+  size_t off_bounds, off_units, off_long, off_pcol, total;
 };
 static inline PlanLayout plan_layout(int64_t nnz) {
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
   PlanLayout L;
-  L.max_units = nnz / kT1 + 8 * (nnz / kPlanSliceMin) + nnz / kPlanCh + 16;
+  // a cut row of L nnz has at most max(8, L / kPlanUnitMin) cells, each with one ragged unit, plus L / ch full ones
+  L.max_units = nnz / kT1 + 8 * (nnz / kPlanSliceMin) + nnz / kPlanUnitMin + nnz / kPlanCh + 16;
   L.max_long = nnz / kPlanSliceMin + nnz / kPlanCh + 2;
-  L.off_units = 256;
+  L.off_bounds = 256;
+  L.off_units = 256 + 768;  // (kPlanCells + 1) ints
   L.off_long = L.off_units + up((size_t)L.max_units * sizeof(int4));
   L.off_pcol = L.off_long + up((size_t)L.max_long * sizeof(int4));
   L.total = L.off_pcol + up((size_t)nnz * sizeof(int)) + 256;
@@ -898,7 +903,7 @@ struct PlanHdr {
   int magic, version;
   int M, nnz, K;
   int n_units, n_long, n_pslots;
-  int ch, t1, tslice;
+  int ch, t1, tslice, unit;
   int xcd_start[9];     // first unit of each XCD's share of the (sorted) unit table
   int slice_bound[9];   // column-slice boundaries (slice x = columns [b[x], b[x+1]))
   int hot_thr[4];       // reference-count thresholds of the hot classes stored in pcol bits 28..30
@@ -1038,6 +1043,12 @@ static int launch_all(const SpmmArgs &a) {
     int64_t ub = ((int64_t)a.plan_units + 3) / 4;
     ub = (ub + 7) & ~int64_t(7);  // a multiple of 8 so that the XCD mapping of the unit blocks applies
     const int nbu = (int)(ub < DGS_NBU ? (ub < 8 ? 8 : ub) : DGS_NBU);
+    if (env_int("DGS_SPLIT", 0)) {  // experiment: unit blocks and row blocks as two launches (no L2 sharing in time)
+      hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)nbu, (unsigned)a.tiles), dim3(kBlock), 0, a.st,
+                         (int)a.M, (int)a.N, nbu, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
+      hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)nbr, (unsigned)a.tiles), dim3(kBlock), 0, a.st,
+                         (int)a.M, (int)a.N, 0, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
+    } else
     hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
                        a.st, (int)a.M, (int)a.N, nbu, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
     if (a.plan_long > 0) {

@@ -72,27 +72,30 @@ __global__ __launch_bounds__(kBlock) void plan_hist(int nnz, const int *__restri
   for (int p = i; p < nnz; p += gridDim.x * kBlock) atomicAdd(&cnt[col[p]], 1);
 }
 
-// slice boundaries: first column c with (references to columns < c) >= x * nnz / 8
-__global__ void plan_bounds(int K, int nnz, const int *__restrict__ cum, PlanHdr *__restrict__ hdr, int M, int ch, int t1,
-                            int tslice) {
+// Column grid: kPlanCells cells with equal reference counts; bounds[c] = first column with (references to columns
+// below it) >= c * nnz / kPlanCells.  8 slices (one per XCD) of kPlanCells/8 cells each; a row is cut on the grid at a
+// level that leaves it about `unit` nnz per cell: level j = (8 << j) cells, each the union of (16 >> j) finest cells.
+__global__ void plan_bounds(int K, int nnz, const int *__restrict__ cum, PlanHdr *__restrict__ hdr, int *__restrict__ bounds,
+                            int M, int ch, int t1, int tslice, int unit) {
   const int x = threadIdx.x;
   if (x == 0) {
     hdr->magic = kPlanMagic;
-    hdr->version = 1;
+    hdr->version = 2;
     hdr->M = M;
     hdr->nnz = nnz;
     hdr->K = K;
     hdr->ch = ch;
     hdr->t1 = t1;
     hdr->tslice = tslice;
+    hdr->unit = unit;
     hdr->has_pcol = 0;
   }
-  if (x > 8) return;
+  if (x > kPlanCells) return;
   int b;
   if (x == 0) b = 0;
-  else if (x == 8) b = INT_MAX;
+  else if (x == kPlanCells) b = INT_MAX;
   else {
-    const long long tgt = (long long)nnz * x / 8;
+    const long long tgt = (long long)nnz * x / kPlanCells;
     int lo = 0, hi = K;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
@@ -100,7 +103,8 @@ __global__ void plan_bounds(int K, int nnz, const int *__restrict__ cum, PlanHdr
     }
     b = lo;
   }
-  hdr->slice_bound[x] = b;
+  bounds[x] = b;
+  if ((x & (kPlanCells / 8 - 1)) == 0) hdr->slice_bound[x / (kPlanCells / 8)] = b;
 }
 
 // rows longer than t1: appended to a list (order irrelevant: the unit table is sorted later)
@@ -137,11 +141,45 @@ __device__ __forceinline__ int seg_lower_bound(const int *__restrict__ col, int 
   return lo;
 }
 
-// One wave per long row: is it cut at slice boundaries (long enough AND sorted)?  how many units?
-// info[i] = {units, units that need a partial slot (0 for a single-unit row), 1 if multi-unit, sliced flag}
-__global__ __launch_bounds__(kBlock) void plan_rowunits(int ch, int tslice, const int *__restrict__ rowptr,
+// grid level of a sliced row: the finest one that still leaves about `unit` nnz per cell
+__device__ __forceinline__ int row_level(int len, int unit) {
+  int j = 0;
+  while (j < 4 && (len >> (j + 1)) >= 8 * unit) j++;
+  return j;
+}
+
+// The cut of a sorted row [rs,re) on level j, spread over the wave: lane l owns cells 2l and 2l+1 (of nc = 8 << j).
+// p0/p1/p2 = first nnz of cell 2l, of cell 2l+1, of cell 2l+2; n0/n1 = units of the two cells; excl = units of the row
+// before this lane's cells.  Returns the row's unit count.  All 64 lanes must be active.
+struct RowCut {
+  int p0, p1, p2, n0, n1, excl;
+};
+__device__ __forceinline__ int cut_row(const int *__restrict__ col, const int *__restrict__ bounds, int rs, int re, int j,
+                                       int ch, int lane, RowCut &rc) {
+  const int nc = 8 << j, sh = 4 - j;
+  const int c0 = 2 * lane;
+  auto pos = [&](int c) { return c <= 0 ? rs : (c >= nc ? re : seg_lower_bound(col, rs, re, bounds[c << sh])); };
+  rc.p0 = pos(c0);
+  rc.p1 = pos(c0 + 1);
+  const int nxt = __shfl_down(rc.p0, 1, 64);
+  rc.p2 = (c0 + 2 >= nc) ? re : nxt;
+  rc.n0 = (rc.p1 - rc.p0 + ch - 1) / ch;
+  rc.n1 = (rc.p2 - rc.p1 + ch - 1) / ch;
+  int incl = rc.n0 + rc.n1;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  rc.excl = incl - rc.n0 - rc.n1;
+  return __shfl(incl, 63, 64);
+}
+
+// One wave per long row: is it cut on the column grid (long enough AND sorted)?  how many units?
+// info[i] = {units, units that need a partial slot (0 for a single-unit row), 1 if multi-unit, 1 + level if cut | 0}
+__global__ __launch_bounds__(kBlock) void plan_rowunits(int ch, int tslice, int unit, const int *__restrict__ rowptr,
                                                         const int *__restrict__ col, const PlanWs *__restrict__ pw,
-                                                        const PlanHdr *__restrict__ hdr, const int *__restrict__ list,
+                                                        const int *__restrict__ bounds, const int *__restrict__ list,
                                                         int4 *__restrict__ info) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = pw->n_longlist;
@@ -154,20 +192,15 @@ __global__ __launch_bounds__(kBlock) void plan_rowunits(int ch, int tslice, cons
       for (int p = rs + lane; p + 1 < re; p += kWave) ok &= col[p] <= col[p + 1];
       sliced = __ballot(!ok) == 0ull;
     }
-    int nu;
+    int nu, lvl = 0;
     if (sliced) {
-      int mine = 0;
-      if (lane < 8) {
-        const int a = lane == 0 ? rs : seg_lower_bound(col, rs, re, hdr->slice_bound[lane]);
-        const int b = lane == 7 ? re : seg_lower_bound(col, rs, re, hdr->slice_bound[lane + 1]);
-        mine = (b - a + ch - 1) / ch;
-      }
-      for (int d = 1; d < 8; d <<= 1) mine += __shfl_xor(mine, d, 64);
-      nu = __shfl(mine, 0, 64);
+      lvl = row_level(re - rs, unit);
+      RowCut rc;
+      nu = cut_row(col, bounds, rs, re, lvl, ch, lane, rc);
     } else {
       nu = (re - rs + ch - 1) / ch;
     }
-    if (lane == 0) info[i] = make_int4(nu, nu > 1 ? nu : 0, nu > 1 ? 1 : 0, sliced ? 1 : 0);
+    if (lane == 0) info[i] = make_int4(nu, nu > 1 ? nu : 0, nu > 1 ? 1 : 0, sliced ? 1 + lvl : 0);
   }
 }
 
@@ -192,7 +225,7 @@ __device__ __forceinline__ unsigned hash32(unsigned x) {
 
 // One wave per long row: write its units (+ sort keys) and, for a multi-unit row, its long-row entry.
 __global__ __launch_bounds__(kBlock) void plan_emit(int ch, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                    const PlanWs *__restrict__ pw, const PlanHdr *__restrict__ hdr,
+                                                    const PlanWs *__restrict__ pw, const int *__restrict__ bounds,
                                                     const int *__restrict__ list, const int4 *__restrict__ info,
                                                     const int4 *__restrict__ scan, int4 *__restrict__ units,
                                                     unsigned long long *__restrict__ keys, int4 *__restrict__ longrows) {
@@ -205,44 +238,18 @@ __global__ __launch_bounds__(kBlock) void plan_emit(int ch, const int *__restric
     const int nu = inf.x;
     if (lane == 0 && nu > 1) longrows[sc.z] = make_int4(r, sc.y, nu, 0);
     if (inf.w) {
-      // segment s = [a_s, b_s); units of segment s start at unit index ub_s (exclusive prefix of the per-segment counts)
-      int a = 0, cntu = 0;
-      if (lane < 8) {
-        a = lane == 0 ? rs : seg_lower_bound(col, rs, re, hdr->slice_bound[lane]);
-        const int b = lane == 7 ? re : seg_lower_bound(col, rs, re, hdr->slice_bound[lane + 1]);
-        cntu = (b - a + ch - 1) / ch;
-      }
-      int incl = cntu;
-      for (int d = 1; d < 8; d <<= 1) {
-        const int t = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += t;
-      }
-      const int excl = incl - cntu;
-      int sa8[9], ex8[8], cn8[8];  // every lane holds all eight segments (shuffles need all lanes active)
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        sa8[q] = __shfl(a, q, 64);
-        ex8[q] = __shfl(excl, q, 64);
-        cn8[q] = __shfl(cntu, q, 64);
-      }
-      sa8[8] = re;
-      for (int k = lane; k < nu; k += kWave) {
-        int seg = 0;  // the segment that holds unit k: the last one with units and a first unit <= k
-#pragma unroll
-        for (int q = 0; q < 8; q++)
-          if (cn8[q] > 0 && ex8[q] <= k) seg = q;
-        int sa = sa8[0], sb = sa8[1], se = ex8[0];
-#pragma unroll
-        for (int q = 1; q < 8; q++)
-          if (seg == q) {
-            sa = sa8[q];
-            sb = sa8[q + 1];
-            se = ex8[q];
-          }
-        const int p0 = sa + (k - se) * ch;
-        const int len = min(ch, sb - p0);
-        units[sc.x + k] = make_int4(r, p0, len, nu > 1 ? sc.y + k : -1);
-        keys[sc.x + k] = ((unsigned long long)seg << 32) | (unsigned)col[p0];
+      const int j = inf.w - 1;
+      RowCut rc;
+      cut_row(col, bounds, rs, re, j, ch, lane, rc);
+      // units are numbered in position order (= column order of the sorted row): cell 2l first, then cell 2l+1
+      int k = rc.excl;
+      for (int q = 0; q < 2; q++) {
+        const int a = q ? rc.p1 : rc.p0, b = q ? rc.p2 : rc.p1;
+        const unsigned long long slice = (unsigned long long)((2 * lane + q) >> j);
+        for (int p0 = a; p0 < b; p0 += ch, k++) {
+          units[sc.x + k] = make_int4(r, p0, min(ch, b - p0), nu > 1 ? sc.y + k : -1);
+          keys[sc.x + k] = (slice << 32) | (unsigned)col[p0];
+        }
       }
     } else {
       for (int k = lane; k < nu; k += kWave) {
@@ -275,6 +282,11 @@ static int plan_tslice() {
   if (t < kPlanSliceMin) t = kPlanSliceMin;
   return t;
 }
+static int plan_unit() {  // nnz per cell a cut row should keep (decides how fine long rows are cut on the column grid)
+  int u = env_int("DGS_PLAN_UNIT", 32);
+  if (u < kPlanUnitMin) u = kPlanUnitMin;
+  return u;
+}
 
 extern "C" size_t dgs_spmm_plan_bytes(int64_t M, int64_t K, int64_t nnz) {
   (void)M;
@@ -301,6 +313,7 @@ extern "C" int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int3
   hipStream_t st = static_cast<hipStream_t>(stream);
   char *pb = static_cast<char *>(plan), *ws = static_cast<char *>(workspace);
   PlanHdr *hdr = reinterpret_cast<PlanHdr *>(pb);
+  int *bounds = reinterpret_cast<int *>(pb + PL.off_bounds);
   int4 *units = reinterpret_cast<int4 *>(pb + PL.off_units);
   int4 *longrows = reinterpret_cast<int4 *>(pb + PL.off_long);
   PlanWs *pw = reinterpret_cast<PlanWs *>(ws);
@@ -313,9 +326,9 @@ extern "C" int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int3
   unsigned long long *keys_out = reinterpret_cast<unsigned long long *>(ws + WL.off_keys_out);
   int4 *units_in = reinterpret_cast<int4 *>(ws + WL.off_units_in);
   void *tmp = ws + WL.off_tmp;
-  const int ch = kPlanCh, tslice = plan_tslice();
+  const int ch = kPlanCh, tslice = plan_tslice(), unit = plan_unit();
 
-  if (hipMemsetAsync(hdr, 0, 256, st) != hipSuccess) return DGS_ELAUNCH;
+  if (hipMemsetAsync(hdr, 0, PL.off_units, st) != hipSuccess) return DGS_ELAUNCH;
   if (hipMemsetAsync(ws, 0, WL.off_list, st) != hipSuccess) return DGS_ELAUNCH;           // counters, cnt, cum
   if (hipMemsetAsync(rinfo, 0, (size_t)WL.cap_long * 16, st) != hipSuccess) return DGS_ELAUNCH;
   if (hipMemsetAsync(keys_in, 0xFF, (size_t)PL.max_units * 8, st) != hipSuccess) return DGS_ELAUNCH;  // unused = last
@@ -325,16 +338,17 @@ extern "C" int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int3
   size_t tb = WL.tmp_bytes;
   if (rocprim::exclusive_scan(tmp, tb, cnt, cum, 0, (size_t)(K + 1), rocprim::plus<int>(), st, false) != hipSuccess)
     return DGS_ELAUNCH;
-  hipLaunchKernelGGL(plan_bounds, dim3(1), dim3(64), 0, st, (int)K, (int)nnz, cum, hdr, (int)M, ch, kT1, tslice);
+  hipLaunchKernelGGL(plan_bounds, dim3(1), dim3(192), 0, st, (int)K, (int)nnz, cum, hdr, bounds, (int)M, ch, kT1, tslice,
+                     unit);
   hipLaunchKernelGGL(plan_longlist, dim3((unsigned)((M + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int)M, kT1, rowptr,
                      pw, list);
-  hipLaunchKernelGGL(plan_rowunits, dim3(1024), dim3(kBlock), 0, st, ch, tslice, rowptr, col, pw, hdr, list, rinfo);
+  hipLaunchKernelGGL(plan_rowunits, dim3(1024), dim3(kBlock), 0, st, ch, tslice, unit, rowptr, col, pw, bounds, list, rinfo);
   tb = WL.tmp_bytes;
   if (rocprim::exclusive_scan(tmp, tb, rinfo, rscan, make_int4(0, 0, 0, 0), (size_t)WL.cap_long, I4Plus(), st, false) !=
       hipSuccess)
     return DGS_ELAUNCH;
   hipLaunchKernelGGL(plan_totals, dim3(1), dim3(1), 0, st, pw, rinfo, rscan, hdr);
-  hipLaunchKernelGGL(plan_emit, dim3(1024), dim3(kBlock), 0, st, ch, rowptr, col, pw, hdr, list, rinfo, rscan, units_in,
+  hipLaunchKernelGGL(plan_emit, dim3(1024), dim3(kBlock), 0, st, ch, rowptr, col, pw, bounds, list, rinfo, rscan, units_in,
                      keys_in, longrows);
   tb = WL.tmp_bytes;
   if (rocprim::radix_sort_pairs(tmp, tb, keys_in, keys_out, units_in, units, (size_t)PL.max_units, 0, 36, st, false) !=

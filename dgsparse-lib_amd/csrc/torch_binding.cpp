@@ -16,7 +16,6 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <hip/hip_runtime_api.h>
 
-#include <mutex>
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
 
@@ -53,11 +52,34 @@ dgsStream_t cur_stream() { return c10::hip::getCurrentHIPStreamMasqueradingAsCUD
 Tensor workspace(size_t bytes, const Tensor &like) {
   return at::empty({(int64_t)bytes}, like.options().dtype(at::kByte));
 }
+using OptTensor = c10::optional<Tensor>;
+bool has(const OptTensor &t) { return t.has_value() && t->defined(); }
+void same_device(const Tensor &a, const Tensor &b, const char *what) {
+  TORCH_CHECK(a.device() == b.device(), "dgsparse: ", what, " live on different devices (", a.device(), " vs ", b.device(), ")");
+}
+// A cached locality plan travels as two tensors: the device buffer (uint8) and the host-side counts (16 int32 on the
+// CPU = dgsSpmmPlanInfo).  dgsparse.Storage builds and keeps them (same lifetime as its CSC view).
+static_assert(sizeof(dgsSpmmPlanInfo) == 16 * sizeof(int32_t), "plan info layout");
+const dgsSpmmPlanInfo *plan_info(const OptTensor &plan, const OptTensor &info, const Tensor &rowptr) {
+  if (!has(plan) || !has(info)) return nullptr;
+  TORCH_CHECK(plan->is_cuda() && plan->scalar_type() == at::kByte && plan->is_contiguous(), "dgsparse: plan must be a contiguous uint8 GPU tensor");
+  TORCH_CHECK(!info->is_cuda() && info->scalar_type() == at::kInt && info->numel() == 16 && info->is_contiguous(),
+              "dgsparse: plan_info must be 16 int32 on the CPU");
+  same_device(*plan, rowptr, "plan and rowptr");
+  return reinterpret_cast<const dgsSpmmPlanInfo *>(info->data_ptr<int>());
+}
 
 // C = reduce(A (*) dense); E (arg column ids) is allocated for max/min only.
+// Precondition the kernels rely on and that is not checked here (it would cost a device sync per call): every column
+// id is < dense.size(0) and rowptr is a non-decreasing prefix array ending at col.numel(); dgsparse.Storage guarantees
+// both for the arrays it hands out.
 std::vector<Tensor> spmm_fwd(int op, const Tensor &rowptr_, const Tensor &col_, const Tensor &values, const Tensor &dense_,
-                             bool has_value, int64_t algorithm) {
+                             bool has_value, int64_t algorithm, const OptTensor &plan = c10::nullopt,
+                             const OptTensor &pinfo = c10::nullopt) {
   const Tensor rowptr = i32vec(rowptr_, "rowptr"), col = i32vec(col_, "col"), dense = f32mat(dense_, "dense");
+  same_device(rowptr, dense, "rowptr and dense");
+  same_device(col, dense, "col and dense");
+  if (has_value) same_device(values, dense, "values and dense");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(dense.device());
   const int64_t M = rowptr.numel() - 1, nnz = col.numel(), K = dense.size(0), N = dense.size(1);
   TORCH_CHECK(M >= 0, "dgsparse: rowptr must have at least one element");
@@ -65,7 +87,7 @@ std::vector<Tensor> spmm_fwd(int op, const Tensor &rowptr_, const Tensor &col_, 
     // dense graph, feature width not a multiple of 4 (e.g. 41 classes): the column-panel schedule needs 16-byte lane
     // vectors, and two small copies buy it.  Feature columns are independent chains: the visible ones are unchanged.
     const Tensor padded = at::constant_pad_nd(dense, {0, ((N + 3) & ~int64_t(3)) - N}, 0);
-    auto r = spmm_fwd(op, rowptr, col, values, padded, has_value, algorithm);
+    auto r = spmm_fwd(op, rowptr, col, values, padded, has_value, algorithm, plan, pinfo);
     r[0] = r[0].narrow(1, 0, N).contiguous();
     if (r[1].defined()) r[1] = r[1].narrow(1, 0, N).contiguous();
     return r;
@@ -75,6 +97,17 @@ std::vector<Tensor> spmm_fwd(int op, const Tensor &rowptr_, const Tensor &col_, 
   Tensor out = at::empty({M, N}, dense.options());
   const bool arg = (op == DGS_MAX || op == DGS_MIN);
   Tensor E = arg ? at::empty({M, N}, dense.options().dtype(at::kInt)) : Tensor();
+  const dgsSpmmPlanInfo *pi = plan_info(plan, pinfo, rowptr);
+  if (pi && M > 0 && N > 0 && nnz > 0 && dgs_spmm_csr_schedule(op, M, K, N, nnz) == DGS_SCHED_ROWS) {
+    TORCH_CHECK((size_t)plan->numel() >= dgs_spmm_plan_bytes(M, K, nnz), "dgsparse: plan buffer too small for this matrix");
+    const size_t wsb = dgs_spmm_csr_plan_workspace_bytes(op, M, N, nnz, pi);
+    Tensor ws = workspace(wsb, dense);
+    check_rc(dgs_spmm_csr_plan_f32(op, M, K, N, nnz, rowptr.data_ptr<int>(), col.data_ptr<int>(), vptr,
+                                   dense.data_ptr<float>(), out.data_ptr<float>(), arg ? E.data_ptr<int>() : nullptr,
+                                   plan->data_ptr(), pi, ws.data_ptr(), wsb, cur_stream()),
+             "spmm (plan)");
+    return {out, E};
+  }
   const size_t wsb = dgs_spmm_csr_workspace_bytes(op, M, N, nnz);
   Tensor ws = wsb ? workspace(wsb, dense) : Tensor();
   check_rc(dgs_spmm_csr_f32(op, M, K, N, nnz, rowptr.data_ptr<int>(), col.data_ptr<int>(), vptr, dense.data_ptr<float>(),
@@ -89,6 +122,9 @@ Tensor sddmm_impl(const Tensor &rowptr_, const Tensor &col_, const Tensor &D1_, 
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(D1.device());
   const int64_t M = rowptr.numel() - 1, nnz = col.numel(), F = D1.size(1);
   TORCH_CHECK(D2.size(1) == F && D1.size(0) >= M, "dgsparse: sddmm shape mismatch");
+  same_device(rowptr, D1, "rowptr and D1");
+  same_device(col, D1, "col and D1");
+  same_device(D2, D1, "D2 and D1");
   if (F % 4 && F > 4 &&
       dgs_sddmm_csr_schedule(M, D2.size(0), (F + 3) & ~int64_t(3), nnz, E.defined() ? 1 : 0) == DGS_SCHED_PANEL) {
     // same trick as in spmm_fwd: zero feature columns add exact zeros to every dot product
@@ -118,6 +154,10 @@ Tensor spmm_mask_impl(const Tensor &ptr_, const Tensor &idx_, const Tensor &tval
   const int64_t Mo = ptr.numel() - 1, nnz = idx.numel(), Mi = grad.size(0), N = grad.size(1);
   Tensor vkeep;
   const float *vptr = opt_values(tvalues, has_value, nnz, vkeep);
+  TORCH_CHECK(E.defined() && E.scalar_type() == at::kInt && E.sizes() == grad.sizes(),
+              "dgsparse: the saved arg ids must be int32 with the shape of the output gradient");
+  same_device(ptr, grad, "colptr and grad");
+  same_device(E, grad, "E and grad");
   const Tensor Ec = E.contiguous();
   const int64_t rows = std::max(n_out, Mo);
   Tensor out = at::empty({rows, N}, grad.options());
@@ -132,51 +172,20 @@ Tensor spmm_mask_impl(const Tensor &ptr_, const Tensor &idx_, const Tensor &tval
 
 // values in CSC order = values[csr2csc]: one pass of the HIP gather over the int32 permutation (index_select wants an
 // int64 copy of the permutation first and takes 2.4 ms for the 114.6 M entries of a Reddit-sized graph; this, 1.9 ms -
-// a random 4-byte gather).  The last result is kept: every layer of a model that shares one adjacency asks for the same
-// permuted values in its backward, and with fixed edge weights every iteration does.  A hit needs the SAME tensor
-// object (weak reference to its TensorImpl, so a recycled address cannot alias), the same version counter (any
-// in-place update since then misses - the trust model of autograd's own saved-tensor check) and the same permutation.
-struct TValuesCache {
-  c10::weak_intrusive_ptr<c10::TensorImpl> impl{c10::intrusive_ptr<c10::TensorImpl>()};
-  uint32_t version = 0;
-  const void *perm = nullptr;
-  Tensor out;
-};
-// heap-allocated and never destroyed: a static Tensor would be freed by a static destructor at process exit, after the
-// HIP runtime and the caching allocator may already be gone
-static TValuesCache &g_tv = *new TValuesCache();
-static std::mutex g_tv_mu;
-
+// a random 4-byte gather).  Callers that own the matrix (dgsparse.Storage) keep the result next to the CSC view and
+// pass it in through the `tvalues` argument of the *_p ops; nothing is cached in this file.
 Tensor t_values(const Tensor &values, const Tensor &csr2csc, bool has_value) {
   if (!has_value) return Tensor();
   if (csr2csc.scalar_type() != at::kInt || !csr2csc.is_cuda())
     return values.view({-1}).index_select(0, csr2csc.to(at::kLong));
   const Tensor perm = csr2csc.contiguous();
-  // never inside a stream capture: a hit would leave the gather out of the graph, and replays would read stale values
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  const bool capturing = hipStreamIsCapturing(static_cast<hipStream_t>(cur_stream()), &cap) != hipSuccess ||
-                         cap != hipStreamCaptureStatusNone;
-  if (!capturing) {
-    std::lock_guard<std::mutex> lk(g_tv_mu);
-    if (g_tv.out.defined() && g_tv.perm == perm.data_ptr() && g_tv.version == values._version() &&
-        g_tv.out.numel() == perm.numel()) {
-      const auto alive = g_tv.impl.lock();
-      if (alive && alive.get() == values.unsafeGetTensorImpl()) return g_tv.out;
-    }
-  }
   Tensor vkeep;
   const float *vptr = opt_values(values, true, perm.numel(), vkeep);
+  same_device(perm, vkeep, "csr2csc and values");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(vkeep.device());
   Tensor out = at::empty({perm.numel()}, vkeep.options());
   check_rc(dgs_gather_rows_f32(perm.numel(), 1, perm.data_ptr<int>(), vptr, out.data_ptr<float>(), cur_stream()),
            "gather");
-  if (!capturing) {
-    std::lock_guard<std::mutex> lk(g_tv_mu);
-    g_tv.impl = c10::weak_intrusive_ptr<c10::TensorImpl>(values.getIntrusivePtr());
-    g_tv.version = values._version();
-    g_tv.perm = perm.data_ptr();
-    g_tv.out = out;
-  }
   return out;
 }
 Tensor pad_rows(const Tensor &g, int64_t n) {
@@ -187,17 +196,21 @@ Tensor pad_rows(const Tensor &g, int64_t n) {
 }
 
 // ---- autograd ------------------------------------------------------------------------------------------
+// Optional extras of the *_p ops (all may be None): tvalues = values[csr2csc] kept by the caller; (plan, plan_info) = the
+// locality plan of (rowptr, col); (plan_t, plan_t_info) = the plan of the CSC arrays (colptr, row) for the backward SpMM.
 template <int OP>
 struct SpMM : public torch::autograd::Function<SpMM<OP>> {
   static Tensor forward(AutogradContext *ctx, Tensor rowptr, Tensor col, Tensor values, Tensor colptr, Tensor row,
-                        Tensor csr2csc, Tensor dense, bool has_value, int64_t algorithm) {
-    auto out = spmm_fwd(OP, rowptr, col, values, dense, has_value, algorithm);
+                        Tensor csr2csc, Tensor dense, bool has_value, int64_t algorithm, OptTensor tvalues, OptTensor plan,
+                        OptTensor pinfo, OptTensor plan_t, OptTensor pinfo_t) {
+    auto out = spmm_fwd(OP, rowptr, col, values, dense, has_value, algorithm, plan, pinfo);
     ctx->saved_data["has_value"] = has_value;
     ctx->saved_data["algorithm"] = algorithm;
-    if (OP == DGS_MAX || OP == DGS_MIN)
-      ctx->save_for_backward({rowptr, col, values, colptr, row, csr2csc, dense, out[1]});
-    else
-      ctx->save_for_backward({rowptr, col, values, colptr, row, csr2csc, dense});
+    const Tensor none;
+    tensor_list sv = {rowptr, col, values, colptr, row, csr2csc, dense, (OP == DGS_MAX || OP == DGS_MIN) ? out[1] : none,
+                      has(tvalues) ? *tvalues : none, has(plan_t) ? *plan_t : none};
+    ctx->save_for_backward(sv);
+    if (has(pinfo_t)) ctx->saved_data["pinfo_t"] = *pinfo_t;  // CPU tensor: plain data, not a graph input
     return out[0];
   }
 
@@ -208,6 +221,14 @@ struct SpMM : public torch::autograd::Function<SpMM<OP>> {
     const auto saved = ctx->get_saved_variables();
     const Tensor &rowptr = saved[0], &col = saved[1], &values = saved[2], &colptr = saved[3], &row = saved[4],
                  &csr2csc = saved[5], &dense = saved[6];
+    OptTensor plan_t, pinfo_t;
+    if (saved[9].defined() && ctx->saved_data.count("pinfo_t")) {
+      plan_t = saved[9];
+      pinfo_t = ctx->saved_data["pinfo_t"].toTensor();
+    }
+    auto tv = [&]() { return saved[8].defined() ? saved[8] : t_values(values, csr2csc, has_value); };
+    TORCH_CHECK(grad_out.dim() == 2 && grad_out.size(0) == rowptr.numel() - 1 && grad_out.size(1) == dense.size(1),
+                "dgsparse: the output gradient must be [rows of A, features]");
     Tensor grad_value, grad_dense;
     const bool need_v = has_value && ctx->needs_input_grad(2), need_d = ctx->needs_input_grad(6);
     if (OP == DGS_MAX || OP == DGS_MIN) {
@@ -228,28 +249,55 @@ struct SpMM : public torch::autograd::Function<SpMM<OP>> {
                                            need_v ? gw.data_ptr<float>() : nullptr, cur_stream()),
                  "spmm_arg_backward");
         if (need_v) grad_value = gw.view_as(values);
-        return {Tensor(), Tensor(), grad_value, Tensor(), Tensor(), Tensor(), grad_dense, Tensor(), Tensor()};
+      } else {
+        if (need_v) grad_value = sddmm_impl(rowptr, col, grad_out, dense, DGS_SUM, E).view_as(values);
+        if (need_d) grad_dense = spmm_mask_impl(colptr, row, tv(), has_value, grad_out, E, dense.size(0));
       }
-      if (need_v) grad_value = sddmm_impl(rowptr, col, grad_out, dense, DGS_SUM, E).view_as(values);
-      if (need_d) grad_dense = spmm_mask_impl(colptr, row, t_values(values, csr2csc, has_value), has_value, grad_out, E, dense.size(0));
     } else if (OP == DGS_MEAN) {
       if (need_v) grad_value = sddmm_impl(rowptr, col, grad_out, dense, DGS_MEAN, Tensor()).view_as(values);
       if (need_d) {  // A^T diag(1/deg) dC: scale grad rows by 1/deg(source row), then a plain transposed SpMM
         const Tensor deg = (rowptr.slice(0, 1) - rowptr.slice(0, 0, -1)).clamp_min(1).to(at::kFloat);
-        grad_dense = pad_rows(spmm_fwd(DGS_SUM, colptr, row, t_values(values, csr2csc, has_value), grad_out / deg.unsqueeze(1), has_value, algorithm)[0], dense.size(0));
+        grad_dense = pad_rows(spmm_fwd(DGS_SUM, colptr, row, tv(), grad_out / deg.unsqueeze(1), has_value, algorithm, plan_t, pinfo_t)[0], dense.size(0));
       }
     } else {
       if (need_v) grad_value = sddmm_impl(rowptr, col, grad_out, dense, DGS_SUM, Tensor()).view_as(values);
-      if (need_d) grad_dense = pad_rows(spmm_fwd(DGS_SUM, colptr, row, t_values(values, csr2csc, has_value), grad_out, has_value, algorithm)[0], dense.size(0));
+      if (need_d) grad_dense = pad_rows(spmm_fwd(DGS_SUM, colptr, row, tv(), grad_out, has_value, algorithm, plan_t, pinfo_t)[0], dense.size(0));
     }
-    return {Tensor(), Tensor(), grad_value, Tensor(), Tensor(), Tensor(), grad_dense, Tensor(), Tensor()};
+    return {Tensor(), Tensor(), grad_value, Tensor(), Tensor(), Tensor(), grad_dense, Tensor(), Tensor(),
+            Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
+// the reference's nine-argument schema (src/spmm.cpp:264-270)
 template <int OP>
 Tensor spmm_op(Tensor rowptr, Tensor col, Tensor values, Tensor colptr, Tensor row, Tensor csr2csc, Tensor dense,
                bool has_value, int64_t algorithm) {
-  return SpMM<OP>::apply(rowptr, col, values, colptr, row, csr2csc, dense, has_value, algorithm);
+  return SpMM<OP>::apply(rowptr, col, values, colptr, row, csr2csc, dense, has_value, algorithm, c10::nullopt, c10::nullopt,
+                         c10::nullopt, c10::nullopt, c10::nullopt);
+}
+// the same with the caller-kept extras (what dgsparse.spmm_* pass from the Storage)
+template <int OP>
+Tensor spmm_op_p(Tensor rowptr, Tensor col, Tensor values, Tensor colptr, Tensor row, Tensor csr2csc, Tensor dense,
+                 bool has_value, int64_t algorithm, OptTensor tvalues, OptTensor plan, OptTensor pinfo, OptTensor plan_t,
+                 OptTensor pinfo_t) {
+  return SpMM<OP>::apply(rowptr, col, values, colptr, row, csr2csc, dense, has_value, algorithm, tvalues, plan, pinfo, plan_t,
+                         pinfo_t);
+}
+
+// (rowptr, col, n_cols) -> [plan buffer (uint8, GPU), plan info (16 int32, CPU)]; blocks once on the current stream
+std::vector<Tensor> spmm_plan_op(Tensor rowptr_, Tensor col_, int64_t n_cols) {
+  const Tensor rowptr = i32vec(rowptr_, "rowptr"), col = i32vec(col_, "col");
+  same_device(rowptr, col, "rowptr and col");
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(rowptr.device());
+  const int64_t M = rowptr.numel() - 1, nnz = col.numel();
+  TORCH_CHECK(M > 0 && nnz > 0 && n_cols > 0, "dgsparse: cannot plan an empty matrix");
+  const size_t pb = dgs_spmm_plan_bytes(M, n_cols, nnz), wb = dgs_spmm_plan_workspace_bytes(M, n_cols, nnz);
+  Tensor plan = workspace(pb, rowptr), ws = workspace(wb, rowptr);
+  Tensor info = at::zeros({16}, at::TensorOptions().dtype(at::kInt).device(at::kCPU));
+  check_rc(dgs_spmm_plan_build(M, n_cols, nnz, rowptr.data_ptr<int>(), col.data_ptr<int>(), plan.data_ptr(), pb,
+                               ws.data_ptr(), wb, reinterpret_cast<dgsSpmmPlanInfo *>(info.data_ptr<int>()), cur_stream()),
+           "spmm_plan_build");
+  return {plan, info};
 }
 
 // csr2csc(rowptr, colind, values) -> [colptr, row, values in CSC order]; square like the reference (src/spmm.cpp:91-94)
@@ -257,6 +305,10 @@ std::vector<Tensor> csr2csc_op(Tensor rowptr_, Tensor colind_, Tensor values) {
   const Tensor rowptr = i32vec(rowptr_, "rowptr"), col = i32vec(colind_, "colind");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(rowptr.device());
   const int64_t n = rowptr.numel() - 1, nnz = col.numel();
+  // square like the reference's op: a column id >= n would alias in the n-bit radix sort (setup path: one sync is fine);
+  // rectangular matrices go through csr2csc_perm / dgsparse.csr2csc(SparseTensor), which pass the column count
+  TORCH_CHECK(nnz == 0 || col.max().item<int64_t>() < n, "dgsparse: csr2csc(rowptr, colind, values) is square-only (a column id >= ",
+              n, " rows was found); use csr2csc_perm with the column count");
   Tensor vkeep;
   const float *vptr = opt_values(values, true, nnz, vkeep);
   Tensor colptr = at::empty({n + 1}, rowptr.options()), row = at::empty({nnz}, rowptr.options());
@@ -294,6 +346,7 @@ std::vector<Tensor> spmm_raw_op(int64_t op, Tensor rowptr, Tensor col, Tensor va
   TORCH_CHECK(op >= 0 && op <= 3, "dgsparse: bad reduce op");
   return spmm_fwd((int)op, rowptr, col, values, dense, has_value, algorithm);
 }
+Tensor t_values_op(Tensor values, Tensor csr2csc) { return t_values(values, csr2csc, true); }
 
 }  // namespace
 
@@ -307,4 +360,11 @@ TORCH_LIBRARY(dgsparse_spmm, m) {
   m.def("sddmm", &sddmm_op);
   m.def("csr2csc_perm", &csr2csc_perm_op);
   m.def("spmm_raw", &spmm_raw_op);
+  // the four operators with the caller-kept extras (permuted values, forward plan, backward plan), and their builders
+  m.def("spmm_sum_p", &spmm_op_p<DGS_SUM>);
+  m.def("spmm_max_p", &spmm_op_p<DGS_MAX>);
+  m.def("spmm_min_p", &spmm_op_p<DGS_MIN>);
+  m.def("spmm_mean_p", &spmm_op_p<DGS_MEAN>);
+  m.def("spmm_plan", &spmm_plan_op);
+  m.def("permute_values", &t_values_op);
 }

@@ -12,8 +12,11 @@ with ONE all-to-all-v:
     per call pack   : gather_rows(B_loc, send_ids)            (HIP kernel dgs_gather_rows_f32)
              exchange: all_to_all_single(B_ext[Mloc:], packed, recv_splits, send_splits)   (RCCL)
              compute : sum/mean: C = spmm(A_loc, B_loc) WHILE the exchange is in flight (RCCL runs on its own
-                                 stream), then C += spmm(A_rem, B_halo)      [A = A_loc + A_rem by column owner]
+                                 stream), then C[rem_rows] += spmm(A_rem, B_halo)   [A = A_loc + A_rem by column owner;
+                                 A_rem holds only the rows that have a remote entry]
                        max/min : C, E = spmm(A_ext, B_ext) after the exchange (one pass keeps first-wins ties exact)
+    backward (DistSpMMFn): the same plan reversed - gradients of halo rows travel home by all-to-all-v and are
+             scatter-added; sum / mean / max / min, w.r.t. the feature rows and the edge values.
 
 xGMI is point-to-point (7 links per GPU), so an all-to-all uses every link at once - the right collective shape for
 this fabric; there is no all-reduce anywhere.  Only feature rows travel; the graph never does.
@@ -125,9 +128,11 @@ def _all_to_all_v(out: torch.Tensor, inp: torch.Tensor, out_splits: List[int], i
 
 
 class HaloPlan:
-    """Who needs which feature rows.  Built once per partition (collective: every rank must call it)."""
+    """Who needs which feature rows.  Built once per partition (collective: every rank must call it, unless
+    ``standalone``: then only the receive side is built - what one rank's shard needs - and nothing is exchanged; the
+    caller fills the halo rows itself.  That is how a single GPU runs ONE rank's shard of a many-rank job)."""
 
-    def __init__(self, part: RowPartition, group=None):
+    def __init__(self, part: RowPartition, group=None, standalone: bool = False):
         dev = part.col.device
         world, rank = part.world, part.rank
         offs = torch.tensor(part.row_offsets, device=dev, dtype=torch.int64)
@@ -144,22 +149,31 @@ class HaloPlan:
         self.recv_splits = recv_splits.tolist()
         self.n_halo = int(rem.numel())
         self.ext2glob = torch.cat([torch.arange(part.r0, part.r0 + part.n_local, device=dev), rem])
-        # A = A_loc + A_rem (same rows): lets the local product run while the halo is still in flight
+        # A = A_loc + A_rem (same rows): lets the local product run while the halo is still in flight.  A_rem is stored
+        # COMPACT: only the rows that have a remote entry (rem_rows), so that the second product and the add touch
+        # those rows only (with an edge cut of 20 % and a median degree of 4, four rows in ten have none)
         nl = part.n_local
         counts = (part.rowptr[1:] - part.rowptr[:-1]).long()
         rows = torch.repeat_interleave(torch.arange(nl, device=dev), counts)
+        self.nnz_pos_loc = torch.nonzero(~is_remote).view(-1)  # positions of the local / remote entries in part.col
+        self.nnz_pos_rem = torch.nonzero(is_remote).view(-1)
 
-        def _sub(mask, shift):
-            rp = torch.zeros(nl + 1, dtype=torch.int64, device=dev)
-            rp[1:] = torch.cumsum(torch.bincount(rows[mask], minlength=nl), 0)
+        def _sub(mask, shift, compact):
+            cnt = torch.bincount(rows[mask], minlength=nl)
+            keep = torch.nonzero(cnt).view(-1) if compact else None
+            if compact:
+                cnt = cnt[keep]
+            rp = torch.zeros(cnt.numel() + 1, dtype=torch.int64, device=dev)
+            rp[1:] = torch.cumsum(cnt, 0)
             return (rp.to(torch.int32), (ext[mask] - shift).to(torch.int32).contiguous(),
-                    None if part.val is None else part.val[mask].contiguous())
+                    None if part.val is None else part.val[mask].contiguous()), keep
 
-        self.loc = _sub(~is_remote, 0)
-        self.rem = _sub(is_remote, nl)
+        self.loc, _ = _sub(~is_remote, 0, False)
+        self.rem, keep = _sub(is_remote, nl, True)
+        self.rem_rows = keep.to(torch.int32).contiguous()
         self.deg = counts.clamp(min=1).to(torch.float32)
-        if world == 1:  # nothing to exchange; no process group needed
-            self.send_splits = [0]
+        if world == 1 or standalone:  # nothing to exchange; no process group needed
+            self.send_splits = [0] * world
             self.send_ids = torch.zeros(0, dtype=torch.int32, device=dev)
             return
         # transpose the plan: tell every owner which of its rows I need
@@ -173,14 +187,27 @@ class HaloPlan:
 
 
 class _HipOps:
-    """The product compute path: the HIP kernels through the C ABI."""
+    """The product compute path: the HIP kernels through the C ABI (with cached locality plans per matrix)."""
 
     def __init__(self):
         from . import _capi
         self._c = _capi
+        self._plans = {}
+
+    def _plan(self, rowptr, col, K, N):
+        key = (rowptr.data_ptr(), col.data_ptr(), int(col.numel()))
+        if key not in self._plans:
+            self._plans[key] = self._c.spmm_plan(rowptr, col, K, N) if col.numel() else None
+        return self._plans[key]
 
     def spmm(self, op, rowptr, col, val, B):
-        return self._c.spmm(op, rowptr, col, val, B)
+        return self._c.spmm(op, rowptr, col, val, B, plan=self._plan(rowptr, col, B.shape[0], B.shape[1]))
+
+    def sddmm(self, rowptr, col, D1, D2, op=0, E=None):
+        return self._c.sddmm(rowptr, col, D1, D2, op, E=E)
+
+    def spmm_arg_backward(self, rowptr, col, val, E, grad, dense, need_dense=True, need_values=True):
+        return self._c.spmm_arg_backward(rowptr, col, val, E, grad, dense, need_dense=need_dense, need_values=need_values)
 
     def gather_rows(self, src, ids):
         return self._c.gather_rows(src, ids)
@@ -189,8 +216,8 @@ class _HipOps:
         return self._c.scatter_add_rows(dst, ids, src)
 
     def csr2csc(self, rowptr, col, val, n_cols):
-        colptr, row, cscval, _ = self._c.csr2csc(rowptr, col, val, n_cols, want_perm=False)
-        return colptr, row, cscval
+        """(colptr, row, values in CSC order | None, permutation CSC slot -> CSR slot)"""
+        return self._c.csr2csc(rowptr, col, val, n_cols, want_perm=True)
 
 
 _OPS = {'sum': 0, 'max': 1, 'min': 2, 'mean': 3}
@@ -200,19 +227,22 @@ class DistSpMM:
     """C_loc = reduce(A_loc_rows (*) B_global) with B row-partitioned like A.  ``ops`` is injectable so that the
     exchange logic can be exercised on CPU/gloo with a stand-in compute back end (tests only)."""
 
-    def __init__(self, part: RowPartition, n_feat: int, ops=None, group=None, overlap: bool = True):
+    def __init__(self, part: RowPartition, n_feat: int, ops=None, group=None, overlap: bool = True,
+                 standalone: bool = False):
         self.part, self.N, self.group, self.overlap = part, n_feat, group, overlap
+        self.standalone = standalone
         self.ops = ops if ops is not None else _HipOps()
-        self.plan = HaloPlan(part, group)
+        self.plan = HaloPlan(part, group, standalone)
         self.n_halo = self.plan.n_halo
         dev = part.col.device
         # one buffer for [local rows | halo rows]: the exchange lands directly where the kernel reads it
         self.B_ext = torch.empty((part.n_local + self.n_halo, n_feat), dtype=torch.float32, device=dev)
         t = torch.tensor([part.nnz], dtype=torch.int64, device=dev)
-        if part.world > 1:
+        if part.world > 1 and not standalone:
             dist.all_reduce(t, group=group)
         self.global_nnz = int(t.item())
-        self.last_E = None
+        self.last_E = None       # global column ids of the last max/min
+        self.last_E_ext = None   # the same in the extended index space (what the backward needs)
 
     def local_features(self) -> torch.Tensor:
         """View of the first n_local rows of the exchange buffer: fill it in place to skip the copy in spmm()."""
@@ -224,50 +254,63 @@ class DistSpMM:
         if B_loc.data_ptr() != self.B_ext.data_ptr():
             self.B_ext[:p.n_local].copy_(B_loc)
         work = None
-        if p.world > 1:
+        if p.world > 1 and not self.standalone:
             self._packed = self.ops.gather_rows(self.B_ext[:p.n_local], plan.send_ids)  # kept alive until waited
             work = dist.all_to_all_single(self.B_ext[p.n_local:], self._packed, plan.recv_splits, plan.send_splits,
                                           group=self.group, async_op=async_op)
         return self.B_ext, work
 
-    def spmm(self, B_loc: torch.Tensor, reduce: str = 'sum') -> torch.Tensor:
-        p, plan = self.part, self.plan
-        if self.overlap and p.world > 1 and reduce in ('sum', 'mean'):
-            B_ext, work = self.exchange(B_loc, async_op=True)
-            C, _ = self.ops.spmm(0, plan.loc[0], plan.loc[1], plan.loc[2], B_ext[:p.n_local])  # overlaps the exchange
-            if work is not None:
-                work.wait()  # current stream waits for the collective; the host does not block
-            if self.n_halo > 0:
-                Cr, _ = self.ops.spmm(0, plan.rem[0], plan.rem[1], plan.rem[2], B_ext[p.n_local:])
-                C += Cr
-            if reduce == 'mean':
-                C /= plan.deg[:, None]
-            self.last_E = None
-            return C
-        B_ext, _ = self.exchange(B_loc)
-        C, E = self.ops.spmm(_OPS[reduce], self.part.rowptr, self.plan.col_ext, self.part.val, B_ext)
-        self.last_E = None
+    def compute(self, reduce: str = 'sum', val: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The product over the CURRENT contents of the [local | halo] buffer (no exchange): one pass over the relabelled
+        matrix.  ``val`` overrides the partition's edge values (same order as ``part.col``)."""
+        val = self.part.val if val is None else val
+        C, E = self.ops.spmm(_OPS[reduce], self.part.rowptr, self.plan.col_ext, val, self.B_ext)
+        self.last_E = self.last_E_ext = None
         if E is not None:  # ext ids -> global column ids (-1 stays -1)
+            self.last_E_ext = E
             g = self.plan.ext2glob[E.clamp(min=0).long()].to(torch.int32)
             self.last_E = torch.where(E >= 0, g, E)
         return C
 
-    # ---- backward of the sum product w.r.t. the dense operand: dB = A^T dC, with the exchange reversed ----------
-    def _transposed(self):
-        if getattr(self, '_csc', None) is None:  # CSC of the relabelled local matrix, built once
+    def spmm(self, B_loc: torch.Tensor, reduce: str = 'sum', val: Optional[torch.Tensor] = None) -> torch.Tensor:
+        p, plan = self.part, self.plan
+        if self.overlap and p.world > 1 and not self.standalone and reduce in ('sum', 'mean'):
+            B_ext, work = self.exchange(B_loc, async_op=True)
+            vl = plan.loc[2] if val is None else val[plan.nnz_pos_loc]
+            vr = plan.rem[2] if val is None else val[plan.nnz_pos_rem]
+            C, _ = self.ops.spmm(0, plan.loc[0], plan.loc[1], vl, B_ext[:p.n_local])  # overlaps the exchange
+            if work is not None:
+                work.wait()  # current stream waits for the collective; the host does not block
+            if plan.rem_rows.numel() > 0:
+                # the halo product only covers the rows that have a remote entry; its rows are added in place
+                Cr, _ = self.ops.spmm(0, plan.rem[0], plan.rem[1], vr, B_ext[p.n_local:])
+                self.ops.scatter_add_rows(C, plan.rem_rows, Cr)
+            if reduce == 'mean':
+                C /= plan.deg[:, None]
+            self.last_E = self.last_E_ext = None
+            return C
+        self.exchange(B_loc)
+        return self.compute(reduce, val)
+
+    # ---- backward: the exchange reversed -----------------------------------------------------------------------------
+    def _transposed(self, val=None):
+        """(colptr, row, values in CSC order) of the relabelled local matrix; the structure is built once, caller-supplied
+        values are permuted into it."""
+        if getattr(self, '_csc', None) is None:
             p = self.part
             self._csc = self.ops.csr2csc(p.rowptr, self.plan.col_ext, p.val, p.n_local + self.n_halo)
-        return self._csc
+        colptr, row, tval, perm = self._csc
+        if val is not None:
+            tval = val[perm.long()]
+        return colptr, row, tval
 
-    def spmm_sum_backward_dense(self, grad_C: torch.Tensor) -> torch.Tensor:
-        """grad w.r.t. this rank's rows of B: local part of A_ext^T grad_C plus the halo parts that the peers computed
-        for rows I own (reverse all-to-all-v, then a scatter-add; every send_ids row is unique per peer but one row
-        may be wanted by several peers, so the adds are applied peer by peer - a fixed order, deterministic)."""
+    def _return_halo_grads(self, g_ext: torch.Tensor) -> torch.Tensor:
+        """g_ext [n_local + n_halo, N] = gradient w.r.t. every row of the [local | halo] buffer.  The halo part belongs to
+        other ranks: reverse all-to-all-v, then scatter-add into my rows (every send_ids row is unique per peer but one
+        row may be wanted by several peers, so the adds are applied peer by peer - a fixed order, deterministic)."""
         p, plan = self.part, self.plan
-        colptr, row, tval = self._transposed()
-        g_ext, _ = self.ops.spmm(0, colptr, row, tval, grad_C.contiguous())  # [n_local + n_halo, N]
         g_loc = g_ext[:p.n_local].contiguous()
-        if p.world > 1:
+        if p.world > 1 and not self.standalone:
             back = torch.empty((int(plan.send_ids.numel()), g_ext.shape[1]), dtype=torch.float32, device=g_ext.device)
             dist.all_to_all_single(back, g_ext[p.n_local:].contiguous(), plan.send_splits, plan.recv_splits,
                                    group=self.group)
@@ -278,9 +321,69 @@ class DistSpMM:
                 off += n
         return g_loc
 
+    def spmm_sum_backward_dense(self, grad_C: torch.Tensor) -> torch.Tensor:
+        """grad w.r.t. this rank's rows of B for the sum product: A_ext^T grad_C, halo parts sent home."""
+        return self.backward(grad_C, 'sum', need_values=False)[0]
+
+    def backward(self, grad_C: torch.Tensor, reduce: str = 'sum', need_dense: bool = True, need_values: bool = False,
+                 val: Optional[torch.Tensor] = None, B_ext: Optional[torch.Tensor] = None,
+                 E_ext: Optional[torch.Tensor] = None):
+        """(grad of my rows of B or None, grad of my edge values or None) of ``spmm(B_loc, reduce)``; same semantics as
+        the single-GPU operators (reference src/spmm.cpp:52-80,113-141,224-253 with the mean fix of SURVEY 3.4):
+          sum   dB = A^T dC                 dW[e] = <dC[row e], B[col e]>
+          mean  the same with dC rows scaled by 1/deg(row)
+          max/min  only the arg entries carry gradient (E from the forward)
+        B_ext / E_ext default to what the last forward left in the engine (the halo buffer is overwritten by the next
+        forward: callers that interleave several forwards pass their own copies)."""
+        p = self.part
+        grad_C = grad_C.contiguous()
+        val = p.val if val is None else val
+        B_ext = self.B_ext if B_ext is None else B_ext
+        g_loc = g_val = None
+        if reduce in ('max', 'min'):
+            E = self.last_E_ext if E_ext is None else E_ext
+            assert E is not None, 'max/min backward needs the arg ids of the forward'
+            gX, g_val = self.ops.spmm_arg_backward(p.rowptr, self.plan.col_ext, val, E, grad_C, B_ext,
+                                                   need_dense=need_dense, need_values=need_values)
+            if need_dense:
+                g_loc = self._return_halo_grads(gX)
+            return g_loc, g_val
+        if reduce == 'mean':
+            grad_C = grad_C / self.plan.deg[:, None]
+        if need_values:
+            g_val = self.ops.sddmm(p.rowptr, self.plan.col_ext, grad_C, B_ext)
+        if need_dense:
+            colptr, row, tval = self._transposed(None if val is p.val else val)
+            g_ext, _ = self.ops.spmm(0, colptr, row, tval, grad_C)  # [n_local + n_halo, N]
+            g_loc = self._return_halo_grads(g_ext)
+        return g_loc, g_val
+
+
+class DistSpMMFn(torch.autograd.Function):
+    """``C_loc = DistSpMMFn.apply(engine, B_loc, values, reduce)``: differentiable w.r.t. this rank's feature rows and
+    (when ``values`` is a tensor that requires grad) its edge values.  ``values=None`` uses the partition's."""
+
+    @staticmethod
+    def forward(ctx, engine: 'DistSpMM', B_loc: torch.Tensor, values: Optional[torch.Tensor], reduce: str):
+        ctx.engine, ctx.reduce = engine, reduce
+        C = engine.spmm(B_loc, reduce, None if values is None else values.detach())
+        need_v = values is not None and values.requires_grad
+        # the halo buffer is reused by the next forward: keep what the values gradient / the arg backward reads
+        keep_B = engine.B_ext.clone() if (need_v or reduce in ('max', 'min')) else None
+        ctx.save_for_backward(values.detach() if values is not None else None, keep_B, engine.last_E_ext)
+        return C
+
+    @staticmethod
+    def backward(ctx, grad_C):
+        values, B_ext, E_ext = ctx.saved_tensors
+        g_loc, g_val = ctx.engine.backward(grad_C, ctx.reduce, need_dense=ctx.needs_input_grad[1],
+                                           need_values=ctx.needs_input_grad[2], val=values, B_ext=B_ext, E_ext=E_ext)
+        return None, g_loc, g_val, None
+
 
 class DistSpMMSum(torch.autograd.Function):
-    """Autograd wrapper: ``C_loc = DistSpMMSum.apply(engine, B_loc)`` differentiable w.r.t. B_loc."""
+    """``C_loc = DistSpMMSum.apply(engine, B_loc)``: the sum product, differentiable w.r.t. B_loc (kept for callers of the
+    first version of this module; DistSpMMFn is the general form)."""
 
     @staticmethod
     def forward(ctx, engine: 'DistSpMM', B_loc: torch.Tensor):

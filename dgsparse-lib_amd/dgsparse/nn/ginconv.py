@@ -13,15 +13,16 @@ _AGGREGATORS = {'sum': spmm_sum, 'max': spmm_max, 'mean': spmm_mean}
 class GINConv(torch.nn.Module):
     r"""``h_i' = act( f( (1 + eps) h_i + AGG_{j in N(i)} h_j ) )`` with AGG in {sum, max, mean}.
 
-    ``cached=True`` builds the neighbourhood ``SparseTensor`` (CSR + its CSC view) once and reuses it; the reference
-    accepts the flag but converts ``edge_index`` -- including a csr2csc -- on every forward."""
+    ``cached=True`` builds the neighbourhood ``SparseTensor`` (CSR + its CSC view + its locality plans) once and reuses
+    it for as long as the SAME ``edge_index`` tensor (object, version) and ``num_nodes`` come in; the reference accepts
+    the flag but converts ``edge_index`` -- including a csr2csc -- on every forward."""
 
     def __init__(self, apply_func=None, aggregator_type='sum', init_eps=0, learn_eps=False, activation=None,
                  cached=False):
         super().__init__()
         self.apply_func, self.activation = apply_func, activation
         self._aggregator_type = aggregator_type
-        self.cached, self._cached_dcsr = cached, None
+        self.cached, self._cached_dcsr, self._cached_key = cached, None, None
         eps = torch.FloatTensor([init_eps])
         if learn_eps:
             self.eps = torch.nn.Parameter(eps)
@@ -29,12 +30,13 @@ class GINConv(torch.nn.Module):
             self.register_buffer('eps', eps)
 
     def _neighbourhood(self, edge_index, num_nodes) -> SparseTensor:
-        if self._cached_dcsr is not None:
+        key = (id(edge_index), edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes))
+        if self._cached_dcsr is not None and self._cached_key == key:
             return self._cached_dcsr
         rowptr, col, w = csr_from_edge_index(edge_index, num_nodes)
         dcsr = SparseTensor(rowptr=rowptr, col=col, values=w.requires_grad_(), has_value=True)
         if self.cached:
-            self._cached_dcsr = dcsr
+            self._cached_dcsr, self._cached_key = dcsr, key
         return dcsr
 
     def aggregate_neigh(self, edge_index, X, num_nodes, algorithm):

@@ -8,7 +8,12 @@ independently.  Two intended differences:
   ``arange(nnz)`` through cuSPARSE as float32 *values* (storage.py:164-169), which is exact only below 2**24 entries;
 * rectangular matrices work: the CSC view has ``sparse_sizes[1] = col.max() + 1`` columns (the reference passes
   ``n, n`` to cuSPARSE and is square-only).
+
+Next to the CSC view the Storage keeps, with the same lifetime and built on first use: the locality plans of the
+forward (CSR) and backward (CSC) SpMM (csrc/spmm_plan.hip) and the edge values in CSC order.
 """
+import os
+import weakref
 from typing import Optional
 
 import torch
@@ -56,6 +61,10 @@ class Storage(object):
 
         if row is not None:
             row = _index_array(row, col, nnz)
+            # COO rows that define the matrix must already be in CSR order (the reference silently builds a wrong
+            # matrix otherwise)
+            if rowptr is None and nnz > 1 and not bool((row[1:] >= row[:-1]).all()):
+                raise ValueError('dgsparse: COO row indices must be sorted (CSR order)')
         if rowptr is not None:
             rowptr = _index_array(rowptr, col, n_rows + 1)
         else:  # COO rows (sorted, as CSR order requires) -> row pointer
@@ -79,6 +88,9 @@ class Storage(object):
 
         self._row, self._rowptr, self._col, self._values = row, rowptr, col, values
         self._colptr, self._csr2csc, self._csc2csr, self._colcount = colptr, csr2csc, csc2csr, colcount
+        self._csc_row = None   # row index of every CSC slot (what the backward SpMM over (colptr, row) needs)
+        self._plans = {}       # 'csr' / 'csc' -> (plan buffer, plan info) or None when the shape takes no plan
+        self._tvalues = None   # (weakref to values, version, values in CSC order)
         self.csr2csc_convert()
 
     @classmethod
@@ -112,12 +124,54 @@ class Storage(object):
     def csr2csc(self) -> torch.Tensor:
         return self._present('_csr2csc')
 
+    def csc_row(self) -> torch.Tensor:
+        """Row index of every entry in CSC order.  The reference keeps these in ``_row`` (storage.py:170-173), which
+        collides with caller-supplied COO rows (CSR order); here they always live in their own attribute."""
+        return self._present('_csc_row')
+
+    # ---- per-matrix state of the HIP schedule, built on first use ---------------------------------------------------
+    def spmm_plan(self, which: str = 'csr', n_feat: int = 64):
+        """(plan buffer, plan info) of the forward ('csr': rowptr/col) or backward ('csc': colptr/csc_row) SpMM, or
+        (None, None) when that shape does not take the planned schedule (small inputs, dense graphs, DGS_PLAN=0)."""
+        if which not in self._plans:
+            plan = None
+            if self.nnz and self._col.is_cuda and os.environ.get('DGS_PLAN', '1') != '0':
+                if which == 'csr':
+                    ptr, idx, M, K = self._rowptr, self._col, self.sparse_sizes[0], self.sparse_sizes[1]
+                else:
+                    ptr, idx, M, K = self._colptr, self._csc_row, self.sparse_sizes[1], self.sparse_sizes[0]
+                if M > 0 and _capi.spmm_schedule(_capi.SUM, M, K, n_feat, self.nnz) == 'rows':
+                    plan = tuple(torch.ops.dgsparse_spmm.spmm_plan(ptr, idx, K))
+            self._plans[which] = plan
+        return self._plans[which] or (None, None)
+
+    def csc_values(self) -> torch.Tensor:
+        """Edge values in CSC order (``values[csr2csc]``), recomputed only when ``values`` was replaced or updated in
+        place (same tensor object by weak reference + its version counter: autograd's own saved-tensor rule)."""
+        v = self._values
+        hit = self._tvalues
+        if hit is not None and hit[0]() is v and hit[1] == v._version and not torch.cuda.is_current_stream_capturing():
+            return hit[2]
+        out = torch.ops.dgsparse_spmm.permute_values(v.detach(), self._csr2csc)
+        if not torch.cuda.is_current_stream_capturing():
+            self._tvalues = (weakref.ref(v), v._version, out)
+        return out
+
     def csr2csc_convert(self):
         """Fills in whatever is missing of (colptr, CSC row indices, CSR->CSC permutation), once.
 
-        As in the reference (storage.py:170-173) the CSC row indices land in ``_row`` when no COO rows were given, and
-        that is what the spmm operators pass as their ``row`` argument."""
-        if None not in (self._csr2csc, self._colptr, self._row):
+        The CSC row indices go to ``_csc_row`` (what the spmm operators pass as their ``row`` argument); as in the
+        reference (storage.py:170-173) they also land in ``_row`` when no COO rows were given."""
+        if None not in (self._csr2csc, self._colptr, self._csc_row):
+            return self._csr2csc
+        if None not in (self._csr2csc, self._colptr):
+            # pre-computed CSC view (reference storage.py:160-161 skips the conversion): the CSC row indices follow from
+            # rowptr and the permutation, whatever the caller's `row` array holds
+            counts = (self._rowptr[1:] - self._rowptr[:-1]).long()
+            coo = torch.repeat_interleave(torch.arange(counts.numel(), device=counts.device), counts)
+            self._csc_row = coo[self._csr2csc.long()].to(_INDEX)
+            if self._row is None:
+                self._row = self._csc_row
             return self._csr2csc
         if self.nnz == 0:
             dev = self._col.device
@@ -125,6 +179,7 @@ class Storage(object):
             csc_row = perm = torch.zeros(0, dtype=_INDEX, device=dev)
         else:
             colptr, csc_row, _, perm = _capi.csr2csc(self._rowptr, self._col, None, self.sparse_sizes[1], want_perm=True)
+        self._csc_row = csc_row
         if self._row is None:
             self._row = csc_row
         if self._colptr is None:

@@ -1,0 +1,82 @@
+"""One rank of the multi-GPU HIP parity check (launched by tests/test_gpu_dist.py under torch.distributed.run, backend
+nccl = RCCL, one rank per GPU; also runnable by hand:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tests/dist_hip_worker.py).
+Every rank builds the same seeded global graph, keeps its row block, runs DistSpMM with the HIP kernels (plain and
+overlapped engines) and checks ITS rows of C / E / the gradients against the single-process CPU oracle on the whole
+graph: the same assertions tests/test_dist_cpu.py makes on gloo with the oracle as compute stand-in."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'dgsparse-lib_amd'), os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+
+def main():
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', device_id=dev)
+    import oracle
+    from bench import graphgen
+    from dgsparse import dist as dd
+    from util import assert_bitexact, assert_close, assert_sum_parity
+
+    per = int(os.environ.get('DGS_TEST_ROWS_PER_RANK', '20000'))  # > 2^16 rows overall from 4 ranks on: planned schedule
+    M, N = per * world, 32
+    rp, col, st = graphgen.powerlaw_csr(M, 14 * M, alpha=2.0, dmax=M // 3, cols='powerlaw', seed=5)
+    val = graphgen.weights(col.shape[0], 'tied', 5)
+    X = (np.random.default_rng(1).integers(-2, 3, (M, N)) / 4).astype(np.float32)
+    G = (np.random.default_rng(2).integers(-2, 3, (M, N)) / 4).astype(np.float32)
+    part = dd.partition_csr(rp, col, val, world)[rank]
+    part.rowptr, part.col, part.val = part.rowptr.to(dev), part.col.to(dev), part.val.to(dev)
+    r0, r1 = part.row_offsets[rank], part.row_offsets[rank + 1]
+    s0, s1 = int(rp[r0]), int(rp[r1])
+    lens = np.diff(rp)
+    C64 = oracle.spmm_sum_f64(rp, col, val, X)
+    S64 = oracle.spmm_sum_f64(rp, col, val, X, absval=True)
+    cp, rw, tv, _ = oracle.csr2csc(rp, col, val, M)
+    Xl = torch.from_numpy(X[r0:r1].copy()).to(dev)
+    Gl = torch.from_numpy(G[r0:r1].copy()).to(dev)
+    for overlap in (False, True):
+        eng = dd.DistSpMM(part, N, overlap=overlap)
+        for red in ('sum', 'mean', 'max', 'min'):
+            C = eng.spmm(Xl, red)
+            Cg, Eg = oracle.spmm(red, rp, col, val, X, fma=True)
+            tag = f'rank {rank}/{world} overlap={overlap} {red}'
+            if red in ('max', 'min'):
+                assert_bitexact(C.cpu().numpy(), Cg[r0:r1], tag + ' values')
+                assert_bitexact(eng.last_E.cpu().numpy(), Eg[r0:r1], tag + ' E (global column ids)')
+            else:
+                sc = 1 if red == 'sum' else np.maximum(lens[r0:r1], 1)[:, None]
+                assert_sum_parity(C.cpu().numpy(), Cg[r0:r1], C64[r0:r1] / sc, S64[r0:r1] / sc, 1e-5, 2e-6, tag,
+                                  lens=lens[r0:r1])
+            # both gradients through the reversed exchange
+            Bl = Xl.clone().requires_grad_()
+            vl = part.val.clone().requires_grad_()
+            dd.DistSpMMFn.apply(eng, Bl, vl, red).backward(Gl)
+            if red in ('sum', 'mean'):
+                Gs = G if red == 'sum' else (G / np.maximum(lens, 1)[:, None]).astype(np.float32)
+                gB, _ = oracle.spmm('sum', cp, rw, tv, Gs, fma=True)
+                gW = oracle.sddmm(rp, col, Gs, X, fma=True)
+            else:
+                gB = oracle.spmm_mask(cp, rw, tv, G, Eg, fma=True)
+                gW = oracle.sddmm_mask(rp, col, G, X, Eg, fma=True)
+            assert_close(Bl.grad.cpu().numpy(), gB[r0:r1], 2e-5, 1e-5, tag + ' dB')
+            assert_close(vl.grad.cpu().numpy(), gW[s0:s1], 2e-5, 1e-5, tag + ' dW')
+        remote = np.unique(col[s0:s1][(col[s0:s1] < r0) | (col[s0:s1] >= r1)])
+        assert eng.n_halo == remote.shape[0] and eng.global_nnz == col.shape[0]
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f'dist hip worker rank {rank}/{world} ok')
+
+
+if __name__ == '__main__':
+    main()

@@ -30,8 +30,25 @@ class OracleOps:
 
     def csr2csc(self, rowptr, col, val, n_cols):
         import oracle
-        colptr, row, cscval, _ = oracle.csr2csc(rowptr.numpy(), col.numpy(), None if val is None else val.numpy(), n_cols)
-        return torch.from_numpy(colptr), torch.from_numpy(row), (None if cscval is None else torch.from_numpy(cscval))
+        colptr, row, cscval, perm = oracle.csr2csc(rowptr.numpy(), col.numpy(), None if val is None else val.numpy(), n_cols)
+        return (torch.from_numpy(colptr), torch.from_numpy(row), (None if cscval is None else torch.from_numpy(cscval)),
+                torch.from_numpy(perm))
+
+    def sddmm(self, rowptr, col, D1, D2, op=0, E=None):
+        import oracle
+        return torch.from_numpy(oracle.sddmm(rowptr.numpy(), col.numpy(), D1.numpy(), D2.numpy(), fma=True))
+
+    def spmm_arg_backward(self, rowptr, col, val, E, grad, dense, need_dense=True, need_values=True):
+        import oracle
+        rp, cl, v = rowptr.numpy(), col.numpy(), None if val is None else val.numpy()
+        K = dense.shape[0]
+        gX = gW = None
+        if need_dense:
+            colptr, row, tval, _ = oracle.csr2csc(rp, cl, v, K)
+            gX = torch.from_numpy(oracle.spmm_mask(colptr, row, tval, grad.numpy(), E.numpy(), fma=True))
+        if need_values:
+            gW = torch.from_numpy(oracle.sddmm_mask(rp, cl, grad.numpy(), dense.numpy(), E.numpy(), fma=True))
+        return gX, gW
 
 
 def _free_port():
@@ -79,6 +96,29 @@ def _worker(rank, world, port, cols, q):
         cp, rw, tv, _ = oracle.csr2csc(rp, col, val, M)
         gB, _ = oracle.spmm('sum', cp, rw, tv, G)
         res['backward'] = bool(np.allclose(Bl.grad.numpy(), gB[r0:r1], rtol=1e-5, atol=2e-6))
+        # every reduce, w.r.t. the feature rows AND the edge values, against the same formulas on the whole graph
+        # (single-GPU semantics: reference src/spmm.cpp:52-80,113-141 + the mean fix)
+        lens = np.diff(rp)
+        row_of = np.repeat(np.arange(M), lens)
+        s0, s1 = int(rp[r0]), int(rp[r1])
+        for red in ('sum', 'mean', 'max', 'min'):
+            for e in (eng, eng_ov):
+                Bl = torch.from_numpy(X[r0:r1].copy()).requires_grad_()
+                vl = torch.from_numpy(val[s0:s1].copy()).requires_grad_()
+                out = dd.DistSpMMFn.apply(e, Bl, vl, red)
+                out.backward(torch.from_numpy(G[r0:r1].copy()))
+                if red in ('sum', 'mean'):
+                    Gs = G if red == 'sum' else (G / np.maximum(lens, 1)[:, None]).astype(np.float32)
+                    gB, _ = oracle.spmm('sum', cp, rw, tv, Gs)
+                    gW = oracle.sddmm(rp, col, Gs, X, fma=True)
+                else:
+                    _, Eg = oracle.spmm(red, rp, col, val, X)
+                    gB = oracle.spmm_mask(cp, rw, tv, G, Eg, fma=True)
+                    gW = oracle.sddmm_mask(rp, col, G, X, Eg, fma=True)
+                key = f'bwd_{red}' + ('_overlap' if e is eng_ov else '')
+                res[key] = bool(np.allclose(Bl.grad.numpy(), gB[r0:r1], rtol=1e-5, atol=2e-6) and
+                                np.allclose(vl.grad.numpy(), gW[s0:s1], rtol=1e-5, atol=2e-6))
+        del row_of
         # plan sanity: halo = unique remote columns, send/recv splits are each other's transpose
         remote = np.unique(col[rp[r0]:rp[r1]][(col[rp[r0]:rp[r1]] < r0) | (col[rp[r0]:rp[r1]] >= r1)])
         res['halo'] = eng.n_halo == remote.shape[0]

@@ -275,3 +275,136 @@ def test_rccl_collectives_single_rank():
                           os.path.join(root, 'tests', 'nccl_selftest.py')], capture_output=True, text=True, env=env,
                          timeout=300)
     assert out.returncode == 0 and 'nccl selftest ok' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_coo_constructed_sparse_tensor_forward_backward():
+    """a caller-supplied COO `row` (CSR order) must not be mistaken for the CSC row indices: forward and both
+    gradients of a SparseTensor(row=..., col=...) equal those of the rowptr-constructed one; unsorted COO rows raise."""
+    import dgsparse
+    g = load_golden('small_weighted_N64')
+    rp, col, val = g['rowptr'], g['col'], g['val']
+    row = np.repeat(np.arange(rp.shape[0] - 1), np.diff(rp)).astype(np.int32)
+    G = torch.from_numpy(g['G']).cuda()
+    outs = []
+    for kw in (dict(rowptr=torch.from_numpy(rp).cuda()), dict(row=torch.from_numpy(row).cuda()),
+               dict(row=torch.from_numpy(row).cuda(), rowptr=torch.from_numpy(rp).cuda())):
+        v = torch.from_numpy(val).cuda().requires_grad_()
+        A = dgsparse.SparseTensor(col=torch.from_numpy(col).cuda(), values=v, has_value=True, **kw)
+        X = torch.from_numpy(g['X']).cuda().requires_grad_()
+        out = dgsparse.spmm_sum(A, X, 0)
+        out.backward(G)
+        outs.append((out.detach(), X.grad.clone(), v.grad.clone()))
+        assert_bitexact(A.storage.csc_row().cpu().numpy(), g['csc_row'])
+        if 'row' in kw:  # the COO rows stay what the caller gave
+            assert torch.equal(A.storage.row().cpu(), torch.from_numpy(row))
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert torch.equal(a, b)
+    assert_close(outs[1][1].cpu().numpy(), g['sum_dX'], RTOL, ATOL, 'dX of the COO-constructed tensor')
+    bad = row.copy()
+    bad[[0, -1]] = bad[[-1, 0]]
+    with pytest.raises(ValueError):
+        dgsparse.SparseTensor(row=torch.from_numpy(bad).cuda(), col=torch.from_numpy(col).cuda())
+
+
+def test_rectangular_csr2csc_and_square_only_op():
+    """dgsparse.csr2csc(SparseTensor) is exact for n_cols > n_rows; the reference-schema op (square-only, like
+    the reference's) refuses wide column ids instead of returning garbage."""
+    import scipy.sparse as sp
+    import dgsparse
+    rng = np.random.default_rng(3)
+    M, K, nnz = 50, 400, 900
+    A = sp.random(M, K, density=nnz / (M * K), format='csr', random_state=3, dtype=np.float32)
+    A.sort_indices()
+    rp, col, val = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float32)
+    st = dgsparse.SparseTensor(rowptr=torch.from_numpy(rp).cuda(), col=torch.from_numpy(col).cuda(),
+                               values=torch.from_numpy(val).cuda(), has_value=True)
+    colptr, crow, cval = dgsparse.csr2csc(st)
+    T = A.tocsc()
+    ncol = st.sparse_sizes[1]
+    assert_bitexact(colptr.cpu().numpy(), T.indptr[:ncol + 1].astype(np.int32))
+    assert_bitexact(crow.cpu().numpy(), T.indices.astype(np.int32))
+    assert_bitexact(cval.cpu().numpy(), T.data.astype(np.float32))
+    with pytest.raises(RuntimeError, match='square-only'):
+        torch.ops.dgsparse_spmm.csr2csc(torch.from_numpy(rp).cuda(), torch.from_numpy(col).cuda(),
+                                        torch.from_numpy(val).cuda())
+    del rng
+
+
+def test_raw_ops_validate_devices_and_shapes():
+    """direct torch.ops calls get cheap argument checks instead of out-of-bounds reads."""
+    g = load_golden('tiny_N32')
+    rp, col, val = (torch.from_numpy(g[k]).cuda() for k in ('rowptr', 'col', 'val'))
+    X = torch.from_numpy(g['X']).cuda()
+    with pytest.raises(RuntimeError, match='GPU'):
+        torch.ops.dgsparse_spmm.spmm_raw(0, rp.cpu(), col, val, X, True, 0)
+    with pytest.raises(RuntimeError, match='one entry per stored element'):
+        torch.ops.dgsparse_spmm.spmm_raw(0, rp, col, val[:-1], X, True, 0)
+    with pytest.raises(RuntimeError):
+        torch.ops.dgsparse_spmm.sddmm(rp, col, X[:, :8].contiguous(), X, 0)
+    if torch.cuda.device_count() > 1:
+        with pytest.raises(RuntimeError, match='different devices'):
+            torch.ops.dgsparse_spmm.spmm_raw(0, rp, col, val, X.to('cuda:1'), True, 0)
+
+
+@pytest.mark.parametrize('reduce', ['sum', 'mean', 'max'])
+def test_public_ops_use_the_storage_plans(reduce):
+    """A graph on the row-stream schedule: the Storage builds the forward plan (and, for sum/mean with a dense gradient, the
+    plan of the transposed product) on first use, the public operator runs on them, and forward + both gradients still
+    meet the bars against the oracle."""
+    import dgsparse
+    import oracle
+    from bench import graphgen
+    rp, col, st = graphgen.powerlaw_csr(70000, 900000, alpha=1.9, dmax=20000, seed=9)
+    M, K, N = st['M'], st['K'], 16
+    val = graphgen.weights(col.shape[0], 'uniform', 1)
+    X = graphgen.features(K, N, 2)
+    G = graphgen.features(M, N, 3)
+    v = torch.from_numpy(val).cuda().requires_grad_()
+    A = dgsparse.SparseTensor(rowptr=torch.from_numpy(rp).cuda(), col=torch.from_numpy(col).cuda(), values=v,
+                              has_value=True)
+    Xd = torch.from_numpy(X).cuda().requires_grad_()
+    fn = {'sum': dgsparse.spmm_sum, 'mean': dgsparse.spmm_mean, 'max': dgsparse.spmm_max}[reduce]
+    out = fn(A, Xd, 0)
+    assert A.storage.spmm_plan('csr', N)[0] is not None and 'csr' in A.storage._plans
+    out.backward(torch.from_numpy(G).cuda())
+    if reduce != 'max':
+        assert A.storage._plans.get('csc') is not None and A.storage._tvalues is not None
+    Co, Eo = oracle.spmm(reduce, rp, col, val, X, fma=True)
+    lens = np.diff(rp)
+    if reduce == 'max':
+        assert_bitexact(out.detach().cpu().numpy(), Co)
+    else:
+        assert_close(out.detach().cpu().numpy(), Co, 2e-5, ATOL, f'{reduce} forward through the plan')
+    # gradients against the formulas on the oracle (A^T G with per-row scaling for mean; arg-masked for max)
+    colptr, crow, tval, _ = oracle.csr2csc(rp, col, val, K)
+    if reduce == 'sum':
+        gX, _ = oracle.spmm('sum', colptr, crow, tval, G, fma=True)
+        gW = oracle.sddmm(rp, col, G, X, fma=True)
+    elif reduce == 'mean':
+        Gs = (G / np.maximum(lens, 1)[:, None]).astype(np.float32)
+        gX, _ = oracle.spmm('sum', colptr, crow, tval, Gs, fma=True)
+        gW = oracle.sddmm(rp, col, Gs, X, fma=True)
+    else:
+        row_of = np.repeat(np.arange(M), lens)
+        hit = Eo[row_of] == col[:, None]  # [nnz, N]: this entry is the arg of (row, f)
+        gW = (hit * G[row_of] * X[col]).sum(1).astype(np.float32)
+        gX = np.zeros((K, N), np.float64)
+        np.add.at(gX, col, hit * (val[:, None].astype(np.float64) * G[row_of]))
+    assert_close(Xd.grad.cpu().numpy(), gX, 3e-5, 1e-5, f'{reduce} dX through the transposed plan')
+    assert_close(v.grad.cpu().numpy(), gW, 3e-5, 1e-5, f'{reduce} dA')
+
+
+def test_gin_cached_neighbourhood_is_keyed_on_the_graph():
+    """cached=True must not reuse the first adjacency for another edge_index."""
+    from dgsparse import nn as dnn
+    conv = dnn.GINConv(None, 'sum', cached=True).cuda()
+    e1 = torch.tensor([[0, 1, 2], [1, 2, 0]], device='cuda')
+    e2 = torch.tensor([[0, 1, 2, 3], [1, 0, 3, 2]], device='cuda')
+    X = torch.eye(4, device='cuda')
+    a = conv(e1, X[:3, :3].contiguous(), 3)
+    d1 = conv._cached_dcsr
+    assert conv(e1, X[:3, :3].contiguous(), 3).equal(a) and conv._cached_dcsr is d1
+    b = conv(e2, X, 4)
+    assert conv._cached_dcsr is not d1 and b.shape == (4, 4)
+    assert torch.equal(b, X + X[[1, 0, 3, 2]])

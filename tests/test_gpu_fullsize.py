@@ -48,6 +48,7 @@ CONFIGS = [  # (name, feat, reduces)   BASELINE.json configs[1], [2], north_star
     ('arxiv', 64, ('sum',)),
     ('synth1m', 64, ('sum', 'max')),
     ('synth1m', 32, ('sum',)),
+    ('synth1m', 128, ('sum', 'max')),
     ('reddit', 128, ('sum', 'max')),
 ]
 

@@ -511,3 +511,33 @@ def test_arg_backward_single_pass(capi, N):
     assert gX is None
     assert_close(gW.cpu().numpy(), oracle.sddmm_mask(rp, col, G, X, E, fma=True), RTOL, ATOL, 'gW only')
 
+
+
+def test_fuzz_slice_seeded():
+    """A bounded, seeded slice of the randomized campaign tests/fuzz_gpu.py (which found the MIN +-0 / NaN rules in round
+    1): ~60 s of random shapes, degree laws, value kinds, unsorted and duplicate columns through every entry point, with
+    the same bars.  The full campaign stays a manual tool (python tests/fuzz_gpu.py SECONDS SEED)."""
+    import time
+    import fuzz_gpu
+    rng = np.random.default_rng(20260928)
+    t0, n = time.time(), 0
+    while time.time() - t0 < 60 and n < 400:
+        fuzz_gpu.one_case(rng, 77000 + n)
+        n += 1
+    assert n >= 20, f'only {n} fuzz cases in 60 s'
+
+
+def test_reference_harness_smoke():
+    """The reference's benchmark harness rebuilt in bench/bench_spmm_time.py (benchmark/bench_spmm_time.py:440-464):
+    one dataset shape, 3 iterations, forward and forward+backward of all four reduces must run and report times."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench', 'bench_spmm_time.py'), '--datasets', 'cora', '--feats',
+                        '32', '--iters', '3', '--no-baseline'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    j = json.loads(line)
+    assert j, j

@@ -46,11 +46,12 @@ def parse_plan(plan, nnz):
     hdr = raw[:256].view(np.int32)
     h = dict(magic=int(hdr[0]), version=int(hdr[1]), M=int(hdr[2]), nnz=int(hdr[3]), K=int(hdr[4]), n_units=int(hdr[5]),
              n_long=int(hdr[6]), n_pslots=int(hdr[7]), ch=int(hdr[8]), t1=int(hdr[9]), tslice=int(hdr[10]),
-             xcd_start=hdr[11:20].copy(), slice_bound=hdr[20:29].copy())
+             unit=int(hdr[11]), xcd_start=hdr[12:21].copy(), slice_bound=hdr[21:30].copy(),
+             bounds=raw[256:256 + 129 * 4].view(np.int32).copy())
     up = lambda x: (x + 255) & ~255
-    max_units = nnz // 64 + 8 * (nnz // 128) + nnz // 256 + 16
+    max_units = nnz // 64 + 8 * (nnz // 128) + nnz // 16 + nnz // 256 + 16
     max_long = nnz // 128 + nnz // 256 + 2
-    off_units = 256
+    off_units = 256 + 768
     off_long = off_units + up(max_units * 16)
     units = raw[off_units:off_units + h['n_units'] * 16].view(np.int32).reshape(-1, 4)
     longrows = raw[off_long:off_long + h['n_long'] * 16].view(np.int32).reshape(-1, 4)
@@ -95,6 +96,7 @@ def test_plan_tables_cover_long_rows_exactly(capi, unsorted):
     xs = h['xcd_start']
     assert xs[0] == 0 and xs[8] == h['n_units'] and (np.diff(xs) >= 0).all()
     sb = h['slice_bound'].astype(np.int64)
+    assert (h['bounds'][::16] == h['slice_bound']).all() and (np.diff(h['bounds'].astype(np.int64)) >= 0).all()
     sorted_row = np.array([bool((np.diff(col[rp[r]:rp[r + 1]]) >= 0).all()) for r in long_rows])
     sliced_rows = set(long_rows[sorted_row & (lens[long_rows] > h['tslice'])].tolist())
     n_sliced_units = 0
