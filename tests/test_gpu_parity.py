@@ -429,6 +429,23 @@ def test_gspmm_u_e_all_ops(capi, N):
             assert_close(out, ref, RTOL, 1e-5, f'u {red.name}')
 
 
+def test_gspmm_vs_torch_emulation_fixture(capi):
+    """The HIP gSpMM against the fixture generated OUTSIDE the oracle (tests/golden/make_gspmm_golden.py: plain torch
+    elementwise compute + scatter_reduce): every REDUCEOP x COMPUTEOP, empty rows included."""
+    import os
+    from dgsparse import gspmm
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'gspmm_dyadic_N8.npz'))
+    drp, dcol, dval, dX = dev(z['rowptr']), dev(z['col']), dev(z['val']), dev(z['X'])
+    for red in gspmm.REDUCEOP:
+        for comp in gspmm.COMPUTEOP:
+            out = gspmm.GSpMM_u_e(drp, dcol, dval.view(-1, 1), dX, red, comp).cpu().numpy()
+            exp = z[f'{red.name.lower()}_{comp.name.lower()}']
+            if comp == gspmm.COMPUTEOP.DIV or red == gspmm.REDUCEOP.MEAN:
+                assert_close(out, exp, RTOL, 1e-6, f'{red.name} {comp.name}')
+            else:  # exact values; +0 == -0 (torch's amin/amax tie rule for signed zeros is not the reference macro's)
+                assert np.array_equal(out, exp), f'{red.name} {comp.name}'
+
+
 @pytest.mark.parametrize('N', [16, 64])
 def test_signed_zero_ties_on_split_rows(capi, N):
     """+0.0 and -0.0 compare equal but differ in bits.  The reference macros keep the EARLIER operand on a MAX tie and

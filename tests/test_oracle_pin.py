@@ -2,6 +2,8 @@
 torch.sparse.mm / _sparse_mm_reduce_impl (the reference tests' oracle), the reference's own
 spmm_reference_host / sddmm_reference_host (oracle/_ref) and scipy tocsc -- see tests/golden/make_golden.py.
 CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -104,3 +106,21 @@ def test_nan_and_identity_semantics():
     X2 = np.full((3, 1), -3e9, np.float32)
     C, E = oracle.spmm('max', rp, col, val, X2)
     assert C[0, 0] == np.float32(-2147483648.0) and E[0, 0] == -1
+
+
+def test_gspmm_oracle_vs_torch_emulation_fixture():
+    """orc_gspmm_csr_f32 (restating src/gspmm-fp/gspmm.cu:212-245) against tests/golden/gspmm_dyadic_N8.npz, whose expected
+    outputs come from plain torch (elementwise compute on gathered rows + Tensor.scatter_reduce_), see
+    tests/golden/make_gspmm_golden.py.  Dyadic inputs make add/sub/mul exact in any order; div within 1e-5."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'gspmm_dyadic_N8.npz'))
+    rp, col, val, X = z['rowptr'], z['col'], z['val'], z['X']
+    assert (np.diff(rp) == 0).sum() >= 50
+    for ri, red in enumerate(('sum', 'max', 'min', 'mean')):
+        for ci, comp in enumerate(('add', 'sub', 'mul', 'div')):
+            got = oracle.gspmm(ri, ci, rp, col, val, X)
+            exp = z[f'{red}_{comp}']
+            if comp == 'div' or red == 'mean':
+                np.testing.assert_allclose(got, exp, rtol=1e-5, atol=1e-6, err_msg=f'{red} {comp}')
+            else:
+                assert np.array_equal(got, exp), f'{red} {comp}'  # exact values (+0 == -0: torch's amin/amax tie rule
+                #                                                     for signed zeros is not the reference macro's)
