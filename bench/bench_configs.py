@@ -41,6 +41,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--quick', action='store_true')
     ap.add_argument('--only', default='')
+    ap.add_argument('--no-plan', action='store_true', help='plan-free calls only (default: cached locality plan where one applies)')
     a = ap.parse_args()
     it = 20 if a.quick else 100
     cfgs = [  # (label, graph, op, feat)
@@ -72,15 +73,18 @@ def main():
         g.manual_seed(1)
         val = torch.rand(nnz, generator=g, device='cuda')
         X = torch.rand((K, N), generator=g, device='cuda')
+        sched = ''
         if op == 'sddmm':
             D1 = torch.rand((M, N), generator=g, device='cuda')
             t = timeit(lambda: _capi.sddmm(rp, col, D1, X), iters=it)
             balg = 4 * (M + 1) + 8 * nnz + 4 * (M + K) * N
         else:
             o = {'sum': 0, 'max': 1, 'min': 2, 'mean': 3}[op]
-            t = timeit(lambda: _capi.spmm(o, rp, col, val, X), iters=it)
+            plan = None if a.no_plan else _capi.spmm_plan(rp, col, K, N)
+            sched = _capi.spmm_schedule(o, M, K, N, nnz) + ('+plan' if plan is not None else '')
+            t = timeit(lambda: _capi.spmm(o, rp, col, val, X, plan=plan), iters=it)
             balg = 4 * (M + 1) + 8 * nnz + 4 * K * N + 4 * M * N * (2 if op in ('max', 'min') else 1)
-        print(json.dumps(dict(config=label, graph=gname, M=M, nnz=nnz, max_deg=st['max_deg'], op=op, feat=N,
+        print(json.dumps(dict(config=label, graph=gname, M=M, nnz=nnz, max_deg=st['max_deg'], op=op, feat=N, schedule=sched,
                               us=round(t * 1e6, 2), gflops=round(2.0 * nnz * N / t / 1e9, 1),
                               alg_gbs=round(balg / t / 1e9, 1), frac=round(balg / t / 1e9 / PEAK, 4))), flush=True)
 

@@ -144,7 +144,8 @@ static inline WsLayout ws_layout_plan(int reduce_op, int64_t N, int64_t pslots) 
 // plan buffer: [256-byte header][column grid: 129 ints][units: max_units int4][long rows: max_long int4][pcol: nnz
 // int32]; the capacities
 // (and so the offsets) are a pure function of nnz, the actual counts live in the header
-constexpr int kPlanCh = 256;          // unit length of the plan's unit table
+constexpr int kPlanCh = 256;          // unit length of the plan's unit table (large inputs)
+constexpr int kPlanChMin = 64;        // ... and the shortest one it uses (small inputs)
 constexpr int kPlanSliceMin = 128;    // smallest row length that may be cut on the column grid
 constexpr int kPlanUnitMin = 16;      // smallest nnz-per-cell target of a cut row
 constexpr int kPlanCells = 128;       // finest column grid: 8 slices (one per XCD) x 16 cells
@@ -156,8 +157,8 @@ static inline PlanLayout plan_layout(int64_t nnz) {
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
   PlanLayout L;
   // a cut row of L nnz has at most max(8, L / kPlanUnitMin) cells, each with one ragged unit, plus L / ch full ones
-  L.max_units = nnz / kT1 + 8 * (nnz / kPlanSliceMin) + nnz / kPlanUnitMin + nnz / kPlanCh + 16;
-  L.max_long = nnz / kPlanSliceMin + nnz / kPlanCh + 2;
+  L.max_units = nnz / kT1 + 8 * (nnz / kPlanSliceMin) + nnz / kPlanUnitMin + nnz / kPlanChMin + 16;
+  L.max_long = nnz / kPlanSliceMin + nnz / kPlanChMin + 2;
   L.off_bounds = 256;
   L.off_units = 256 + 768;  // (kPlanCells + 1) ints
   L.off_long = L.off_units + up((size_t)L.max_units * sizeof(int4));
@@ -749,7 +750,7 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
 // each own 4 x 64 consecutive rows.  Unit blocks come first so that the longest-running work starts first; the
 // two kinds of work share the CUs, so the fabric-bound unit gathers overlap the row kernel's latency phases.
 template <int G, int V, int OP, bool HAS_VAL>
-__global__ __launch_bounds__(kBlock) void spmm_fused(int M, int N, int nbu, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(kBlock) void spmm_fused(int M, int N, int nbu, int rpw, const int *__restrict__ rowptr,
                                                      const int *__restrict__ col, const float *__restrict__ val,
                                                      const float *__restrict__ B, float *__restrict__ C,
                                                      int *__restrict__ E, const UnitTab ut, float *__restrict__ part,
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(kBlock) void spmm_fused(int M, int N, int nbu, cons
     const int per = nbr / 8;
     if (rb < per * 8) rb = (rb % 8) * per + rb / 8;
 #endif
-    spmm_rows_body<G, V, OP, HAS_VAL, false>(rb, kRowsPerWave, lds, M, N, rowptr, col, val, B, C, E);
+    spmm_rows_body<G, V, OP, HAS_VAL, false>(rb, rpw, lds, M, N, rowptr, col, val, B, C, E);
   }
 }
 
@@ -1004,7 +1005,7 @@ static int launch_all(const SpmmArgs &a) {
       }
       const int nbu = 1024;
       hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)nbu, (unsigned)a.tiles), dim3(kBlock), 0, a.st, (int)a.M,
-                         (int)a.N, nbu, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
+                         (int)a.N, nbu, kRowsPerWave, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
       const int64_t cb = (L.max_long + 3) / 4;
       const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
       hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B,
@@ -1023,7 +1024,11 @@ static int launch_all(const SpmmArgs &a) {
                        a.rowptr, a.col, a.val, a.B, a.C, a.E);
     return check_launch();
   }
-  const int rows_per_block = (kBlock / kWave) * kRowsPerWave;
+  // rows per wave: 64 when there are plenty of rows; mid-size graphs (arxiv-shaped: 169 k rows, 6.5 nnz/row) get fewer,
+  // so that the chip still sees >= ~8k waves and a group's sequential stream stays a few gather rounds long
+  int rpw = kRowsPerWave;
+  while (rpw > 8 && a.M / rpw < env_int("DGS_MIN_WAVES", 8192)) rpw >>= 1;
+  const int rows_per_block = (kBlock / kWave) * rpw;
   const int64_t nbr = (a.M + rows_per_block - 1) / rows_per_block;
 #ifndef DGS_NBU
 #define DGS_NBU 1024
@@ -1045,12 +1050,12 @@ static int launch_all(const SpmmArgs &a) {
     const int nbu = (int)(ub < DGS_NBU ? (ub < 8 ? 8 : ub) : DGS_NBU);
     if (env_int("DGS_SPLIT", 0)) {  // experiment: unit blocks and row blocks as two launches (no L2 sharing in time)
       hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)nbu, (unsigned)a.tiles), dim3(kBlock), 0, a.st,
-                         (int)a.M, (int)a.N, nbu, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
+                         (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
       hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)nbr, (unsigned)a.tiles), dim3(kBlock), 0, a.st,
-                         (int)a.M, (int)a.N, 0, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
+                         (int)a.M, (int)a.N, 0, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
     } else
     hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
-                       a.st, (int)a.M, (int)a.N, nbu, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
+                       a.st, (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
     if (a.plan_long > 0) {
       const int64_t cb = ((int64_t)a.plan_long + 3) / 4;
       const dim3 g3((unsigned)(cb < 2048 ? cb : 2048), (unsigned)a.tiles);
@@ -1075,7 +1080,7 @@ static int launch_all(const SpmmArgs &a) {
   const int64_t ub = (L.max_units + 3) / 4;
   const int nbu = (int)(ub < DGS_NBU ? (ub < 1 ? 1 : ub) : DGS_NBU);
   hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
-                     a.st, (int)a.M, (int)a.N, nbu, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
+                     a.st, (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
   // combine: one wave per multi-unit row
   const int64_t cb = (L.max_long + 3) / 4;
   const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);

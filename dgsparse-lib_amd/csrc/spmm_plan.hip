@@ -283,7 +283,7 @@ static int plan_tslice() {
   return t;
 }
 static int plan_unit() {  // nnz per cell a cut row should keep (decides how fine long rows are cut on the column grid)
-  int u = env_int("DGS_PLAN_UNIT", 32);
+  int u = env_int("DGS_PLAN_UNIT", 64);
   if (u < kPlanUnitMin) u = kPlanUnitMin;
   return u;
 }
@@ -326,7 +326,10 @@ extern "C" int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int3
   unsigned long long *keys_out = reinterpret_cast<unsigned long long *>(ws + WL.off_keys_out);
   int4 *units_in = reinterpret_cast<int4 *>(ws + WL.off_units_in);
   void *tmp = ws + WL.off_tmp;
-  const int ch = kPlanCh, tslice = plan_tslice(), unit = plan_unit();
+  // unit length: 256 nnz when there is plenty of work; smaller inputs get shorter units (a unit is a chain of up to
+  // ch/64 dependent tiles, and a mid-size graph has too few units to hide it)
+  const int ch = env_int("DGS_PLAN_CH", nnz >= (8 << 20) ? kPlanCh : (nnz >= (2 << 20) ? 128 : 64));
+  const int tslice = plan_tslice(), unit = plan_unit();
 
   if (hipMemsetAsync(hdr, 0, PL.off_units, st) != hipSuccess) return DGS_ELAUNCH;
   if (hipMemsetAsync(ws, 0, WL.off_list, st) != hipSuccess) return DGS_ELAUNCH;           // counters, cnt, cum

@@ -49,8 +49,8 @@ def parse_plan(plan, nnz):
              unit=int(hdr[11]), xcd_start=hdr[12:21].copy(), slice_bound=hdr[21:30].copy(),
              bounds=raw[256:256 + 129 * 4].view(np.int32).copy())
     up = lambda x: (x + 255) & ~255
-    max_units = nnz // 64 + 8 * (nnz // 128) + nnz // 16 + nnz // 256 + 16
-    max_long = nnz // 128 + nnz // 256 + 2
+    max_units = nnz // 64 + 8 * (nnz // 128) + nnz // 16 + nnz // 64 + 16
+    max_long = nnz // 128 + nnz // 64 + 2
     off_units = 256 + 768
     off_long = off_units + up(max_units * 16)
     units = raw[off_units:off_units + h['n_units'] * 16].view(np.int32).reshape(-1, 4)
