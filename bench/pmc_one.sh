@@ -7,4 +7,5 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 (cd "$REPO" && rocprofv3 --pmc $CTRS --output-format csv -d "$OUT/run" -- "$@" > "$OUT/run.log" 2>&1)
-python "$REPO/bench/pmc_summary.py" "$OUT"
+python "$REPO/bench/pmc_summary.py" "$OUT" | tee "$OUT/summary.txt"
+if [ "${PMC_KEEP_RAW:-0}" != 1 ]; then rm -rf "$OUT/run"; fi

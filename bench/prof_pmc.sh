@@ -16,4 +16,5 @@ run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
 run dram TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
 run sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT
 python "$REPO/bench/pmc_summary.py" "$OUT" > "$OUT/summary.txt" 2>&1
+if [ "${PMC_KEEP_RAW:-0}" != 1 ]; then for t in fetch write tcc dram sq; do rm -rf "$OUT/$t"; done; fi  # raw csvs are ~10 MB per pass
 cat "$OUT/summary.txt"

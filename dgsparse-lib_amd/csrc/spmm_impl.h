@@ -896,6 +896,7 @@ struct SpmmArgs {
   // cached plan (dgs_spmm_plan_build): device tables + the counts the host needs to size grids and the workspace
   const struct PlanHdr *plan = nullptr;
   int plan_units = 0, plan_long = 0, plan_pslots = 0;
+  int hints = 0;  // DGS_ALG_* bits of the `algorithm` argument
 };
 
 // Device-resident header of a cached plan, followed by the tables (all offsets in bytes from the header).
@@ -932,7 +933,8 @@ static inline int env_int(const char *k, int dflt) {
 static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
   PanelPlan P{};
   const int force = env_int("DGS_PANEL", -1);
-  if (force == 0 || !a.ws || (tiles != 1 && G != 64) || G < 8 || a.N % 4 || a.M <= 0) return P;
+  // the sweep needs one workgroup per CU, all co-resident: not on a GPU the caller shares with other kernels
+  if (force == 0 || !a.ws || (tiles != 1 && G != 64) || G < 8 || a.N % 4 || a.M <= 0 || (a.hints & DGS_ALG_SHARED_GPU)) return P;
   P.nwg = cu_count();
   const bool arg = (a.reduce_op == DGS_MAX || a.reduce_op == DGS_MIN);
   const int64_t W = a.N < 256 ? a.N : 256;  // feature tile per launch (wider operands: one sweep per 256 features)

@@ -30,7 +30,7 @@ extern "C" int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_
 extern "C" int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,
                                 const int32_t *col, const float *val, const float *B, float *C, int32_t *E,
                                 int algorithm, void *workspace, size_t workspace_bytes, dgsStream_t stream) {
-  (void)algorithm;  // every algorithm id returns the algorithm-0 result
+  // every algorithm id returns the algorithm-0 result; bits from 8 up are scheduling hints
   if (reduce_op < DGS_SUM || reduce_op > DGS_MEAN || M < 0 || K < 0 || N < 0 || nnz < 0) return DGS_EINVAL;
   if (M >= INT32_MAX || K >= INT32_MAX || N >= INT32_MAX || nnz >= INT32_MAX) return DGS_ERANGE;
   const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
@@ -46,6 +46,7 @@ extern "C" int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, 
                   (need == 0 || is_aligned16(workspace));
   const FeatMap fm = feat_map(N, al);
   SpmmArgs a{M, K, N, nnz, rowptr, col, val, B, C, arg ? E : nullptr, fm.tiles, need ? workspace : nullptr, st, reduce_op};
+  a.hints = algorithm & ~0xff;
   return run(fm, a);
 }
 

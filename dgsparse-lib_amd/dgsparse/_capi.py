@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdgsparse_hip.so')
 
 SUM, MAX, MIN, MEAN = 0, 1, 2, 3  # include/gspmm.h:13 in the reference
+ALG_SHARED_GPU = 0x100  # `algorithm` hint bit: the GPU is shared with concurrently running kernels
 
 if not os.path.exists(LIB_PATH):  # mirrors dgsparse/__init__.py:25 in the reference (ImportError, no fallback)
     raise ImportError(f"Could not find the HIP kernel library '{LIB_PATH}'. Build it with "

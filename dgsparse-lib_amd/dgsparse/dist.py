@@ -200,8 +200,10 @@ class _HipOps:
             self._plans[key] = self._c.spmm_plan(rowptr, col, K, N) if col.numel() else None
         return self._plans[key]
 
-    def spmm(self, op, rowptr, col, val, B):
-        return self._c.spmm(op, rowptr, col, val, B, plan=self._plan(rowptr, col, B.shape[0], B.shape[1]))
+    def spmm(self, op, rowptr, col, val, B, shared_gpu=False):
+        """shared_gpu: a collective is in flight on another stream: keep off schedules that need every CU."""
+        return self._c.spmm(op, rowptr, col, val, B, algorithm=self._c.ALG_SHARED_GPU if shared_gpu else 0,
+                            plan=self._plan(rowptr, col, B.shape[0], B.shape[1]))
 
     def sddmm(self, rowptr, col, D1, D2, op=0, E=None):
         return self._c.sddmm(rowptr, col, D1, D2, op, E=E)
@@ -278,7 +280,7 @@ class DistSpMM:
             B_ext, work = self.exchange(B_loc, async_op=True)
             vl = plan.loc[2] if val is None else val[plan.nnz_pos_loc]
             vr = plan.rem[2] if val is None else val[plan.nnz_pos_rem]
-            C, _ = self.ops.spmm(0, plan.loc[0], plan.loc[1], vl, B_ext[:p.n_local])  # overlaps the exchange
+            C, _ = self.ops.spmm(0, plan.loc[0], plan.loc[1], vl, B_ext[:p.n_local], shared_gpu=True)  # overlaps the exchange
             if work is not None:
                 work.wait()  # current stream waits for the collective; the host does not block
             if plan.rem_rows.numel() > 0:

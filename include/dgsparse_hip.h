@@ -55,7 +55,12 @@ const char *dgs_strerror(int code);
  *   (float)INT_MIN / (float)INT_MAX; empty row -> 0 / -1).  SUM/MEAN: sequential CSR order for rows up
  *   to the split threshold (bit-exact vs an fmaf chain), fixed-tree split above it (<=1e-5 rel).
  *   workspace: dgs_spmm_csr_workspace_bytes() bytes, 256-B aligned; contents undefined on entry/exit.
+ *   algorithm: low byte = the reference's algorithm id (a hint, ignored); higher bits = scheduling hints:
+ *     DGS_ALG_SHARED_GPU  other kernels run concurrently on this GPU (e.g. an overlapped RCCL collective): do not take
+ *                         the column-panel sweep, whose soft barrier assumes one workgroup per CU, all co-resident
+ *                         (correct but several times slower when CUs are taken away).
  */
+#define DGS_ALG_SHARED_GPU 0x100
 size_t dgs_spmm_csr_workspace_bytes(int reduce_op, int64_t M, int64_t N, int64_t nnz);
 int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz,
                      const int32_t *rowptr, const int32_t *col, const float *val, const float *B,

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class OracleOps:
-    def spmm(self, op, rowptr, col, val, B):
+    def spmm(self, op, rowptr, col, val, B, shared_gpu=False):
         import oracle
         C, E = oracle.spmm(op, rowptr.numpy(), col.numpy(), None if val is None else val.numpy(), B.numpy())
         return torch.from_numpy(C), (torch.from_numpy(E) if op in (1, 2) else None)

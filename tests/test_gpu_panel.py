@@ -322,3 +322,44 @@ def test_panel_odd_feature_width_is_padded(capi, monkeypatch, N):
     got = capi.sddmm(dev(rp), dev(col), dev(D1), dev(X), E=dev(Eo)).cpu().numpy()
     np.testing.assert_allclose(got, oracle.sddmm_mask(rp, col, D1, X, Eo, fma=True), rtol=1e-5, atol=2e-6)
 
+
+
+def test_panel_next_to_a_cu_hogging_stream_and_the_shared_gpu_hint(capi):
+    """the column-panel sweep assumes one workgroup per CU, all co-resident.  (1) While a second stream
+    keeps the CUs busy the sweep must stay CORRECT (its soft barrier is a bounded hint, never a dependency); (2) with the
+    DGS_ALG_SHARED_GPU hint - what dgsparse.dist passes for the product it overlaps with the halo all-to-all - the call
+    takes the row-stream schedule instead, gives the same result (sum bit-exact for rows <= 64 nnz, 1e-5 above) and is not
+    slower than the contended sweep."""
+    import time
+    M, K, N = 40000, 40000, 128
+    rp, col = dense_graph(M, K, 300, 600, seed=17)  # 'panel' by the default rule (reuse >= 5.5)
+    assert capi.spmm_schedule(oracle.SUM, M, K, N, col.size) == 'panel'
+    rng = np.random.default_rng(3)
+    val = rng.random(col.size, dtype=np.float32)
+    X = rng.random((K, N), dtype=np.float32)
+    rpd, cold, vald, Xd = dev(rp), dev(col), dev(val), dev(X)
+    ref, _ = capi.spmm(oracle.SUM, rpd, cold, vald, Xd)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    A = torch.rand(4096, 4096, device='cuda')
+
+    def contended(algorithm):
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(12):
+                A @ A  # noqa: B018  (keeps every CU busy on the side stream for several ms)
+        t0 = time.perf_counter()
+        out, _ = capi.spmm(oracle.SUM, rpd, cold, vald, Xd, algorithm=algorithm)
+        torch.cuda.current_stream().synchronize()
+        dt = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        return out, dt
+
+    out_panel, t_panel = contended(0)
+    assert torch.equal(out_panel, ref), 'the sweep under contention must give the very same bits (one chain per row)'
+    out_rows, t_rows = contended(capi.ALG_SHARED_GPU)
+    lens = np.diff(rp)
+    C64 = oracle.spmm_sum_f64(rp, col, val, X)
+    assert_sum_parity(out_rows.cpu().numpy(), ref.cpu().numpy(), C64, None, 1e-5, 2e-6, 'row-stream under the hint', lens=lens)
+    print(f'contended: panel sweep {t_panel * 1e3:.2f} ms, row-stream (shared-GPU hint) {t_rows * 1e3:.2f} ms')
+    assert t_rows < 3.0 * t_panel + 5e-3
