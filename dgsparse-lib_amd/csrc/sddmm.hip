@@ -98,8 +98,13 @@ __device__ __forceinline__ void sd_tile_dots(const int2 *tile, int *cnt, int cnt
   if (lane < cntn) out[t0 + lane] = __int_as_float(cnt[lane]);
 }
 
+// compiled for 5 waves per SIMD (96 VGPRs, no spills; the natural 108 give 4): 554 -> 494 us on the 1M power-law graph,
+// 2.34 -> 2.23 ms products-shaped; 6 waves spill 21 registers and lose (643 us)
+#ifndef DGS_SD_WAVES
+#define DGS_SD_WAVES 5
+#endif
 template <int G, int V, bool MEAN, bool MASK>
-__global__ __launch_bounds__(kBlock) void sddmm_nnzbal(int M, int F, int tiles, int nnz,
+__global__ __launch_bounds__(kBlock, DGS_SD_WAVES) void sddmm_nnzbal(int M, int F, int tiles, int nnz,
                                                        const int *__restrict__ rowptr, const int *__restrict__ col,
                                                        const float *__restrict__ D1, const float *__restrict__ D2,
                                                        const int *__restrict__ E, float *__restrict__ out) {

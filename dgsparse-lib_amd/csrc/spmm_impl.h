@@ -746,11 +746,21 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Waves per SIMD the fused kernel is compiled for.  The kernel hides DRAM latency with waves, not with a deep per-wave
+// pipeline: max went 0.650 -> 0.523 ms on the headline graph when 106 VGPRs (4 waves) became 96 (5 waves, 6 spilled).
+#ifndef DGS_WAVES_SUM
+#define DGS_WAVES_SUM 5
+#endif
+#ifndef DGS_WAVES_ARG
+#define DGS_WAVES_ARG 5
+#endif
+constexpr int fused_waves_per_simd(int op) { return (op == DGS_MAX || op == DGS_MIN) ? DGS_WAVES_ARG : DGS_WAVES_SUM; }
+
 // Fused launch: blocks [0, nbu) walk the unit table of the huge rows (persistent, strided), the remaining blocks
 // each own 4 x 64 consecutive rows.  Unit blocks come first so that the longest-running work starts first; the
 // two kinds of work share the CUs, so the fabric-bound unit gathers overlap the row kernel's latency phases.
 template <int G, int V, int OP, bool HAS_VAL>
-__global__ __launch_bounds__(kBlock) void spmm_fused(int M, int N, int nbu, int rpw, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(kBlock, fused_waves_per_simd(OP)) void spmm_fused(int M, int N, int nbu, int rpw, const int *__restrict__ rowptr,
                                                      const int *__restrict__ col, const float *__restrict__ val,
                                                      const float *__restrict__ B, float *__restrict__ C,
                                                      int *__restrict__ E, const UnitTab ut, float *__restrict__ part,
