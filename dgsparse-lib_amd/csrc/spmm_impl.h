@@ -77,7 +77,10 @@ constexpr int kRowsPerWave = 64;
 #define DGS_KU1 6
 #endif
 constexpr int kU1 = DGS_KU1;   // rolling window of B-row gathers per lane in the row stream
-constexpr int kU = 8;          // gathers in flight per lane in the wave-cooperative unit loop
+#ifndef DGS_KU
+#define DGS_KU 8
+#endif
+constexpr int kU = DGS_KU;     // gathers in flight per lane in the wave-cooperative unit loop
 
 struct SpmmWs {       // workspace header (zeroed every call with one 16-byte memset)
   int n_units;        // K0 -> fused/K2: number of unit descriptors
@@ -949,9 +952,11 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
   const bool arg = (a.reduce_op == DGS_MAX || a.reduce_op == DGS_MIN);
   const int64_t W = a.N < 256 ? a.N : 256;  // feature tile per launch (wider operands: one sweep per 256 features)
   const int ebytes = a.reduce_op == DGS_MAX ? 6 : (arg ? 8 : 4);  // fp32 value (+ 16-bit arg position | 32-bit arg id)
-  int slots = (int)(kPanelAccBytes / (W * ebytes)) & ~1;
+  int slots = (int)(kPanelAccBytes / (W * ebytes)) & ~1;  // the dispatch rule's calibration (128 KiB of accumulators)
   if (slots > kPanelRMax) slots = kPanelRMax;
   if (slots < 8) return P;
+  int rmax = (int)(kPanelLdsBytes / (W * ebytes + kPanelRowState)) & ~1;  // what really fits: accumulators + row state
+  if (rmax > kPanelRMax) rmax = kPanelRMax;
   // Worth it when (a) the dense operand overflows the L2s and (b) an XCD's workgroups touch every panel row several
   // times per sweep: reuse = (rows resident per XCD) * (nnz per row) / K = gathered bytes / re-fetched panel bytes, and
   // a row visit still holds a handful of nnz: visit = (nnz per row) * (panel rows) / K.  Measured on MI355X (233 k
@@ -966,14 +971,14 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
   const double visit = deg * (double)pc / (double)(a.K > 0 ? a.K : 1);
   const bool pays = reuse >= 5.5 || (reuse >= 4.0 && visit >= 10.0);
   if (force != 1 && !(bbytes >= 16e6 && pays && a.M >= 4096)) return P;
-  P.nsb = (int)((a.M + (int64_t)P.nwg * slots - 1) / ((int64_t)P.nwg * slots));
+  P.nsb = (int)((a.M + (int64_t)P.nwg * rmax - 1) / ((int64_t)P.nwg * rmax));
   P.R = (int)((a.M + (int64_t)P.nwg * P.nsb - 1) / ((int64_t)P.nwg * P.nsb));
   P.pcols = (int)pc;
   P.npanels = (int)((a.K + pc - 1) / pc);
   if (P.npanels < 1) P.npanels = 1;
   P.lead = env_int("DGS_PANEL_LEAD", 1);
   P.tlong = env_int("DGS_PANEL_TLONG", 4096);
-  P.lds = (size_t)P.R * W * ebytes;
+  P.lds = (((size_t)P.R * W * ebytes + 15) & ~size_t(15)) + (size_t)P.R * kPanelRowState;
   P.use = true;
   return P;
 }
@@ -1004,7 +1009,7 @@ static int launch_all(const SpmmArgs &a) {
       if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) return DGS_ELAUNCH;
       if (!attr_set[dev_id]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kPanelAccBytes) != hipSuccess)
+                                kPanelLdsBytes) != hipSuccess)
           return DGS_ELAUNCH;
         attr_set[dev_id] = true;
       }

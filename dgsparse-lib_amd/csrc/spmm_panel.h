@@ -37,8 +37,10 @@ namespace dgs {
 
 constexpr int kPanelBlock = 1024;
 constexpr int kPW = kPanelBlock / kWave;  // waves per workgroup
-constexpr int kPanelAccBytes = 128 * 1024;
-constexpr int kPanelRMax = 1024;          // R <= 32768 / N <= 1024 (N >= 32)
+constexpr int kPanelAccBytes = 128 * 1024;  // accumulator budget the DISPATCH rule was calibrated with (reuse estimate)
+constexpr int kPanelLdsBytes = 160 * 1024 - 512;  // what a workgroup may really take: accumulators + per-row state
+constexpr int kPanelRowState = 6 * 4;     // deg, order, cur, rend, nextc, rbeg: 24 bytes per row, carved from the same LDS
+constexpr int kPanelRMax = 1024;          // R <= workgroup size (one thread per row in the set-up phases)
 #ifndef DGS_PU
 #define DGS_PU 8
 #endif
@@ -101,6 +103,17 @@ __device__ __forceinline__ void panel_visit(int r, int c, float w, int pend, int
   do {
     const uint64_t bal = __ballot(c < pend);
     cnt = __popcll((bal >> gbase) & gmask);
+    // a full chunk means the row may have more columns in this panel: fetch the next chunk NOW, so that its (HBM)
+    // latency runs under the gathers of this one instead of stalling the wave between two chunks of a long row
+    again = __any(cnt == G);
+    int cn = INT_MAX;
+    float wn = 0.f;
+    if (again) {
+      const int idx = pos + cnt + lig;
+      const bool ok = idx < e;
+      cn = ok ? ld_stream(col + idx) : INT_MAX;
+      if constexpr (HAS_VAL) wn = ok ? ld_stream(val + idx) : 0.f;
+    }
     for (int j = 0; __any(j < cnt); j += PU) {
       float x[PU][V];
       float wj[PU];
@@ -142,12 +155,9 @@ __device__ __forceinline__ void panel_visit(int r, int c, float w, int pend, int
       }
     }
     pos += cnt;
-    again = __any(cnt == G);  // a full chunk: the row may have more columns in this panel
     if (again) {
-      const int idx = pos + lig;
-      const bool ok = idx < e;
-      c = ok ? ld_stream(col + idx) : INT_MAX;
-      if constexpr (HAS_VAL) w = ok ? ld_stream(val + idx) : 0.f;
+      c = cn;
+      if constexpr (HAS_VAL) w = wn;
     }
   } while (again);
   // here cnt < G for every group: lane cnt holds the column at the new cursor (INT_MAX past the row end)
@@ -173,12 +183,15 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int ld, 
                                                           int *__restrict__ E, int *arrivals) {
   constexpr int V = 4;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
-  __shared__ int s_deg[kPanelRMax], s_order[kPanelRMax], s_cur[kPanelRMax], s_rend[kPanelRMax], s_nextc[kPanelRMax],
-      s_rbeg[kPanelRMax];
   __shared__ int s_ctr;
   extern __shared__ __align__(16) char panel_dyn[];
   float *acc = reinterpret_cast<float *>(panel_dyn);        // [R][N]
   unsigned short *acce = reinterpret_cast<unsigned short *>(acc + (size_t)R * N);  // [R][N] arg positions (max/min)
+  // per-row state behind the accumulators (the whole 160 KiB is one budget: every row slot more is a row less to sweep
+  // B for again - Reddit-shaped, N = 128: 304 rows per workgroup = 3 super-blocks instead of 4 with 256)
+  constexpr int kEB = (OP == DGS_MAX) ? 6 : (ARG ? 8 : 4);
+  int *s_deg = reinterpret_cast<int *>(panel_dyn + (((size_t)R * N * kEB + 15) & ~size_t(15)));
+  int *s_order = s_deg + R, *s_cur = s_order + R, *s_rend = s_cur + R, *s_nextc = s_rend + R, *s_rbeg = s_nextc + R;
   const PanelLds L{s_deg, s_order, s_cur, s_rend, s_nextc, s_rbeg};
 
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
