@@ -144,8 +144,7 @@ static inline WsLayout ws_layout_plan(int reduce_op, int64_t N, int64_t pslots) 
   L.total = prow + (arg ? prow : 0) + 256;
   return L;
 }
-// plan buffer: [256-byte header][column grid: 129 ints][units: max_units int4][long rows: max_long int4][pcol: nnz
-// int32]; the capacities
+// plan buffer: [256-byte header][column grid: 129 ints][units: max_units int4][long rows: max_long int4]; the capacities
 // (and so the offsets) are a pure function of nnz, the actual counts live in the header
 constexpr int kPlanCh = 256;          // unit length of the plan's unit table (large inputs)
 constexpr int kPlanChMin = 64;        // ... and the shortest one it uses (small inputs)
@@ -154,7 +153,7 @@ constexpr int kPlanUnitMin = 16;      // smallest nnz-per-cell target of a cut r
 constexpr int kPlanCells = 128;       // finest column grid: 8 slices (one per XCD) x 16 cells
 struct PlanLayout {
   int64_t max_units, max_long;
-  size_t off_bounds, off_units, off_long, off_pcol, total;
+  size_t off_bounds, off_units, off_long, total;
 };
 static inline PlanLayout plan_layout(int64_t nnz) {
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
@@ -165,8 +164,7 @@ static inline PlanLayout plan_layout(int64_t nnz) {
   L.off_bounds = 256;
   L.off_units = 256 + 768;  // (kPlanCells + 1) ints
   L.off_long = L.off_units + up((size_t)L.max_units * sizeof(int4));
-  L.off_pcol = L.off_long + up((size_t)L.max_long * sizeof(int4));
-  L.total = L.off_pcol + up((size_t)nnz * sizeof(int)) + 256;
+  L.total = L.off_long + up((size_t)L.max_long * sizeof(int4)) + 256;
   return L;
 }
 

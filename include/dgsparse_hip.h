@@ -100,7 +100,7 @@ typedef struct dgsSpmmPlanInfo {
   int32_t n_units;      /* entries of the unit table */
   int32_t n_long;       /* multi-unit rows */
   int32_t n_pslots;     /* partial rows a call needs in its workspace */
-  int32_t has_pcol;     /* 1 when the plan carries hot-column classes for the row stream */
+  int32_t has_pcol;     /* reserved (0) */
   int32_t tslice;       /* rows longer than this were cut at column-slice boundaries */
   int32_t xcd_start[9]; /* first unit of each XCD's share */
   int32_t reserved[2];

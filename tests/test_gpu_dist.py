@@ -109,3 +109,24 @@ def test_c5_shard_sampled_rows_vs_oracle(c5_shard, reduce):
     else:
         C64 = oracle.spmm_sum_f64(srp, scol, sval, Bh)
         assert_sum_parity(got, Co, C64, None, 1e-5, 2e-6, 'C5 shard sum', lens=np.diff(srp))
+
+
+def test_bench_partitioned_path_under_the_launcher():
+    """bench.py's multi-GPU branch (partition generator -> DistSpMM -> all-to-all-v -> timing -> worst-case second run)
+    with ONE rank under torch.distributed.run: the code the driver's 2/4/8-GPU runs execute must not be dead code on the
+    box that has a single GPU.  (With N > 1 from a bare shell bench.py launches these ranks itself.)"""
+    import json
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-dist', '--rows-log2', '17',
+           '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert j['n_gpus'] == 1 and j['value'] > 0 and j['config']['parallelism'].startswith('rowpart1')
+    assert 'halo' in j and 'error' not in j.get('worst_case', {'error': 1}), j.get('worst_case')
+    assert j['roofline']['frac'] > 0 and j['scaling'] == 'weak'
