@@ -906,7 +906,7 @@ struct SpmmArgs {
   int reduce_op;
   // cached plan (dgs_spmm_plan_build): device tables + the counts the host needs to size grids and the workspace
   const struct PlanHdr *plan = nullptr;
-  int plan_units = 0, plan_long = 0, plan_pslots = 0;
+  int plan_units = 0, plan_long = 0, plan_pslots = 0, plan_off_long = 0;
   int hints = 0;  // DGS_ALG_* bits of the `algorithm` argument
 };
 
@@ -1059,7 +1059,7 @@ static int launch_all(const SpmmArgs &a) {
     const PlanHdr *ph = a.plan;
     const PlanLayout PL = plan_layout(a.nnz);
     const UnitTab ut{&ph->n_units, &ph->n_long, ph->xcd_start, reinterpret_cast<const int4 *>(pb + PL.off_units),
-                     reinterpret_cast<const int4 *>(pb + PL.off_long)};
+                     reinterpret_cast<const int4 *>(pb + (a.plan_off_long ? (size_t)a.plan_off_long : PL.off_long))};
     int64_t ub = ((int64_t)a.plan_units + 3) / 4;
     ub = (ub + 7) & ~int64_t(7);  // a multiple of 8 so that the XCD mapping of the unit blocks applies
     const int nbu = (int)(ub < DGS_NBU ? (ub < 8 ? 8 : ub) : DGS_NBU);

@@ -368,6 +368,8 @@ extern "C" int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int3
     info->n_pslots = h.n_pslots;
     info->has_pcol = h.has_pcol;
     info->tslice = h.tslice;
+    info->off_long = 0;
+    info->reserved = 0;
     for (int x = 0; x < 9; x++) info->xcd_start[x] = h.xcd_start[x];
   }
   return DGS_OK;
@@ -377,4 +379,28 @@ extern "C" size_t dgs_spmm_csr_plan_workspace_bytes(int reduce_op, int64_t M, in
                                                     const dgsSpmmPlanInfo *info) {
   if (M <= 0 || N <= 0 || nnz <= 0 || !info) return 0;
   return ws_layout_plan(reduce_op, N, info->n_pslots).total;
+}
+
+extern "C" size_t dgs_spmm_plan_compact_bytes(const dgsSpmmPlanInfo *info) {
+  if (!info) return 0;
+  auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+  return 256 + 768 + up((size_t)info->n_units * sizeof(int4)) + up((size_t)info->n_long * sizeof(int4)) + 256;
+}
+
+extern "C" int dgs_spmm_plan_compact(const void *plan, dgsSpmmPlanInfo *info, void *compact, size_t compact_bytes,
+                                     int64_t nnz, dgsStream_t stream) {
+  if (!plan || !info || !compact || nnz <= 0 || info->off_long != 0) return DGS_EINVAL;
+  if (compact_bytes < dgs_spmm_plan_compact_bytes(info)) return DGS_EWORKSPACE;
+  auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+  const PlanLayout PL = plan_layout(nnz);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const char *src = static_cast<const char *>(plan);
+  char *dst = static_cast<char *>(compact);
+  const size_t ub = (size_t)info->n_units * sizeof(int4), lb = (size_t)info->n_long * sizeof(int4);
+  const size_t off_long = PL.off_units + up(ub);
+  if (hipMemcpyAsync(dst, src, PL.off_units + ub, hipMemcpyDeviceToDevice, st) != hipSuccess) return DGS_ELAUNCH;
+  if (lb && hipMemcpyAsync(dst + off_long, src + PL.off_long, lb, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return DGS_ELAUNCH;
+  info->off_long = (int32_t)off_long;
+  return DGS_OK;
 }

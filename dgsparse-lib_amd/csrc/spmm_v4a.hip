@@ -75,6 +75,7 @@ extern "C" int dgs_spmm_csr_plan_f32(int reduce_op, int64_t M, int64_t K, int64_
   a.plan_units = info->n_units;
   a.plan_long = info->n_long;
   a.plan_pslots = info->n_pslots;
+  a.plan_off_long = info->off_long;
   return run(fm, a);
 }
 

@@ -99,7 +99,8 @@ std::vector<Tensor> spmm_fwd(int op, const Tensor &rowptr_, const Tensor &col_, 
   Tensor E = arg ? at::empty({M, N}, dense.options().dtype(at::kInt)) : Tensor();
   const dgsSpmmPlanInfo *pi = plan_info(plan, pinfo, rowptr);
   if (pi && M > 0 && N > 0 && nnz > 0 && dgs_spmm_csr_schedule(op, M, K, N, nnz) == DGS_SCHED_ROWS) {
-    TORCH_CHECK((size_t)plan->numel() >= dgs_spmm_plan_bytes(M, K, nnz), "dgsparse: plan buffer too small for this matrix");
+    TORCH_CHECK((size_t)plan->numel() >= (pi->off_long ? dgs_spmm_plan_compact_bytes(pi) : dgs_spmm_plan_bytes(M, K, nnz)),
+                "dgsparse: plan buffer too small for this matrix");
     const size_t wsb = dgs_spmm_csr_plan_workspace_bytes(op, M, N, nnz, pi);
     Tensor ws = workspace(wsb, dense);
     check_rc(dgs_spmm_csr_plan_f32(op, M, K, N, nnz, rowptr.data_ptr<int>(), col.data_ptr<int>(), vptr,
@@ -294,10 +295,15 @@ std::vector<Tensor> spmm_plan_op(Tensor rowptr_, Tensor col_, int64_t n_cols) {
   const size_t pb = dgs_spmm_plan_bytes(M, n_cols, nnz), wb = dgs_spmm_plan_workspace_bytes(M, n_cols, nnz);
   Tensor plan = workspace(pb, rowptr), ws = workspace(wb, rowptr);
   Tensor info = at::zeros({16}, at::TensorOptions().dtype(at::kInt).device(at::kCPU));
+  dgsSpmmPlanInfo *pi = reinterpret_cast<dgsSpmmPlanInfo *>(info.data_ptr<int>());
   check_rc(dgs_spmm_plan_build(M, n_cols, nnz, rowptr.data_ptr<int>(), col.data_ptr<int>(), plan.data_ptr(), pb,
-                               ws.data_ptr(), wb, reinterpret_cast<dgsSpmmPlanInfo *>(info.data_ptr<int>()), cur_stream()),
+                               ws.data_ptr(), wb, pi, cur_stream()),
            "spmm_plan_build");
-  return {plan, info};
+  // the build buffer is sized for the worst case (~2.9 B per nnz): keep a copy as large as the tables actually are
+  const size_t cb = dgs_spmm_plan_compact_bytes(pi);
+  Tensor small = workspace(cb, rowptr);
+  check_rc(dgs_spmm_plan_compact(plan.data_ptr(), pi, small.data_ptr(), cb, nnz, cur_stream()), "spmm_plan_compact");
+  return {small, info};
 }
 
 // csr2csc(rowptr, colind, values) -> [colptr, row, values in CSC order]; square like the reference (src/spmm.cpp:91-94)

@@ -42,7 +42,7 @@ class PlanInfo(ctypes.Structure):
     """dgsSpmmPlanInfo (include/dgsparse_hip.h)."""
     _fields_ = [('n_units', ctypes.c_int32), ('n_long', ctypes.c_int32), ('n_pslots', ctypes.c_int32),
                 ('has_pcol', ctypes.c_int32), ('tslice', ctypes.c_int32), ('xcd_start', ctypes.c_int32 * 9),
-                ('reserved', ctypes.c_int32 * 2)]
+                ('off_long', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 _lib.dgs_spmm_plan_bytes.restype = _sz
@@ -51,6 +51,10 @@ _lib.dgs_spmm_plan_workspace_bytes.restype = _sz
 _lib.dgs_spmm_plan_workspace_bytes.argtypes = [_i64, _i64, _i64]
 _lib.dgs_spmm_plan_build.restype = _int
 _lib.dgs_spmm_plan_build.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp, _sz, ctypes.POINTER(PlanInfo), _vp]
+_lib.dgs_spmm_plan_compact_bytes.restype = _sz
+_lib.dgs_spmm_plan_compact_bytes.argtypes = [ctypes.POINTER(PlanInfo)]
+_lib.dgs_spmm_plan_compact.restype = _int
+_lib.dgs_spmm_plan_compact.argtypes = [_vp, ctypes.POINTER(PlanInfo), _vp, _sz, _i64, _vp]
 _lib.dgs_spmm_csr_plan_workspace_bytes.restype = _sz
 _lib.dgs_spmm_csr_plan_workspace_bytes.argtypes = [_int, _i64, _i64, _i64, ctypes.POINTER(PlanInfo)]
 _lib.dgs_spmm_csr_plan_f32.restype = _int
@@ -85,7 +89,8 @@ _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
 EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
            'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes', 'dgs_spmm_plan_build',
-           'dgs_spmm_csr_plan_workspace_bytes', 'dgs_spmm_csr_plan_f32',
+           'dgs_spmm_plan_compact_bytes', 'dgs_spmm_plan_compact', 'dgs_spmm_csr_plan_workspace_bytes',
+           'dgs_spmm_csr_plan_f32',
            'dgs_spmm_csr_schedule', 'dgs_spmm_arg_backward_f32', 'dgs_sddmm_csr_schedule',
            'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
            'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'dgs_sddmm_coo_f32', 'dgs_gspmm_csr_workspace_bytes', 'dgs_gspmm_csr_f32', 'gespmmCsrSpMM',
@@ -217,7 +222,11 @@ def spmm_plan(rowptr, col, K, N=64, force=False):
         info = PlanInfo()
         _check(_lib.dgs_spmm_plan_build(M, int(K), nnz, _p(rowptr), _p(col), _p(buf), pb, _p(ws), wb,
                                         ctypes.byref(info), _stream(dev)), 'spmm_plan_build')
-    return SpmmPlan(buf, info, M, int(K), nnz, rowptr.data_ptr(), col.data_ptr())
+        # the build buffer is sized for the worst case (~2.9 B per nnz); keep a copy that is as large as the tables
+        cb = _lib.dgs_spmm_plan_compact_bytes(ctypes.byref(info))
+        small = torch.empty(cb, dtype=torch.uint8, device=dev)
+        _check(_lib.dgs_spmm_plan_compact(_p(buf), ctypes.byref(info), _p(small), cb, nnz, _stream(dev)), 'spmm_plan_compact')
+    return SpmmPlan(small, info, M, int(K), nnz, rowptr.data_ptr(), col.data_ptr())
 
 
 def spmm(reduce_op, rowptr, col, values, dense, algorithm=0, want_E=None, plan=None):

@@ -103,13 +103,20 @@ typedef struct dgsSpmmPlanInfo {
   int32_t has_pcol;     /* reserved (0) */
   int32_t tslice;       /* rows longer than this were cut at column-slice boundaries */
   int32_t xcd_start[9]; /* first unit of each XCD's share */
-  int32_t reserved[2];
+  int32_t off_long;     /* byte offset of the long-row table inside the plan buffer; 0 = the build-time layout */
+  int32_t reserved;
 } dgsSpmmPlanInfo;
 size_t dgs_spmm_plan_bytes(int64_t M, int64_t K, int64_t nnz);
 size_t dgs_spmm_plan_workspace_bytes(int64_t M, int64_t K, int64_t nnz);
 int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int32_t *rowptr, const int32_t *col, void *plan,
                         size_t plan_bytes, void *workspace, size_t workspace_bytes, dgsSpmmPlanInfo *info,
                         dgsStream_t stream);
+/* The build needs a buffer sized for the worst case (~2.9 bytes per nnz); the tables it leaves are ~16 bytes per UNIT
+ * (1M x 1M / 16 M nnz: 46 MB vs 1.7 MB).  dgs_spmm_plan_compact copies them into a buffer of dgs_spmm_plan_compact_bytes
+ * and updates *info to describe the copy (pass that buffer + info to the calls; the build buffer can be freed). */
+size_t dgs_spmm_plan_compact_bytes(const dgsSpmmPlanInfo *info);
+int dgs_spmm_plan_compact(const void *plan, dgsSpmmPlanInfo *info, void *compact, size_t compact_bytes, int64_t nnz,
+                          dgsStream_t stream);
 size_t dgs_spmm_csr_plan_workspace_bytes(int reduce_op, int64_t M, int64_t N, int64_t nnz,
                                          const dgsSpmmPlanInfo *info);
 int dgs_spmm_csr_plan_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,

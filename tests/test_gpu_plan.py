@@ -52,7 +52,8 @@ def parse_plan(plan, nnz):
     max_units = nnz // 64 + 8 * (nnz // 128) + nnz // 16 + nnz // 64 + 16
     max_long = nnz // 128 + nnz // 64 + 2
     off_units = 256 + 768
-    off_long = off_units + up(max_units * 16)
+    off_long = plan.info.off_long if plan.info.off_long else off_units + up(max_units * 16)
+    assert plan.buf.numel() < 64 * h['n_units'] + 4096  # the kept buffer is as large as its tables, not the worst case
     units = raw[off_units:off_units + h['n_units'] * 16].view(np.int32).reshape(-1, 4)
     longrows = raw[off_long:off_long + h['n_long'] * 16].view(np.int32).reshape(-1, 4)
     assert h['n_units'] <= max_units and h['n_long'] <= max_long
