@@ -109,6 +109,34 @@ int main(int argc, char **argv) {
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
 
+  // Cached locality plan (include/dgsparse_hip.h): built once from (rowptr, col) when the shape takes the row-stream
+  // schedule; the same calls then run over the plan's tables.
+  void *d_plan = nullptr, *d_pws = nullptr;
+  dgsSpmmPlanInfo pinfo;
+  size_t pwsb = 0;
+  const bool planned = nnz > 0 && dgs_spmm_csr_schedule(DGS_SUM, M, K, N, nnz) == DGS_SCHED_ROWS;
+  if (planned) {
+    const size_t pb = dgs_spmm_plan_bytes(M, K, nnz), bb = dgs_spmm_plan_workspace_bytes(M, K, nnz);
+    void *d_big, *d_bws;
+    HIP_OK(hipMalloc(&d_big, pb));
+    HIP_OK(hipMalloc(&d_bws, bb));
+    int rc = dgs_spmm_plan_build(M, K, nnz, d_ptr, d_idx, d_big, pb, d_bws, bb, &pinfo, st);
+    if (rc) {
+      fprintf(stderr, "dgs_spmm_plan_build: %s\n", dgs_strerror(rc));
+      return 3;
+    }
+    const size_t cb = dgs_spmm_plan_compact_bytes(&pinfo);
+    HIP_OK(hipMalloc(&d_plan, cb));
+    rc = dgs_spmm_plan_compact(d_big, &pinfo, d_plan, cb, nnz, st);
+    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipFree(d_big));
+    HIP_OK(hipFree(d_bws));
+    if (rc) return 3;
+    pwsb = dgs_spmm_csr_plan_workspace_bytes(DGS_MAX, M, N, nnz, &pinfo);
+    HIP_OK(hipMalloc(&d_pws, pwsb));
+    printf("plan: %d units, %d long rows, %d partial rows, %zu bytes\n", pinfo.n_units, pinfo.n_long, pinfo.n_pslots, cb);
+  }
+
   const char *names[4] = {"sum", "max", "min", "mean"};
   int bad_total = 0;
   for (int op = 0; op < 4; op++) {
@@ -117,13 +145,14 @@ int main(int argc, char **argv) {
       for (int f = 0; f < N; f++) {
         const int s = indptr[r], e = indptr[r + 1];
         float res = op == DGS_MAX ? (float)INT32_MIN : op == DGS_MIN ? (float)INT32_MAX : 0.f;
+        double acc = 0.0;  // sum/mean: exact yardstick (a sequential fp32 chain drifts by > 1e-5 on rows of 10^3+ nnz)
         for (int p = s; p < e; p++) {
           const float t = val[p] * B[(size_t)indices[p] * N + f];
           if (op == DGS_MAX) res = res < t ? t : res;
           else if (op == DGS_MIN) res = res < t ? res : t;
-          else res += t;
+          else acc += (double)t;
         }
-        if (op == DGS_MEAN && e > s) res /= (float)(e - s);
+        if (op == DGS_SUM || op == DGS_MEAN) res = (float)(op == DGS_MEAN && e > s ? acc / (double)(e - s) : acc);
         Cref[(size_t)r * N + f] = e > s ? res : 0.f;
       }
     int rc = dgs_spmm_csr_f32(op, M, K, N, nnz, d_ptr, d_idx, d_val, d_B, d_C, d_E, 0, d_ws, wsb, st);
@@ -146,6 +175,29 @@ int main(int argc, char **argv) {
     HIP_OK(hipEventElapsedTime(&ms, e0, e1));
     printf("[SpMM-%s] check %s (%ld mismatches)  time %.6f ms  throughput %.2f GFLOP/s\n", names[op],
            bad ? "FAILED" : "passed", bad, ms / 100, 2.0 * nnz * N / (ms / 100) * 1e-6);
+    if (planned) {  // the same product over the cached plan
+      rc = dgs_spmm_csr_plan_f32(op, M, K, N, nnz, d_ptr, d_idx, d_val, d_B, d_C, d_E, d_plan, &pinfo, d_pws, pwsb, st);
+      if (rc) {
+        fprintf(stderr, "dgs_spmm_csr_plan_f32: %s\n", dgs_strerror(rc));
+        return 3;
+      }
+      HIP_OK(hipMemcpyAsync(C.data(), d_C, C.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+      HIP_OK(hipStreamSynchronize(st));
+      long pbad = 0;
+      for (size_t i = 0; i < C.size(); i++)
+        if (fabsf(C[i] - Cref[i]) > 1e-5f * fabsf(Cref[i]) + 2e-6f) pbad++;
+      bad_total += pbad != 0;
+      for (int i = 0; i < 10; i++)
+        dgs_spmm_csr_plan_f32(op, M, K, N, nnz, d_ptr, d_idx, d_val, d_B, d_C, d_E, d_plan, &pinfo, d_pws, pwsb, st);
+      HIP_OK(hipEventRecord(e0, st));
+      for (int i = 0; i < 100; i++)
+        dgs_spmm_csr_plan_f32(op, M, K, N, nnz, d_ptr, d_idx, d_val, d_B, d_C, d_E, d_plan, &pinfo, d_pws, pwsb, st);
+      HIP_OK(hipEventRecord(e1, st));
+      HIP_OK(hipEventSynchronize(e1));
+      HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+      printf("[SpMM-%s, plan] verification %s (%ld mismatches)  time %.6f ms  throughput %.2f GFLOP/s\n", names[op],
+             pbad ? "FAILED" : "ok", pbad, ms / 100, 2.0 * nnz * N / (ms / 100) * 1e-6);
+    }
   }
   {  // SDDMM
     std::vector<float> out(nnz), ref(nnz);

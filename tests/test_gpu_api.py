@@ -197,6 +197,20 @@ def test_standalone_cabi_driver_on_mtx(tmp_path):
     out = subprocess.run([os.path.join(root, 'examples', 'spmm_mtx'), p, '48'], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count('passed') == 5 and 'FAILED' not in out.stdout
+    # a larger graph takes the row-stream schedule: the driver then also builds the cached plan through the C ABI
+    # (build -> compact -> dgs_spmm_csr_plan_f32) and verifies the four reduces over it
+    n = 70000
+    rows = np.repeat(np.arange(n), np.minimum(rng.zipf(1.6, n), 6000))
+    cols = rng.integers(0, n, rows.shape[0])
+    ent = sorted({(int(max(a, b)), int(min(a, b))) for a, b in zip(rows, cols)})
+    p2 = str(tmp_path / 'g2.mtx')
+    with open(p2, 'w') as f:
+        f.write('%%MatrixMarket matrix coordinate pattern symmetric\n')
+        f.write(f'{n} {n} {len(ent)}\n')
+        f.writelines(f'{a + 1} {b + 1}\n' for a, b in ent)
+    out = subprocess.run([os.path.join(root, 'examples', 'spmm_mtx'), p2, '32'], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count('passed') == 5 and out.stdout.count('verification ok') == 4 and 'FAILED' not in out.stdout
 
 
 def test_hip_graph_capture_and_replay():
