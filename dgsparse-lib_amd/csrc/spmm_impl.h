@@ -949,7 +949,7 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
   P.nwg = cu_count();
   const bool arg = (a.reduce_op == DGS_MAX || a.reduce_op == DGS_MIN);
   const int64_t W = a.N < 256 ? a.N : 256;  // feature tile per launch (wider operands: one sweep per 256 features)
-  const int ebytes = a.reduce_op == DGS_MAX ? 6 : (arg ? 8 : 4);  // fp32 value (+ 16-bit arg position | 32-bit arg id)
+  const int ebytes = arg ? 6 : 4;  // fp32 value (+ 16-bit arg position | 32-bit arg id)
   int slots = (int)(kPanelAccBytes / (W * ebytes)) & ~1;  // the dispatch rule's calibration (128 KiB of accumulators)
   if (slots > kPanelRMax) slots = kPanelRMax;
   if (slots < 8) return P;

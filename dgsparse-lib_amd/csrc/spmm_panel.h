@@ -71,11 +71,11 @@ __device__ __forceinline__ void panel_visit(int r, int c, float w, int pend, int
   constexpr int PU = kPU;
   const bool have = r >= 0;
   float a[V] = {0.f, 0.f, 0.f, 0.f};
-  // max: the arg is kept as the POSITION of the winning nnz inside its row (16 bits: rows swept here have at most
+  // max/min: the arg is kept as the POSITION of the winning nnz inside its row (16 bits: rows swept here have at most
   // tlong < 65535 nnz; 0xFFFF = none yet), 6 bytes per element instead of 8, and becomes a column id at write-out.
-  // min keeps the 32-bit column id: its step holds two compare results per element and the 16-bit packing on top
-  // costs ~50 spilled VGPRs at the 128-register budget (measured: 4.1 -> 10 ms; fewer gathers in flight: 5.8-6.4 ms).
-  constexpr bool E16 = (OP == DGS_MAX);
+  // (Round 1 kept 32-bit ids for min because the packing spilled ~50 VGPRs; with the round-2 visit loop it spills 13 and
+  // the extra rows per workgroup win: Reddit-shaped N = 128, 5.9 -> 5.4 ms.)
+  constexpr bool E16 = ARG;
   int ae[V];
 #pragma unroll
   for (int v = 0; v < V; v++) ae[v] = E16 ? 0xFFFF : -1;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int ld, 
   unsigned short *acce = reinterpret_cast<unsigned short *>(acc + (size_t)R * N);  // [R][N] arg positions (max/min)
   // per-row state behind the accumulators (the whole 160 KiB is one budget: every row slot more is a row less to sweep
   // B for again - Reddit-shaped, N = 128: 304 rows per workgroup = 3 super-blocks instead of 4 with 256)
-  constexpr int kEB = (OP == DGS_MAX) ? 6 : (ARG ? 8 : 4);
+  constexpr int kEB = ARG ? 6 : 4;
   int *s_deg = reinterpret_cast<int *>(panel_dyn + (((size_t)R * N * kEB + 15) & ~size_t(15)));
   int *s_order = s_deg + R, *s_cur = s_order + R, *s_rend = s_cur + R, *s_nextc = s_rend + R, *s_rbeg = s_nextc + R;
   const PanelLds L{s_deg, s_order, s_cur, s_rend, s_nextc, s_rbeg};
@@ -208,8 +208,7 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int ld, 
     for (int i = tid; i < R * n4; i += kPanelBlock) {
       const float z = reduce_init<OP>();
       reinterpret_cast<float4 *>(acc)[i] = make_float4(z, z, z, z);
-      if constexpr (OP == DGS_MAX) reinterpret_cast<uint2 *>(acce)[i] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-      else if constexpr (ARG) reinterpret_cast<int4 *>(acce)[i] = make_int4(-1, -1, -1, -1);
+      if constexpr (ARG) reinterpret_cast<uint2 *>(acce)[i] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
     }
     // ---- per-row state; rank the workgroup's rows by length (longest first; absent / too-long rows last) ----
     if (tid < R) {
@@ -320,7 +319,7 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int ld, 
         float o[V] = {t.x, t.y, t.z, t.w};
         if constexpr (ARG) {
           int oe[V];
-          if constexpr (OP == DGS_MAX) {
+          if constexpr (ARG) {
             const uint2 te = reinterpret_cast<uint2 *>(acce)[i];
             const unsigned pe[V] = {te.x & 0xFFFF, te.x >> 16, te.y & 0xFFFF, te.y >> 16};
 #pragma unroll
