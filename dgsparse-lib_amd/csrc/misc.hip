@@ -54,9 +54,31 @@ __global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(int64_t n_ids,
   store_vec<V>(d, y);
 }
 
+// ids[i] = map[ids[i]] for ids[i] >= 0 (negative ids - "no arg" - stay): 4 ids per thread
+__global__ __launch_bounds__(kBlock) void relabel_kernel(int64_t n, int *__restrict__ ids, const int *__restrict__ map) {
+  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+  if (i + 3 < n && (reinterpret_cast<uintptr_t>(ids) & 15u) == 0) {
+    dgs_i4 v = *reinterpret_cast<const dgs_i4 *>(ids + i);
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = v[k] >= 0 ? map[v[k]] : v[k];
+    *reinterpret_cast<dgs_i4 *>(ids + i) = v;
+  } else {
+    for (int64_t k = i; k < n && k < i + 4; k++) ids[k] = ids[k] >= 0 ? map[ids[k]] : ids[k];
+  }
+}
+
 }  // namespace dgs
 
 using namespace dgs;
+
+extern "C" int dgs_relabel_i32(int64_t n, int32_t *ids, const int32_t *map, dgsStream_t stream) {
+  if (n < 0) return DGS_EINVAL;
+  if (n == 0) return DGS_OK;
+  if (!ids || !map) return DGS_EINVAL;
+  const int64_t blocks = (n + 4 * kBlock - 1) / (4 * kBlock);
+  hipLaunchKernelGGL(relabel_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), n, ids, map);
+  return check_launch();
+}
 
 extern "C" int dgs_version(void) { return 1000; }
 extern "C" const char *dgs_arch(void) { return "gfx950"; }

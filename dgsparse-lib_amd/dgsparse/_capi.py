@@ -84,6 +84,8 @@ _lib.dgs_sddmm_coo_f32.restype = _int
 _lib.dgs_sddmm_coo_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]
 _lib.dgs_gather_rows_f32.restype = _int
 _lib.dgs_gather_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
+_lib.dgs_relabel_i32.restype = _int
+_lib.dgs_relabel_i32.argtypes = [_i64, _vp, _vp, _vp]
 _lib.dgs_scatter_add_rows_f32.restype = _int
 _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
@@ -93,7 +95,7 @@ EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_by
            'dgs_spmm_csr_plan_f32',
            'dgs_spmm_csr_schedule', 'dgs_spmm_arg_backward_f32', 'dgs_sddmm_csr_schedule',
            'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
-           'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'dgs_sddmm_coo_f32', 'dgs_gspmm_csr_workspace_bytes', 'dgs_gspmm_csr_f32', 'gespmmCsrSpMM',
+           'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'dgs_relabel_i32', 'dgs_sddmm_coo_f32', 'dgs_gspmm_csr_workspace_bytes', 'dgs_gspmm_csr_f32', 'gespmmCsrSpMM',
            'spmm_cuda', 'spmm_cuda_no_edge_value', 'sddmm_cuda_csr', 'sddmm_cuda_coo', 'gespmmAlgSel',
            'csrspmm_parreduce_rowbalance', 'csrspmm_parreduce_nnzbalance', 'csrspmm_seqreduce_rowbalance',
            'csrspmm_seqreduce_nnzbalance', 'csrspmm_rowcaching_rowbalance', 'csrspmm_rowcaching_nnzbalance']
@@ -421,3 +423,13 @@ def scatter_add_rows(dst, ids, src):
         _check(_lib.dgs_scatter_add_rows_f32(ids.numel(), src.shape[1], _p(ids), _p(src), _p(dst), _stream(dev)),
                'scatter_add')
     return dst
+
+
+def relabel_(ids, mapping):
+    """In place: ids[i] = mapping[ids[i]] where ids[i] >= 0 (int32 tensors; negative ids stay)."""
+    dev = _need_gpu(ids, mapping)
+    if ids.dtype != torch.int32 or mapping.dtype != torch.int32 or not ids.is_contiguous() or not mapping.is_contiguous():
+        raise TypeError('dgsparse: relabel_ wants contiguous int32 tensors')
+    with _on_device(dev):
+        _check(_lib.dgs_relabel_i32(ids.numel(), _p(ids), _p(mapping), _stream(dev)), 'relabel')
+    return ids

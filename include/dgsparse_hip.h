@@ -214,6 +214,9 @@ int dgs_gather_rows_f32(int64_t n_ids, int64_t N, const int32_t *ids, const floa
                         dgsStream_t stream);
 int dgs_scatter_add_rows_f32(int64_t n_ids, int64_t N, const int32_t *ids, const float *src, float *dst,
                              dgsStream_t stream);
+/* In-place relabel of arg ids: ids[i] = map[ids[i]] where ids[i] >= 0 (-1 = "no arg" stays).  The multi-GPU path
+ * computes max/min in the extended [local | halo] column space and hands back GLOBAL column ids (new). */
+int dgs_relabel_i32(int64_t n, int32_t *ids, const int32_t *map, dgsStream_t stream);
 
 /* ---- GE-SpMM / SDDMM compatibility entry points (same names and argument order as the reference's
  *      standalone C libraries; default stream, void return) ------------------------------------- */

@@ -28,6 +28,9 @@ class OracleOps:
         dst[ids.long()] += src
         return dst
 
+    def relabel(self, ids, mapping):
+        return torch.where(ids >= 0, mapping[ids.clamp(min=0).long()], ids)
+
     def csr2csc(self, rowptr, col, val, n_cols):
         import oracle
         colptr, row, cscval, perm = oracle.csr2csc(rowptr.numpy(), col.numpy(), None if val is None else val.numpy(), n_cols)
