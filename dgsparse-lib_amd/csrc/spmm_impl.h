@@ -453,12 +453,15 @@ struct RowsLds {
   int4 rows[kBlock / kWave][kRowsPerWave + 1];  // {start, end, next non-empty short row, -}
 };
 
-template <int G, int V, int OP, bool HAS_VAL, bool INLINE>
+// ACC (sum only): C[out row] += result instead of C[row] = result, out row = rowmap[row] when a map is given (the
+// halo product of dgsparse.dist adds into the rows that have remote entries); rows without entries are left alone.
+template <int G, int V, int OP, bool HAS_VAL, bool INLINE, bool ACC = false>
 __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, int M, int N,
                                                const int *__restrict__ rowptr,
                                                const int *__restrict__ col, const float *__restrict__ val,
                                                const float *__restrict__ B, float *__restrict__ C,
-                                               int *__restrict__ E) {
+                                               int *__restrict__ E, const int *__restrict__ rowmap = nullptr) {
+  static_assert(!ACC || OP == DGS_SUM, "accumulation exists for the sum only");
   constexpr int NG = kWave / G;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -485,9 +488,11 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
     const unsigned long long livemask = __ballot(live_i);
     const unsigned long long above = (lane >= 63) ? 0ull : (livemask >> (lane + 1));
     const int nxt = above ? (lane + 1 + (__ffsll((long long)above) - 1)) : kRowsPerWave;
-    rows[lane] = make_int4(s_i, e_i, nxt, 0);
+    int orow_i = 0;
+    if constexpr (ACC) orow_i = (lane < nrows) ? (rowmap ? rowmap[r0 + lane] : r0 + lane) : 0;
+    rows[lane] = make_int4(s_i, e_i, nxt, orow_i);
     // empty rows: 0 / E = -1 (spmm_cuda.cuh:49-51); NG rows per pass, one per group
-    unsigned long long em = __ballot(lane < nrows && len_i == 0);
+    unsigned long long em = ACC ? 0ull : __ballot(lane < nrows && len_i == 0);
     while (em) {
       int r = -1;
       unsigned long long t = em;
@@ -612,8 +617,17 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
                 for (int v = 0; v < V; v++) acc[v] /= d;
               }
               if (fl) {
-                store_vec_hidden<V>(C + (int64_t)(r0 + cur) * N + f0, acc);
-                if constexpr (ARG) store_vec_hidden<V>(E + (int64_t)(r0 + cur) * N + f0, ei);
+                if constexpr (ACC) {
+                  float *cp = C + (int64_t)q.w * N + f0;
+                  float old[V];
+                  load_vec<V>(cp, old);
+#pragma unroll
+                  for (int v = 0; v < V; v++) acc[v] += old[v];
+                  store_vec_hidden<V>(cp, acc);
+                } else {
+                  store_vec_hidden<V>(C + (int64_t)(r0 + cur) * N + f0, acc);
+                  if constexpr (ARG) store_vec_hidden<V>(E + (int64_t)(r0 + cur) * N + f0, ei);
+                }
               }
 #pragma unroll
               for (int v = 0; v < V; v++) {
@@ -661,20 +675,30 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
 #pragma unroll
         for (int v = 0; v < V; v++) acc[v] /= dg;
       }
-      store_vec_stream<V>(C + (int64_t)(r0 + r) * N + f0, acc);
-      if constexpr (ARG) store_vec_stream<V>(E + (int64_t)(r0 + r) * N + f0, ei);
+      if constexpr (ACC) {
+        float *cp = C + (int64_t)rows[r].w * N + f0;
+        float old[V];
+        load_vec<V>(cp, old);
+#pragma unroll
+        for (int v = 0; v < V; v++) acc[v] += old[v];
+        store_vec_stream<V>(cp, acc);
+      } else {
+        store_vec_stream<V>(C + (int64_t)(r0 + r) * N + f0, acc);
+        if constexpr (ARG) store_vec_stream<V>(E + (int64_t)(r0 + r) * N + f0, ei);
+      }
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // K2: one wave per unit (<= ch nnz of a long row).
-template <int G, int V, int OP, bool HAS_VAL>
+template <int G, int V, int OP, bool HAS_VAL, bool ACC = false>
 __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &lds, int N,
                                                 const int *__restrict__ rowptr, const int *__restrict__ col,
                                                 const float *__restrict__ val, const float *__restrict__ B,
                                                 float *__restrict__ C, int *__restrict__ E, const UnitTab &ut,
-                                                float *__restrict__ part, int *__restrict__ parte) {
+                                                float *__restrict__ part, int *__restrict__ parte,
+                                                const int *__restrict__ rowmap = nullptr) {
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane / G, l = lane % G;
@@ -735,8 +759,17 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
 #pragma unroll
           for (int v = 0; v < V; v++) acc[v] /= dg;
         }
-        store_vec_stream<V>(C + (int64_t)d.x * N + f0, acc);
-        if constexpr (ARG) store_vec_stream<V>(E + (int64_t)d.x * N + f0, ei);
+        if constexpr (ACC) {
+          float *cp = C + (int64_t)(rowmap ? rowmap[d.x] : d.x) * N + f0;
+          float old[V];
+          load_vec<V>(cp, old);
+#pragma unroll
+          for (int v = 0; v < V; v++) acc[v] += old[v];
+          store_vec_stream<V>(cp, acc);
+        } else {
+          store_vec_stream<V>(C + (int64_t)d.x * N + f0, acc);
+          if constexpr (ARG) store_vec_stream<V>(E + (int64_t)d.x * N + f0, ei);
+        }
       } else {
         const int64_t slot = (int64_t)d.w * N + f0;
         store_vec<V>(part + slot, acc);
@@ -760,15 +793,15 @@ constexpr int fused_waves_per_simd(int op) { return (op == DGS_MAX || op == DGS_
 // Fused launch: blocks [0, nbu) walk the unit table of the huge rows (persistent, strided), the remaining blocks
 // each own 4 x 64 consecutive rows.  Unit blocks come first so that the longest-running work starts first; the
 // two kinds of work share the CUs, so the fabric-bound unit gathers overlap the row kernel's latency phases.
-template <int G, int V, int OP, bool HAS_VAL>
+template <int G, int V, int OP, bool HAS_VAL, bool ACC = false>
 __global__ __launch_bounds__(kBlock, fused_waves_per_simd(OP)) void spmm_fused(int M, int N, int nbu, int rpw, const int *__restrict__ rowptr,
                                                      const int *__restrict__ col, const float *__restrict__ val,
                                                      const float *__restrict__ B, float *__restrict__ C,
                                                      int *__restrict__ E, const UnitTab ut, float *__restrict__ part,
-                                                     int *__restrict__ parte) {
+                                                     int *__restrict__ parte, const int *__restrict__ rowmap) {
   __shared__ RowsLds lds;
   if ((int)blockIdx.x < nbu)
-    spmm_units_body<G, V, OP, HAS_VAL>(blockIdx.x, nbu, lds, N, rowptr, col, val, B, C, E, ut, part, parte);
+    spmm_units_body<G, V, OP, HAS_VAL, ACC>(blockIdx.x, nbu, lds, N, rowptr, col, val, B, C, E, ut, part, parte, rowmap);
   else {
     // XCD-aware row mapping: workgroups are dealt round-robin to the 8 XCDs (observed: block b -> XCD b % 8), each
     // with a private L2.  Give every XCD a CONTIGUOUS eighth of the row blocks, so that neighbouring rows - which
@@ -780,32 +813,32 @@ __global__ __launch_bounds__(kBlock, fused_waves_per_simd(OP)) void spmm_fused(i
     const int per = nbr / 8;
     if (rb < per * 8) rb = (rb % 8) * per + rb / 8;
 #endif
-    spmm_rows_body<G, V, OP, HAS_VAL, false>(rb, rpw, lds, M, N, rowptr, col, val, B, C, E);
+    spmm_rows_body<G, V, OP, HAS_VAL, false, ACC>(rb, rpw, lds, M, N, rowptr, col, val, B, C, E, rowmap);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // Small inputs (the Cora/Citeseer/Pubmed/PPI class: a few 10^4 rows, <= 2.6e5 nnz) finish in a few microseconds,
 // so launch count is what matters: ONE launch, row blocks only, every long row reduced by its whole wave in place.
-template <int G, int V, int OP, bool HAS_VAL>
+template <int G, int V, int OP, bool HAS_VAL, bool ACC = false>
 __global__ __launch_bounds__(kBlock) void spmm_small(int M, int N, int rpw, const int *__restrict__ rowptr,
                                                      const int *__restrict__ col, const float *__restrict__ val,
                                                      const float *__restrict__ B, float *__restrict__ C,
-                                                     int *__restrict__ E) {
+                                                     int *__restrict__ E, const int *__restrict__ rowmap) {
   __shared__ RowsLds lds;
-  spmm_rows_body<G, V, OP, HAS_VAL, true>(blockIdx.x, rpw, lds, M, N, rowptr, col, val, B, C, E);
+  spmm_rows_body<G, V, OP, HAS_VAL, true, ACC>(blockIdx.x, rpw, lds, M, N, rowptr, col, val, B, C, E, rowmap);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // K3: one wave per entry of the long-row table folds that row's partial rows in unit order (groups take interleaved
 // units, 4 independent partial loads in flight per lane, then the fixed cross-group tree).
-template <int G, int V, int OP>
+template <int G, int V, int OP, bool ACC = false>
 __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restrict__ rowptr,
                                                        const int *__restrict__ col, const float *__restrict__ val,
                                                        const float *__restrict__ B, float *__restrict__ C,
                                                        int *__restrict__ E, const UnitTab ut,
                                                        const float *__restrict__ part,
-                                                       const int *__restrict__ parte) {
+                                                       const int *__restrict__ parte, const int *__restrict__ rowmap) {
   constexpr int NG = kWave / G;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
   constexpr int UP = 4;
@@ -886,8 +919,17 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
 #pragma unroll
         for (int v = 0; v < V; v++) acc[v] /= dg;
       }
-      store_vec_stream<V>(C + (int64_t)d.x * N + f0, acc);
-      if constexpr (ARG) store_vec_stream<V>(E + (int64_t)d.x * N + f0, ei);
+      if constexpr (ACC) {
+        float *cp = C + (int64_t)(rowmap ? rowmap[d.x] : d.x) * N + f0;
+        float old[V];
+        load_vec<V>(cp, old);
+#pragma unroll
+        for (int v = 0; v < V; v++) acc[v] += old[v];
+        store_vec_stream<V>(cp, acc);
+      } else {
+        store_vec_stream<V>(C + (int64_t)d.x * N + f0, acc);
+        if constexpr (ARG) store_vec_stream<V>(E + (int64_t)d.x * N + f0, ei);
+      }
     }
     }
   }
@@ -908,6 +950,8 @@ struct SpmmArgs {
   const struct PlanHdr *plan = nullptr;
   int plan_units = 0, plan_long = 0, plan_pslots = 0, plan_off_long = 0;
   int hints = 0;  // DGS_ALG_* bits of the `algorithm` argument
+  bool accumulate = false;      // C[rowmap[r]] += ... instead of C[r] = ... (sum only)
+  const int *rowmap = nullptr;  // accumulate: output row of every row of A (nullptr = identity)
 };
 
 // Device-resident header of a cached plan, followed by the tables (all offsets in bytes from the header).
@@ -981,9 +1025,9 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
   return P;
 }
 
-template <int G, int V, int OP, bool HAS_VAL>
-static int launch_all(const SpmmArgs &a) {
-  if constexpr (V == 4 && G >= 8) {
+template <int G, int V, int OP, bool HAS_VAL, bool ACC>
+static int launch_impl(const SpmmArgs &a) {
+  if constexpr (V == 4 && G >= 8 && !ACC) {
     const PanelPlan P = panel_plan(a, a.tiles, G);
     if (P.use) {
       // rows up to tlong nnz: panel sweep; longer rows: the unit path (classify -> unit blocks -> combine)
@@ -1019,12 +1063,12 @@ static int launch_all(const SpmmArgs &a) {
                            a.E ? a.E + fb : nullptr, &hdr->arrivals);
       }
       const int nbu = 1024;
-      hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)nbu, (unsigned)a.tiles), dim3(kBlock), 0, a.st, (int)a.M,
-                         (int)a.N, nbu, kRowsPerWave, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
+      hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC>), dim3((unsigned)nbu, (unsigned)a.tiles), dim3(kBlock), 0, a.st, (int)a.M,
+                         (int)a.N, nbu, kRowsPerWave, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.rowmap);
       const int64_t cb = (L.max_long + 3) / 4;
       const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
-      hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B,
-                         a.C, a.E, ut, part, parte);
+      hipLaunchKernelGGL((spmm_combine<G, V, OP, ACC>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B,
+                         a.C, a.E, ut, part, parte, a.rowmap);
       return check_launch();
     }
   }
@@ -1035,8 +1079,8 @@ static int launch_all(const SpmmArgs &a) {
     while (rpw > NGc && rpw > 4 && (a.M + rpw - 1) / rpw < 2048) rpw >>= 1;
     const int rpb = (kBlock / kWave) * rpw;
     const dim3 grid((unsigned)((a.M + rpb - 1) / rpb), (unsigned)a.tiles);
-    hipLaunchKernelGGL((spmm_small<G, V, OP, HAS_VAL>), grid, dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, rpw,
-                       a.rowptr, a.col, a.val, a.B, a.C, a.E);
+    hipLaunchKernelGGL((spmm_small<G, V, OP, HAS_VAL, ACC>), grid, dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, rpw,
+                       a.rowptr, a.col, a.val, a.B, a.C, a.E, a.rowmap);
     return check_launch();
   }
   // rows per wave: 64 when there are plenty of rows; mid-size graphs (arxiv-shaped: 169 k rows, 6.5 nnz/row) get fewer,
@@ -1063,19 +1107,13 @@ static int launch_all(const SpmmArgs &a) {
     int64_t ub = ((int64_t)a.plan_units + 3) / 4;
     ub = (ub + 7) & ~int64_t(7);  // a multiple of 8 so that the XCD mapping of the unit blocks applies
     const int nbu = (int)(ub < DGS_NBU ? (ub < 8 ? 8 : ub) : DGS_NBU);
-    if (env_int("DGS_SPLIT", 0)) {  // experiment: unit blocks and row blocks as two launches (no L2 sharing in time)
-      hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)nbu, (unsigned)a.tiles), dim3(kBlock), 0, a.st,
-                         (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
-      hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)nbr, (unsigned)a.tiles), dim3(kBlock), 0, a.st,
-                         (int)a.M, (int)a.N, 0, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
-    } else
-    hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
-                       a.st, (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
+    hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
+                       a.st, (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.rowmap);
     if (a.plan_long > 0) {
       const int64_t cb = ((int64_t)a.plan_long + 3) / 4;
       const dim3 g3((unsigned)(cb < 2048 ? cb : 2048), (unsigned)a.tiles);
-      hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B,
-                         a.C, a.E, ut, part, parte);
+      hipLaunchKernelGGL((spmm_combine<G, V, OP, ACC>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B,
+                         a.C, a.E, ut, part, parte, a.rowmap);
     }
     return check_launch();
   }
@@ -1094,14 +1132,23 @@ static int launch_all(const SpmmArgs &a) {
   // unit / multi counts live on the device: a bounded number of persistent unit blocks stride over the table
   const int64_t ub = (L.max_units + 3) / 4;
   const int nbu = (int)(ub < DGS_NBU ? (ub < 1 ? 1 : ub) : DGS_NBU);
-  hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
-                     a.st, (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte);
+  hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
+                     a.st, (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.rowmap);
   // combine: one wave per multi-unit row
   const int64_t cb = (L.max_long + 3) / 4;
   const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
-  hipLaunchKernelGGL((spmm_combine<G, V, OP>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B, a.C,
-                     a.E, ut, part, parte);
+  hipLaunchKernelGGL((spmm_combine<G, V, OP, ACC>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B, a.C,
+                     a.E, ut, part, parte, a.rowmap);
   return check_launch();
+}
+
+template <int G, int V, int OP, bool HAS_VAL>
+static int launch_all(const SpmmArgs &a) {
+  if (a.accumulate) {  // C[rowmap[r]] += row r of A.B (sum only; never the column-panel sweep)
+    if constexpr (OP == DGS_SUM) return launch_impl<G, V, OP, HAS_VAL, true>(a);
+    else return DGS_EINVAL;
+  }
+  return launch_impl<G, V, OP, HAS_VAL, false>(a);
 }
 
 template <int G, int V, int OP>

@@ -206,6 +206,10 @@ class _HipOps:
         return self._c.spmm(op, rowptr, col, val, B, algorithm=self._c.ALG_SHARED_GPU if shared_gpu else 0,
                             plan=self._plan(rowptr, col, B.shape[0], B.shape[1]))
 
+    def spmm_acc(self, rowptr, col, val, B, C, rowmap):
+        """C[rowmap[r]] += row r of A.B, in place (dgs_spmm_csr_acc_f32)."""
+        return self._c.spmm_acc(rowptr, col, val, B, C, rowmap, plan=self._plan(rowptr, col, B.shape[0], B.shape[1]))
+
     def sddmm(self, rowptr, col, D1, D2, op=0, E=None):
         return self._c.sddmm(rowptr, col, D1, D2, op, E=E)
 
@@ -288,9 +292,9 @@ class DistSpMM:
             if work is not None:
                 work.wait()  # current stream waits for the collective; the host does not block
             if plan.rem_rows.numel() > 0:
-                # the halo product only covers the rows that have a remote entry; its rows are added in place
-                Cr, _ = self.ops.spmm(0, plan.rem[0], plan.rem[1], vr, B_ext[p.n_local:])
-                self.ops.scatter_add_rows(C, plan.rem_rows, Cr)
+                # the halo product only covers the rows that have a remote entry and ACCUMULATES into them: no
+                # temporary, no add pass (C[rem_rows[r]] += row r of A_rem . B_halo)
+                self.ops.spmm_acc(plan.rem[0], plan.rem[1], vr, B_ext[p.n_local:], C, plan.rem_rows)
             if reduce == 'mean':
                 C /= plan.deg[:, None]
             self.last_E = self.last_E_ext = None

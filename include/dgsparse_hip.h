@@ -125,6 +125,21 @@ int dgs_spmm_csr_plan_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_
                           dgsStream_t stream);
 
 /*
+ * Accumulating SpMM (sum):  C[rowmap[r],:] += sum_{p in row r} val[p] * B[col[p],:]   (rowmap == NULL: C[r,:] += ...)
+ * New (the reference has no accumulating product; its nnz-balanced algorithms atomically add into a caller-zeroed C,
+ * src/ge-spmm/gespmm.cc:65-90, which is the closest thing).  Rows of A without entries leave C untouched, so a product
+ * over a COMPACT matrix (only the rows that have entries, rowmap = their row numbers) touches those rows of C only:
+ * dgsparse.dist adds the halo product into the local one this way, without a temporary and without an M x N add pass.
+ * Every element of C receives exactly one add per call (rows are reduced first, in the schedule's usual order), so the
+ * result is deterministic.  plan/info: optional cached plan of (rowptr, col) (NULL: plan-free); workspace as for the
+ * corresponding plain call (dgs_spmm_csr_plan_workspace_bytes with a plan, dgs_spmm_csr_workspace_bytes without).
+ * Never takes the column-panel schedule.
+ */
+int dgs_spmm_csr_acc_f32(int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                         const float *val, const float *B, float *C, const int32_t *rowmap, const void *plan,
+                         const dgsSpmmPlanInfo *info, void *workspace, size_t workspace_bytes, dgsStream_t stream);
+
+/*
  * Masked SpMM = backward of max/min w.r.t. the dense operand, run on the CSC arrays of A:
  *   out[j,:] = sum_{p in [ptr[j],ptr[j+1])} [E[idx[p],:] == j] * val[p] * G[idx[p],:]
  * Replaces: spmm_cuda_with_mask(), src/cuda/spmm_cuda.cu:255-303 /

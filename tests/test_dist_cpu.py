@@ -21,6 +21,12 @@ class OracleOps:
         C, E = oracle.spmm(op, rowptr.numpy(), col.numpy(), None if val is None else val.numpy(), B.numpy())
         return torch.from_numpy(C), (torch.from_numpy(E) if op in (1, 2) else None)
 
+    def spmm_acc(self, rowptr, col, val, B, C, rowmap):
+        import oracle
+        Cr, _ = oracle.spmm(0, rowptr.numpy(), col.numpy(), None if val is None else val.numpy(), B.numpy())
+        C[rowmap.long()] += torch.from_numpy(Cr)
+        return C
+
     def gather_rows(self, src, ids):
         return src[ids.long()].contiguous()
 

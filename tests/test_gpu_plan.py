@@ -179,3 +179,44 @@ def test_plan_rejects_foreign_arrays_and_small_inputs(capi):
     rc = capi._lib.dgs_spmm_csr_plan_f32(0, 2000, 2000, 64, 20000, 0, 0, 0, 0, 0, 0, plan.buf.data_ptr(),
                                          ctypes.byref(plan.info), 0, 0, 0)
     assert rc == -1
+
+
+@pytest.mark.parametrize('shape', ['tiny', 'mid', 'big-plan', 'big-compact'])
+def test_accumulating_spmm(capi, shape):
+    """dgs_spmm_csr_acc_f32: C[rowmap[r]] += row r of A.B, through every schedule it can take (single launch, row stream
+    + units + combine, the same over a plan) and with a row map (compact matrix -> scattered rows of C, what dgsparse.dist
+    does with the halo product).  Rows of A without entries must leave their C row bit-untouched."""
+    rng = np.random.default_rng(7)
+    if shape == 'tiny':
+        rp, col, st = graphgen.powerlaw_csr(3000, 30000, alpha=1.9, dmax=900, seed=4)
+    elif shape == 'mid':
+        rp, col, st = graphgen.powerlaw_csr(70000, 500000, alpha=1.8, dmax=20000, seed=4)
+    else:
+        rp, col, st = big_graph(41)
+    M, K, N = st['M'], st['K'], 32
+    val = graphgen.weights(col.shape[0], 'uniform', 2)
+    X = rng.random((K, N), dtype=np.float32)
+    rpd, cold, vald, Xd = dev(rp), dev(col), dev(val), dev(X)
+    plan = capi.spmm_plan(rpd, cold, K, N, force=True) if shape.startswith('big') else None
+    Co, _ = oracle.spmm('sum', rp, col, val, X, fma=True)
+    lens = np.diff(rp)
+    if shape == 'big-compact':
+        Mc = 3 * M  # C has more rows than A; A's row r lands in a random distinct row of C
+        rowmap = rng.permutation(Mc)[:M].astype(np.int32)
+    else:
+        Mc, rowmap = M, None
+    C0 = rng.random((Mc, N), dtype=np.float32)
+    C = dev(C0)
+    capi.spmm_acc(rpd, cold, vald, Xd, C, None if rowmap is None else dev(rowmap), plan=plan)
+    torch.cuda.synchronize()
+    got = C.cpu().numpy()
+    exp = C0.copy()
+    tgt = np.arange(M) if rowmap is None else rowmap
+    exp[tgt] = C0[tgt] + Co
+    np.testing.assert_allclose(got, exp, rtol=2e-5, atol=1e-5)
+    untouched = np.ones(Mc, bool)
+    untouched[tgt[lens > 0]] = False
+    assert_bitexact(got[untouched], C0[untouched], 'rows of C that no row of A maps to (or whose row is empty)')
+    # short rows: one fma chain + one add, exactly
+    short = (lens > 0) & (lens <= 64)
+    assert_bitexact(got[tgt[short]], (C0[tgt[short]] + Co[short]).astype(np.float32), 'short rows: chain + one add')
