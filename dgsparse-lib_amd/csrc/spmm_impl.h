@@ -963,8 +963,7 @@ struct PlanHdr {
   int ch, t1, tslice, unit;
   int xcd_start[9];     // first unit of each XCD's share of the (sorted) unit table
   int slice_bound[9];   // column-slice boundaries (slice x = columns [b[x], b[x+1]))
-  int hot_thr[4];       // reference-count thresholds of the hot classes stored in pcol bits 28..30
-  int has_pcol;
+  int reserved[5];      // (popularity classes of an abandoned cache-policy experiment: DESIGN.md 4.1d)
 };
 static_assert(sizeof(PlanHdr) <= 256, "plan header must fit its 256-byte slot");
 

@@ -88,7 +88,6 @@ __global__ void plan_bounds(int K, int nnz, const int *__restrict__ cum, PlanHdr
     hdr->t1 = t1;
     hdr->tslice = tslice;
     hdr->unit = unit;
-    hdr->has_pcol = 0;
   }
   if (x > kPlanCells) return;
   int b;
@@ -366,7 +365,7 @@ extern "C" int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int3
     info->n_units = h.n_units;
     info->n_long = h.n_long;
     info->n_pslots = h.n_pslots;
-    info->has_pcol = h.has_pcol;
+    info->has_pcol = 0;
     info->tslice = h.tslice;
     info->off_long = 0;
     info->reserved = 0;
