@@ -1085,7 +1085,8 @@ static int launch_impl(const SpmmArgs &a) {
   // rows per wave: 64 when there are plenty of rows; mid-size graphs (arxiv-shaped: 169 k rows, 6.5 nnz/row) get fewer,
   // so that the chip still sees >= ~8k waves and a group's sequential stream stays a few gather rounds long
   int rpw = kRowsPerWave;
-  while (rpw > 8 && a.M / rpw < env_int("DGS_MIN_WAVES", 8192)) rpw >>= 1;
+  const int min_waves = env_int("DGS_MIN_WAVES", 8192);
+  while (rpw > 8 && a.M / rpw < min_waves) rpw >>= 1;
   const int rows_per_block = (kBlock / kWave) * rpw;
   const int64_t nbr = (a.M + rows_per_block - 1) / rows_per_block;
 #ifndef DGS_NBU

@@ -327,7 +327,8 @@ extern "C" int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int3
   void *tmp = ws + WL.off_tmp;
   // unit length: 256 nnz when there is plenty of work; smaller inputs get shorter units (a unit is a chain of up to
   // ch/64 dependent tiles, and a mid-size graph has too few units to hide it)
-  const int ch = env_int("DGS_PLAN_CH", nnz >= (8 << 20) ? kPlanCh : (nnz >= (2 << 20) ? 128 : 64));
+  int ch = env_int("DGS_PLAN_CH", nnz >= (8 << 20) ? kPlanCh : (nnz >= (2 << 20) ? 128 : 64));
+  ch = ch < kPlanChMin ? kPlanChMin : (ch > (1 << 20) ? (1 << 20) : ch);  // the table capacities assume ch >= kPlanChMin
   const int tslice = plan_tslice(), unit = plan_unit();
 
   if (hipMemsetAsync(hdr, 0, PL.off_units, st) != hipSuccess) return DGS_ELAUNCH;
