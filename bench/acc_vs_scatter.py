@@ -47,3 +47,31 @@ def b():
 print(f'rows with a remote entry {plan.rem_rows.numel()} of {part.n_local}, remote nnz {col.numel()}, halo rows {eng.n_halo}')
 print(f'(a) product into a temporary + scatter-add: {timeit(a):.4f} ms')
 print(f'(b) accumulating SpMM:                      {timeit(b):.4f} ms')
+
+# max: the undivided product over [local | halo] columns (what the non-overlapped path runs after the exchange) against the
+# two products of the overlapped path (local columns while the halo travels, then the accumulating max of the halo part)
+B_ext = torch.rand((part.n_local + eng.n_halo, N), device='cuda')
+erp, ecol, eval_ = part.rowptr, plan.col_ext, part.val
+lrp, lcol, lval = plan.loc
+Pe = _capi.spmm_plan(erp, ecol, B_ext.shape[0], N)
+Pl = _capi.spmm_plan(lrp, lcol, part.n_local, N)
+B_l, B_h = B_ext[:part.n_local], B_ext[part.n_local:]
+Cm, Em = _capi.spmm(1, lrp, lcol, lval, B_l, plan=Pl)
+
+
+def m_whole():
+    _capi.spmm(1, erp, ecol, eval_, B_ext, plan=Pe)
+
+
+def m_local():
+    _capi.spmm(1, lrp, lcol, lval, B_l, plan=Pl)
+
+
+def m_acc():
+    _capi.spmm_acc_max(rp, col, val, B_h, Cm, Em, plan.rem_rows, part.n_local, part.n_local, plan.h_lo, plan=P)
+
+
+tw, tl, ta = timeit(m_whole), timeit(m_local), timeit(m_acc)
+print(f'max, undivided extended product:            {tw:.4f} ms')
+print(f'max, local columns only:                    {tl:.4f} ms   (runs under the exchange)')
+print(f'max, accumulating halo product:             {ta:.4f} ms   (what is left after the exchange; sum of both {tl + ta:.4f})')

@@ -453,6 +453,61 @@ struct RowsLds {
   int4 rows[kBlock / kWave][kRowsPerWave + 1];  // {start, end, next non-empty short row, -}
 };
 
+// Accumulating variants (ACC): the row result is merged into what C (and E) already hold instead of overwriting it.
+//   sum  C[orow] += result
+//   max  (C, E)[orow] = the better of the old pair and (result, arg + col_off), first occurrence winning ties.  The two
+//        pairs come from two column subsets of the same matrix rows (dgsparse.dist: columns this rank owns / halo
+//        columns), whose ids live in one extended space [0, nl) = local, [nl, ...) = halo slots in global order; h_lo
+//        halo slots belong to lower ranks, i.e. come BEFORE the local columns in a row.  key() restores that order, so
+//        for rows with sorted columns "smaller key" = "earlier in CSR order" and MAX's rule (the earlier operand keeps
+//        value and arg on a tie) is reproduced exactly.  (MIN keeps the LATER operand's value bits on a tie while E
+//        names the first one; the position of the last minimum is not recoverable from (C, E), so min is not offered.)
+struct AccArg {
+  const int *rowmap;  // output row of every row of A (nullptr = identity)
+  int col_off;        // added to this product's arg column ids (halo slot -> extended id)
+  int nl, h_lo;       // extended-id layout: local columns [0, nl), h_lo of the halo slots precede them
+};
+__device__ __forceinline__ int acc_key(int e, int nl, int h_lo) { return e < nl ? h_lo + e : (e - nl < h_lo ? e - nl : e); }
+
+template <int V, int OP, bool HIDDEN>
+__device__ __forceinline__ void acc_commit(float *__restrict__ C, int *__restrict__ E, int64_t orow, int N, int f0,
+                                           const float (&acc)[V], const int (&ei)[V], const AccArg &aa) {
+  float *cp = C + orow * N + f0;
+  float old[V];
+  load_vec<V>(cp, old);
+  if constexpr (OP == DGS_MAX) {
+    int *ep = E + orow * N + f0;
+    int eo[V];
+    load_vec<V>(ep, eo);
+    // Branch-free on purpose, results in fresh arrays: hipcc 7.2 miscompiled the short-circuit form of this merge for
+    // V = 4 (a 64-bit register-pair move clobbered the kept value of the neighbouring feature).
+    float cv[V];
+    int ev[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+      const int en = ei[v] >= 0 ? ei[v] + aa.col_off : -1;
+      const int kn = acc_key(en, aa.nl, aa.h_lo), ko = acc_key(eo[v], aa.nl, aa.h_lo);
+      const int better = (int)(eo[v] < 0) | (int)(old[v] < acc[v]) | ((int)(old[v] == acc[v]) & (int)(kn < ko));
+      const bool take = ((int)(en >= 0) & better) != 0;
+      cv[v] = take ? acc[v] : old[v];
+      ev[v] = take ? en : eo[v];
+    }
+    if constexpr (HIDDEN) {
+      store_vec_hidden<V>(ep, ev);
+      store_vec_hidden<V>(cp, cv);
+    } else {
+      store_vec_stream<V>(ep, ev);
+      store_vec_stream<V>(cp, cv);
+    }
+  } else {
+    float cv[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) cv[v] = acc[v] + old[v];
+    if constexpr (HIDDEN) store_vec_hidden<V>(cp, cv);
+    else store_vec_stream<V>(cp, cv);
+  }
+}
+
 // ACC (sum only): C[out row] += result instead of C[row] = result, out row = rowmap[row] when a map is given (the
 // halo product of dgsparse.dist adds into the rows that have remote entries); rows without entries are left alone.
 template <int G, int V, int OP, bool HAS_VAL, bool INLINE, bool ACC = false>
@@ -460,8 +515,9 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
                                                const int *__restrict__ rowptr,
                                                const int *__restrict__ col, const float *__restrict__ val,
                                                const float *__restrict__ B, float *__restrict__ C,
-                                               int *__restrict__ E, const int *__restrict__ rowmap = nullptr) {
-  static_assert(!ACC || OP == DGS_SUM, "accumulation exists for the sum only");
+                                               int *__restrict__ E, const AccArg aa = AccArg{}) {
+  static_assert(!ACC || OP == DGS_SUM || OP == DGS_MAX, "accumulation exists for sum and max");
+  const int *rowmap = aa.rowmap;
   constexpr int NG = kWave / G;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -618,12 +674,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
               }
               if (fl) {
                 if constexpr (ACC) {
-                  float *cp = C + (int64_t)q.w * N + f0;
-                  float old[V];
-                  load_vec<V>(cp, old);
-#pragma unroll
-                  for (int v = 0; v < V; v++) acc[v] += old[v];
-                  store_vec_hidden<V>(cp, acc);
+                  acc_commit<V, OP, true>(C, E, q.w, N, f0, acc, ei, aa);
                 } else {
                   store_vec_hidden<V>(C + (int64_t)(r0 + cur) * N + f0, acc);
                   if constexpr (ARG) store_vec_hidden<V>(E + (int64_t)(r0 + cur) * N + f0, ei);
@@ -676,12 +727,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
         for (int v = 0; v < V; v++) acc[v] /= dg;
       }
       if constexpr (ACC) {
-        float *cp = C + (int64_t)rows[r].w * N + f0;
-        float old[V];
-        load_vec<V>(cp, old);
-#pragma unroll
-        for (int v = 0; v < V; v++) acc[v] += old[v];
-        store_vec_stream<V>(cp, acc);
+        acc_commit<V, OP, false>(C, E, rows[r].w, N, f0, acc, ei, aa);
       } else {
         store_vec_stream<V>(C + (int64_t)(r0 + r) * N + f0, acc);
         if constexpr (ARG) store_vec_stream<V>(E + (int64_t)(r0 + r) * N + f0, ei);
@@ -698,7 +744,7 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
                                                 const float *__restrict__ val, const float *__restrict__ B,
                                                 float *__restrict__ C, int *__restrict__ E, const UnitTab &ut,
                                                 float *__restrict__ part, int *__restrict__ parte,
-                                                const int *__restrict__ rowmap = nullptr) {
+                                                const AccArg aa = AccArg{}) {
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane / G, l = lane % G;
@@ -760,12 +806,7 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
           for (int v = 0; v < V; v++) acc[v] /= dg;
         }
         if constexpr (ACC) {
-          float *cp = C + (int64_t)(rowmap ? rowmap[d.x] : d.x) * N + f0;
-          float old[V];
-          load_vec<V>(cp, old);
-#pragma unroll
-          for (int v = 0; v < V; v++) acc[v] += old[v];
-          store_vec_stream<V>(cp, acc);
+          acc_commit<V, OP, false>(C, E, aa.rowmap ? aa.rowmap[d.x] : d.x, N, f0, acc, ei, aa);
         } else {
           store_vec_stream<V>(C + (int64_t)d.x * N + f0, acc);
           if constexpr (ARG) store_vec_stream<V>(E + (int64_t)d.x * N + f0, ei);
@@ -798,10 +839,10 @@ __global__ __launch_bounds__(kBlock, fused_waves_per_simd(OP)) void spmm_fused(i
                                                      const int *__restrict__ col, const float *__restrict__ val,
                                                      const float *__restrict__ B, float *__restrict__ C,
                                                      int *__restrict__ E, const UnitTab ut, float *__restrict__ part,
-                                                     int *__restrict__ parte, const int *__restrict__ rowmap) {
+                                                     int *__restrict__ parte, const AccArg aa) {
   __shared__ RowsLds lds;
   if ((int)blockIdx.x < nbu)
-    spmm_units_body<G, V, OP, HAS_VAL, ACC>(blockIdx.x, nbu, lds, N, rowptr, col, val, B, C, E, ut, part, parte, rowmap);
+    spmm_units_body<G, V, OP, HAS_VAL, ACC>(blockIdx.x, nbu, lds, N, rowptr, col, val, B, C, E, ut, part, parte, aa);
   else {
     // XCD-aware row mapping: workgroups are dealt round-robin to the 8 XCDs (observed: block b -> XCD b % 8), each
     // with a private L2.  Give every XCD a CONTIGUOUS eighth of the row blocks, so that neighbouring rows - which
@@ -813,7 +854,7 @@ __global__ __launch_bounds__(kBlock, fused_waves_per_simd(OP)) void spmm_fused(i
     const int per = nbr / 8;
     if (rb < per * 8) rb = (rb % 8) * per + rb / 8;
 #endif
-    spmm_rows_body<G, V, OP, HAS_VAL, false, ACC>(rb, rpw, lds, M, N, rowptr, col, val, B, C, E, rowmap);
+    spmm_rows_body<G, V, OP, HAS_VAL, false, ACC>(rb, rpw, lds, M, N, rowptr, col, val, B, C, E, aa);
   }
 }
 
@@ -824,9 +865,9 @@ template <int G, int V, int OP, bool HAS_VAL, bool ACC = false>
 __global__ __launch_bounds__(kBlock) void spmm_small(int M, int N, int rpw, const int *__restrict__ rowptr,
                                                      const int *__restrict__ col, const float *__restrict__ val,
                                                      const float *__restrict__ B, float *__restrict__ C,
-                                                     int *__restrict__ E, const int *__restrict__ rowmap) {
+                                                     int *__restrict__ E, const AccArg aa) {
   __shared__ RowsLds lds;
-  spmm_rows_body<G, V, OP, HAS_VAL, true, ACC>(blockIdx.x, rpw, lds, M, N, rowptr, col, val, B, C, E, rowmap);
+  spmm_rows_body<G, V, OP, HAS_VAL, true, ACC>(blockIdx.x, rpw, lds, M, N, rowptr, col, val, B, C, E, aa);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -838,7 +879,7 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
                                                        const float *__restrict__ B, float *__restrict__ C,
                                                        int *__restrict__ E, const UnitTab ut,
                                                        const float *__restrict__ part,
-                                                       const int *__restrict__ parte, const int *__restrict__ rowmap) {
+                                                       const int *__restrict__ parte, const AccArg aa) {
   constexpr int NG = kWave / G;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
   constexpr int UP = 4;
@@ -920,12 +961,7 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
         for (int v = 0; v < V; v++) acc[v] /= dg;
       }
       if constexpr (ACC) {
-        float *cp = C + (int64_t)(rowmap ? rowmap[d.x] : d.x) * N + f0;
-        float old[V];
-        load_vec<V>(cp, old);
-#pragma unroll
-        for (int v = 0; v < V; v++) acc[v] += old[v];
-        store_vec_stream<V>(cp, acc);
+        acc_commit<V, OP, false>(C, E, aa.rowmap ? aa.rowmap[d.x] : d.x, N, f0, acc, ei, aa);
       } else {
         store_vec_stream<V>(C + (int64_t)d.x * N + f0, acc);
         if constexpr (ARG) store_vec_stream<V>(E + (int64_t)d.x * N + f0, ei);
@@ -950,8 +986,8 @@ struct SpmmArgs {
   const struct PlanHdr *plan = nullptr;
   int plan_units = 0, plan_long = 0, plan_pslots = 0, plan_off_long = 0;
   int hints = 0;  // DGS_ALG_* bits of the `algorithm` argument
-  bool accumulate = false;      // C[rowmap[r]] += ... instead of C[r] = ... (sum only)
-  const int *rowmap = nullptr;  // accumulate: output row of every row of A (nullptr = identity)
+  bool accumulate = false;      // merge into C (and E) instead of overwriting (sum, max): see AccArg
+  AccArg acc{};
 };
 
 // Device-resident header of a cached plan, followed by the tables (all offsets in bytes from the header).
@@ -1063,11 +1099,11 @@ static int launch_impl(const SpmmArgs &a) {
       }
       const int nbu = 1024;
       hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC>), dim3((unsigned)nbu, (unsigned)a.tiles), dim3(kBlock), 0, a.st, (int)a.M,
-                         (int)a.N, nbu, kRowsPerWave, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.rowmap);
+                         (int)a.N, nbu, kRowsPerWave, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.acc);
       const int64_t cb = (L.max_long + 3) / 4;
       const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
       hipLaunchKernelGGL((spmm_combine<G, V, OP, ACC>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B,
-                         a.C, a.E, ut, part, parte, a.rowmap);
+                         a.C, a.E, ut, part, parte, a.acc);
       return check_launch();
     }
   }
@@ -1079,7 +1115,7 @@ static int launch_impl(const SpmmArgs &a) {
     const int rpb = (kBlock / kWave) * rpw;
     const dim3 grid((unsigned)((a.M + rpb - 1) / rpb), (unsigned)a.tiles);
     hipLaunchKernelGGL((spmm_small<G, V, OP, HAS_VAL, ACC>), grid, dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, rpw,
-                       a.rowptr, a.col, a.val, a.B, a.C, a.E, a.rowmap);
+                       a.rowptr, a.col, a.val, a.B, a.C, a.E, a.acc);
     return check_launch();
   }
   // rows per wave: 64 when there are plenty of rows; mid-size graphs (arxiv-shaped: 169 k rows, 6.5 nnz/row) get fewer,
@@ -1108,12 +1144,12 @@ static int launch_impl(const SpmmArgs &a) {
     ub = (ub + 7) & ~int64_t(7);  // a multiple of 8 so that the XCD mapping of the unit blocks applies
     const int nbu = (int)(ub < DGS_NBU ? (ub < 8 ? 8 : ub) : DGS_NBU);
     hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
-                       a.st, (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.rowmap);
+                       a.st, (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.acc);
     if (a.plan_long > 0) {
       const int64_t cb = ((int64_t)a.plan_long + 3) / 4;
       const dim3 g3((unsigned)(cb < 2048 ? cb : 2048), (unsigned)a.tiles);
       hipLaunchKernelGGL((spmm_combine<G, V, OP, ACC>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B,
-                         a.C, a.E, ut, part, parte, a.rowmap);
+                         a.C, a.E, ut, part, parte, a.acc);
     }
     return check_launch();
   }
@@ -1133,19 +1169,19 @@ static int launch_impl(const SpmmArgs &a) {
   const int64_t ub = (L.max_units + 3) / 4;
   const int nbu = (int)(ub < DGS_NBU ? (ub < 1 ? 1 : ub) : DGS_NBU);
   hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
-                     a.st, (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.rowmap);
+                     a.st, (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.acc);
   // combine: one wave per multi-unit row
   const int64_t cb = (L.max_long + 3) / 4;
   const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
   hipLaunchKernelGGL((spmm_combine<G, V, OP, ACC>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B, a.C,
-                     a.E, ut, part, parte, a.rowmap);
+                     a.E, ut, part, parte, a.acc);
   return check_launch();
 }
 
 template <int G, int V, int OP, bool HAS_VAL>
 static int launch_all(const SpmmArgs &a) {
-  if (a.accumulate) {  // C[rowmap[r]] += row r of A.B (sum only; never the column-panel sweep)
-    if constexpr (OP == DGS_SUM) return launch_impl<G, V, OP, HAS_VAL, true>(a);
+  if (a.accumulate) {  // merge into C / (C, E) (sum, max; never the column-panel sweep)
+    if constexpr (OP == DGS_SUM || OP == DGS_MAX) return launch_impl<G, V, OP, HAS_VAL, true>(a);
     else return DGS_EINVAL;
   }
   return launch_impl<G, V, OP, HAS_VAL, false>(a);

@@ -63,6 +63,9 @@ _lib.dgs_spmm_csr_plan_f32.argtypes = [_int, _i64, _i64, _i64, _i64, _vp, _vp, _
 _lib.dgs_spmm_csr_acc_f32.restype = _int
 _lib.dgs_spmm_csr_acc_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(PlanInfo), _vp, _sz,
                                       _vp]
+_lib.dgs_spmm_csr_acc_max_f32.restype = _int
+_lib.dgs_spmm_csr_acc_max_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp,
+                                          ctypes.POINTER(PlanInfo), _vp, _sz, _vp]
 _lib.dgs_spmm_csr_mask_f32.restype = _int
 _lib.dgs_spmm_csr_mask_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
 _lib.dgs_spmm_csr_mask_workspace_bytes.restype = _sz
@@ -95,7 +98,7 @@ _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
            'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes', 'dgs_spmm_plan_build',
            'dgs_spmm_plan_compact_bytes', 'dgs_spmm_plan_compact', 'dgs_spmm_csr_plan_workspace_bytes',
-           'dgs_spmm_csr_plan_f32', 'dgs_spmm_csr_acc_f32',
+           'dgs_spmm_csr_plan_f32', 'dgs_spmm_csr_acc_f32', 'dgs_spmm_csr_acc_max_f32',
            'dgs_spmm_csr_schedule', 'dgs_spmm_arg_backward_f32', 'dgs_sddmm_csr_schedule',
            'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
            'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'dgs_relabel_i32', 'dgs_sddmm_coo_f32', 'dgs_gspmm_csr_workspace_bytes', 'dgs_gspmm_csr_f32', 'gespmmCsrSpMM',
@@ -303,6 +306,43 @@ def spmm_acc(rowptr, col, values, dense, C, rowmap=None, plan=None):
                                          ctypes.byref(plan.info) if plan is not None else None, _p(ws), wsb, _stream(dev)),
                'spmm_acc')
     return C
+
+
+def spmm_acc_max(rowptr, col, values, dense, C, E, rowmap=None, col_off=0, n_local=0, h_lo=0, plan=None):
+    """(C, E)[rowmap[r], :] <- better of what they hold and max over row r of A (args written as col + col_off), in place;
+    ties go to the column that comes first in the order  [h_lo lower slots | n_local first-product columns | the rest]
+    (include/dgsparse_hip.h: dgs_spmm_csr_acc_max_f32)."""
+    dev = _need_gpu(rowptr, col, values, dense, C, E, rowmap)
+    rowptr = _i32(rowptr, 'rowptr')
+    col = _i32(col, 'col')
+    dense = _f32mat(dense, 'dense')
+    M, nnz, (K, N) = rowptr.numel() - 1, col.numel(), dense.shape
+    if C.dtype != torch.float32 or C.dim() != 2 or C.shape[1] != N or not C.is_contiguous():
+        raise TypeError('dgsparse: C must be a contiguous float32 [rows, N] tensor')
+    if E.dtype != torch.int32 or E.shape != C.shape or not E.is_contiguous():
+        raise TypeError('dgsparse: E must be a contiguous int32 tensor with the shape of C')
+    if rowmap is not None:
+        rowmap = _i32(rowmap, 'rowmap')
+        if rowmap.numel() != M:
+            raise ValueError('dgsparse: rowmap needs one entry per row of A')
+    elif C.shape[0] < M:
+        raise ValueError('dgsparse: C has fewer rows than A')
+    values = _f32vec(values, 'values', nnz)
+    if plan is not None and (plan.M != M or plan.nnz != nnz or plan.col_ptr != col.data_ptr() or
+                             plan.rowptr_ptr != rowptr.data_ptr()):
+        raise ValueError('dgsparse: the plan was built for other (rowptr, col) arrays')
+    with _on_device(dev):
+        if plan is not None:
+            wsb = _lib.dgs_spmm_csr_plan_workspace_bytes(MAX, M, N, nnz, ctypes.byref(plan.info))
+        else:
+            wsb = _lib.dgs_spmm_csr_workspace_bytes(MAX, M, N, nnz)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        _check(_lib.dgs_spmm_csr_acc_max_f32(M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(dense), _p(C), _p(E),
+                                             _p(rowmap), int(col_off), int(n_local), int(h_lo),
+                                             _p(plan.buf) if plan is not None else None,
+                                             ctypes.byref(plan.info) if plan is not None else None, _p(ws), wsb,
+                                             _stream(dev)), 'spmm_acc_max')
+    return C, E
 
 
 SCHEDULES = ('small', 'rows', 'panel')

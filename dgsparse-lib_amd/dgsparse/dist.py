@@ -173,6 +173,14 @@ class HaloPlan:
         self.rem, keep = _sub(is_remote, nl, True)
         self.rem_rows = keep.to(torch.int32).contiguous()
         self.deg = counts.clamp(min=1).to(torch.float32)
+        # for the overlapped max: halo slots owned by lower ranks (they precede the local columns in a sorted row), and
+        # whether every row's columns are sorted (then "smaller global column" = "earlier in CSR order")
+        self.h_lo = int(recv_splits[:rank].sum())
+        inc = torch.ones(col.numel(), dtype=torch.bool, device=dev)
+        if col.numel() > 1:
+            inc[1:] = col[1:] >= col[:-1]
+            inc[part.rowptr[1:-1].long().clamp(max=col.numel() - 1)] = True  # a row start never breaks the order
+        self.rows_sorted = bool(inc.all())
         if world == 1 or standalone:  # nothing to exchange; no process group needed
             self.send_splits = [0] * world
             self.send_ids = torch.zeros(0, dtype=torch.int32, device=dev)
@@ -209,6 +217,11 @@ class _HipOps:
     def spmm_acc(self, rowptr, col, val, B, C, rowmap):
         """C[rowmap[r]] += row r of A.B, in place (dgs_spmm_csr_acc_f32)."""
         return self._c.spmm_acc(rowptr, col, val, B, C, rowmap, plan=self._plan(rowptr, col, B.shape[0], B.shape[1]))
+
+    def spmm_acc_max(self, rowptr, col, val, B, C, E, rowmap, col_off, n_local, h_lo):
+        """(C, E)[rowmap[r]] <- better of the old pair and the max over row r (dgs_spmm_csr_acc_max_f32), in place."""
+        return self._c.spmm_acc_max(rowptr, col, val, B, C, E, rowmap, col_off, n_local, h_lo,
+                                    plan=self._plan(rowptr, col, B.shape[0], B.shape[1]))
 
     def sddmm(self, rowptr, col, D1, D2, op=0, E=None):
         return self._c.sddmm(rowptr, col, D1, D2, op, E=E)
@@ -298,6 +311,21 @@ class DistSpMM:
             if reduce == 'mean':
                 C /= plan.deg[:, None]
             self.last_E = self.last_E_ext = None
+            return C
+        if self.overlap and p.world > 1 and not self.standalone and reduce == 'max' and plan.rows_sorted:
+            # the same overlap for max: (value, arg) of the local columns while the halo travels, then the halo product
+            # merges into them, ties going to the smaller GLOBAL column = the earlier entry of a sorted row (exact)
+            B_ext, work = self.exchange(B_loc, async_op=True)
+            vl = plan.loc[2] if val is None else val[plan.nnz_pos_loc]
+            vr = plan.rem[2] if val is None else val[plan.nnz_pos_rem]
+            C, E = self.ops.spmm(1, plan.loc[0], plan.loc[1], vl, B_ext[:p.n_local], shared_gpu=True)
+            if work is not None:
+                work.wait()
+            if plan.rem_rows.numel() > 0:
+                self.ops.spmm_acc_max(plan.rem[0], plan.rem[1], vr, B_ext[p.n_local:], C, E, plan.rem_rows, p.n_local,
+                                      p.n_local, plan.h_lo)
+            self.last_E_ext = E
+            self.last_E = self.ops.relabel(E, plan.ext2glob32)
             return C
         self.exchange(B_loc)
         return self.compute(reduce, val)

@@ -140,6 +140,23 @@ int dgs_spmm_csr_acc_f32(int64_t M, int64_t K, int64_t N, int64_t nnz, const int
                          const dgsSpmmPlanInfo *info, void *workspace, size_t workspace_bytes, dgsStream_t stream);
 
 /*
+ * Accumulating SpMM (max with arg ids):  (C, E)[rowmap[r],:] = better of { what they hold, max over row r of A } where the
+ * arg of this product is written as col + col_off.  For a matrix whose columns were split into two products over one
+ * extended index space - ids [0, n_local) = columns of the first product, [n_local, ...) = the second's, of which the
+ * first h_lo slots stand for columns that PRECEDE the first product's in the original rows (dgsparse.dist: this rank's
+ * columns / halo slots in global order, h_lo of them owned by lower ranks).  Ties go to the entry that comes first in
+ * that original column order, value and arg together - exactly algorithm 0's rule on the undivided row provided the row's
+ * columns are sorted (include/cuda/spmm_cuda.cuh:38-41).  E == -1 means "no arg yet" (empty so far).  New; lets the
+ * multi-GPU max overlap its local product with the halo exchange.  MIN is not offered: its macro keeps the LATER
+ * operand's bits on a tie (+0.0 / -0.0) while E names the first, and the position of the last minimum cannot be
+ * recovered from (C, E).
+ */
+int dgs_spmm_csr_acc_max_f32(int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                             const float *val, const float *B, float *C, int32_t *E, const int32_t *rowmap,
+                             int32_t col_off, int32_t n_local, int32_t h_lo, const void *plan,
+                             const dgsSpmmPlanInfo *info, void *workspace, size_t workspace_bytes, dgsStream_t stream);
+
+/*
  * Masked SpMM = backward of max/min w.r.t. the dense operand, run on the CSC arrays of A:
  *   out[j,:] = sum_{p in [ptr[j],ptr[j+1])} [E[idx[p],:] == j] * val[p] * G[idx[p],:]
  * Replaces: spmm_cuda_with_mask(), src/cuda/spmm_cuda.cu:255-303 /

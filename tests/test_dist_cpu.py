@@ -27,6 +27,21 @@ class OracleOps:
         C[rowmap.long()] += torch.from_numpy(Cr)
         return C
 
+    def spmm_acc_max(self, rowptr, col, val, B, C, E, rowmap, col_off, n_local, h_lo):
+        """numpy restatement of dgs_spmm_csr_acc_max_f32's merge rule (include/dgsparse_hip.h)."""
+        import oracle
+        Cr, Er = oracle.spmm(1, rowptr.numpy(), col.numpy(), None if val is None else val.numpy(), B.numpy())
+        rm = rowmap.long().numpy()
+        Co, Eo = C.numpy()[rm], E.numpy()[rm]
+        en = np.where(Er >= 0, Er + col_off, -1)
+
+        def key(e):
+            return np.where(e < n_local, h_lo + e, np.where(e - n_local < h_lo, e - n_local, e))
+        take = (en >= 0) & ((Eo < 0) | (Co < Cr) | ((Co == Cr) & (key(en) < key(Eo))))
+        C[rowmap.long()] = torch.from_numpy(np.where(take, Cr, Co))
+        E[rowmap.long()] = torch.from_numpy(np.where(take, en, Eo).astype(np.int32))
+        return C, E
+
     def gather_rows(self, src, ids):
         return src[ids.long()].contiguous()
 
@@ -97,6 +112,11 @@ def _worker(rank, world, port, cols, q):
             if red in ('sum', 'mean'):  # overlapped path: local part + halo part, summation order differs
                 Co = eng_ov.spmm(torch.from_numpy(X[r0:r1].copy()), red)
                 res[red + '_overlap'] = bool(np.allclose(Co.numpy(), Cg[r0:r1], rtol=1e-5, atol=2e-6))
+            if red == 'max':  # overlapped max: two products merged by global column order: values AND E bit-exact
+                assert eng_ov.plan.rows_sorted
+                Co = eng_ov.spmm(torch.from_numpy(X[r0:r1].copy()), red)
+                res['max_overlap'] = bool(np.array_equal(Co.numpy().view(np.int32), Cg[r0:r1].view(np.int32)) and
+                                          np.array_equal(eng_ov.last_E.numpy(), Eg[r0:r1]))
         # backward of sum w.r.t. B through the reversed exchange == rows [r0,r1) of A^T G on the whole graph
         G = (np.random.default_rng(2).integers(-2, 3, (M, N)) / 4).astype(np.float32)
         Bl = torch.from_numpy(X[r0:r1].copy()).requires_grad_()

@@ -220,3 +220,43 @@ def test_accumulating_spmm(capi, shape):
     # short rows: one fma chain + one add, exactly
     short = (lens > 0) & (lens <= 64)
     assert_bitexact(got[tgt[short]], (C0[tgt[short]] + Co[short]).astype(np.float32), 'short rows: chain + one add')
+
+
+@pytest.mark.parametrize('shape', ['tiny', 'big-plan'])
+def test_accumulating_max_merges_two_column_subsets_exactly(capi, shape):
+    """dgs_spmm_csr_acc_max_f32: a matrix whose columns are split into "local" [a, b) and "halo" (the rest, as slots in
+    global order, h_lo = a of them preceding the local ones) is reduced in two products - max over the local columns, then
+    the halo product merged into (C, E) - and must equal algorithm 0 on the undivided rows BIT FOR BIT, values and arg
+    ids, with plenty of ties (tied weights, quantised features): what dgsparse.dist's overlapped max relies on."""
+    if shape == 'tiny':
+        rp, col, st = graphgen.powerlaw_csr(3000, 40000, alpha=1.9, dmax=900, seed=8)
+    else:
+        rp, col, st = big_graph(43)
+    M, K, N = st['M'], st['K'], 16
+    a, b = K // 3, K // 3 + K // 4  # local columns
+    nl, h_lo = b - a, a
+    val = graphgen.weights(col.shape[0], 'tied', 3)
+    X = (np.random.default_rng(9).integers(-2, 3, (K, N)) / 4).astype(np.float32)
+    # extended index space: local first, then the halo slots in global order
+    ext = np.where((col >= a) & (col < b), col - a, np.where(col < a, nl + col, col)).astype(np.int32)
+    Xe = np.concatenate([X[a:b], X[:a], X[b:]])
+    Co, Eo = oracle.spmm('max', rp, ext, val, Xe)  # the undivided rows, CSR order = global column order
+    is_loc = (col >= a) & (col < b)
+    rows = np.repeat(np.arange(M), np.diff(rp))
+
+    def sub(mask, shift, compact):
+        cnt = np.bincount(rows[mask], minlength=M)
+        keep = np.nonzero(cnt)[0] if compact else np.arange(M)
+        rpp = np.concatenate([[0], np.cumsum(cnt[keep])]).astype(np.int32)
+        return rpp, (ext[mask] - shift).astype(np.int32), val[mask], keep.astype(np.int32)
+
+    lrp, lcol, lval, _ = sub(is_loc, 0, False)
+    rrp, rcol, rval, rrows = sub(~is_loc, nl, True)
+    Xd = dev(Xe)
+    C, E = capi.spmm(oracle.MAX, dev(lrp), dev(lcol), dev(lval), Xd[:nl])
+    rrpd, rcold = dev(rrp), dev(rcol)
+    plan = capi.spmm_plan(rrpd, rcold, K - nl, N, force=True) if shape == 'big-plan' else None
+    capi.spmm_acc_max(rrpd, rcold, dev(rval), Xd[nl:], C, E, dev(rrows), col_off=nl, n_local=nl, h_lo=h_lo, plan=plan)
+    torch.cuda.synchronize()
+    assert_bitexact(C.cpu().numpy(), Co, 'merged max values')
+    assert_bitexact(E.cpu().numpy(), Eo, 'merged arg ids (extended space)')
