@@ -649,6 +649,9 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
         cv[u] = tile[min(ps + u, last)];
         load_vec_gather<V>(Bl + (int64_t)(cv[u].x & 0x7fffffff) * N, x[u]);
         if constexpr (OP == kOpMaskSum) load_vec<V>(El + (int64_t)(cv[u].x & 0x7fffffff) * N, mk[u]);
+        // keep the fill in slot order: hipcc otherwise issues slot 0 LAST, and the loop's first wait - merged over the
+        // entry edge and the back edge - becomes vmcnt(1), a drain of the whole window once per kU1 gathers
+        __builtin_amdgcn_sched_barrier(0);
       }
       for (int p = ps; p < pe; p += kU1) {
 #pragma unroll
