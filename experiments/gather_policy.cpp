@@ -71,7 +71,7 @@ static void run(const char *name, const float *hot, const float *cold, const int
       if (rep && ms < best[mode]) best[mode] = ms;
     }
   const double half = total / 2 * 256.0;
-  printf("cold policy %-12s hot %5.1f MB: mixed %.3f ms | hot alone %.3f ms (%.1f TB/s) | cold alone %.3f ms (%.2f TB/s) | mixed - cold alone = %.3f ms\n",
+  printf("cold policy %-12s hot %7.3f MB: mixed %.3f ms | hot alone %.3f ms (%.1f TB/s) | cold alone %.3f ms (%.2f TB/s) | mixed - cold alone = %.3f ms\n",
          name, hot_rows * 256.0 / 1048576.0, best[0], best[1], half / best[1] / 1e9, best[2], half / best[2] / 1e9,
          best[0] - best[2]);
 }
@@ -93,7 +93,7 @@ int main() {
   for (long i = 0; i < total; i++) h[i] = (int)(((long)rand() * 32768 + rand()) & 0x7fffffff);
   hipMemcpy(idx, h.data(), total * 4, hipMemcpyHostToDevice);
   const int cold_rows = (int)(cbytes / 256);
-  for (int hot_rows : {4096, 8192, 16384}) {  // 1, 2, 4 MB
+  for (int hot_rows : {32, 64, 128, 256, 4096, 8192, 16384}) {  // 8 .. 64 KB (the 32 KB L1?), then 1, 2, 4 MB
     run<0>("default", hot, cold, idx, out, total, hot_rows, cold_rows);
     run<1>("nt", hot, cold, idx, out, total, hot_rows, cold_rows);
     run<2>("sc1", hot, cold, idx, out, total, hot_rows, cold_rows);
