@@ -56,6 +56,57 @@ def one_case(rng, it):
         else:
             sc = 1 if reduce == 'sum' else np.maximum(np.diff(rp), 1)[:, None]
             assert_sum_parity(C, Co, C64 / sc, S64 / sc, 1e-5, 2e-6, tag + ' ' + reduce, lens=np.diff(rp))
+    if col.shape[0] and M > 1 and rng.integers(0, 2) == 0:
+        # round-2 entries: a forced locality plan must reproduce the plan-free results (max/min + E bit for bit, sum within
+        # the bar), the accumulating sum adds into what C holds, the accumulating max merges a column split exactly
+        plan = capi.spmm_plan(drp, dcol, K, N, force=True)
+        if plan is not None:
+            for reduce in ('sum', 'max', 'min'):
+                C, E = capi.spmm(oracle.REDUCE[reduce], drp, dcol, dval, dX, plan=plan)
+                Co, Eo = oracle.spmm(reduce, rp, col, val, X, fma=True)
+                if reduce == 'sum':
+                    assert_sum_parity(C.cpu().numpy(), Co, C64, S64, 1e-5, 2e-6, tag + ' plan sum', lens=np.diff(rp))
+                else:
+                    assert_bitexact(C.cpu().numpy(), Co, tag + ' plan ' + reduce)
+                    assert_bitexact(E.cpu().numpy(), Eo, tag + ' plan E ' + reduce)
+        C0 = (rng.integers(-4, 5, (M, N)) / 4).astype(np.float32)
+        Cacc = dev(C0)
+        capi.spmm_acc(drp, dcol, dval, dX, Cacc, None, plan=plan)
+        Co, _ = oracle.spmm('sum', rp, col, val, X, fma=True)
+        live = np.diff(rp) > 0
+        assert_sum_parity(Cacc.cpu().numpy()[live].astype(np.float64) - C0[live], Co[live], C64[live], S64[live] + np.abs(C0[live]), 1e-5, 4e-6,
+                          tag + ' acc sum', lens=np.diff(rp)[live])
+        assert_bitexact(Cacc.cpu().numpy()[~live], C0[~live], tag + ' acc sum leaves empty rows alone')
+        srt = all(np.all(np.diff(col[rp[r]:rp[r + 1]]) >= 0) for r in range(M)) if M <= 5000 else False
+        if srt and K >= 3:
+            a, b = K // 3, K // 3 + max(1, K // 4)
+            nl, h_lo = b - a, a
+            ext = np.where((col >= a) & (col < b), col - a, np.where(col < a, nl + col, col)).astype(np.int32)
+            Xe = np.concatenate([X[a:b], X[:a], X[b:]])
+            Cu, Eu = oracle.spmm('max', rp, ext, val, Xe, fma=True)
+            is_loc = (col >= a) & (col < b)
+            rows_of = np.repeat(np.arange(M), np.diff(rp))
+            vv = val if val is not None else np.ones(col.shape[0], np.float32)
+
+            def sub(mask, shift, compact):
+                cnt = np.bincount(rows_of[mask], minlength=M)
+                keep = np.nonzero(cnt)[0] if compact else np.arange(M)
+                rpp = np.concatenate([[0], np.cumsum(cnt[keep])]).astype(np.int32)
+                return rpp, (ext[mask] - shift).astype(np.int32), vv[mask], keep.astype(np.int32)
+
+            lrp, lcol, lval, _ = sub(is_loc, 0, False)
+            rrp, rcol, rval, rrows = sub(~is_loc, nl, True)
+            Xd = dev(Xe)
+            if lcol.shape[0]:
+                Cm, Em = capi.spmm(oracle.MAX, dev(lrp), dev(lcol), dev(lval), Xd[:nl].contiguous())
+            else:
+                Cm = torch.zeros((M, N), device='cuda')
+                Em = torch.full((M, N), -1, dtype=torch.int32, device='cuda')
+            if rcol.shape[0]:
+                capi.spmm_acc_max(dev(rrp), dev(rcol), dev(rval), Xd[nl:].contiguous(), Cm, Em, dev(rrows), col_off=nl,
+                                  n_local=nl, h_lo=h_lo)
+            assert_bitexact(Cm.cpu().numpy(), Cu, tag + ' acc max values')
+            assert_bitexact(Em.cpu().numpy(), Eu, tag + ' acc max E')
     if col.shape[0]:
         D1 = (rng.integers(-3, 4, (M, N)) / 8).astype(np.float32)
         dD1 = dev(D1)
