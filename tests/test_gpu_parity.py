@@ -331,6 +331,42 @@ def test_cabi_error_codes(capi):
     assert bool((E == -1).all())
 
 
+def test_cabi_error_codes_of_the_accumulating_entries(capi):
+    """dgs_spmm_csr_acc_f32 / dgs_spmm_csr_acc_max_f32: null operands, negative sizes, missing workspace -> error codes,
+    C / E untouched; an empty product is DGS_OK and a no-op; the ctypes wrapper refuses wrong dtypes and shapes."""
+    lib = capi._lib
+    M, K, N = 70000, 70000, 64
+    rp, col, st = graphgen.powerlaw_csr(M, 600000, K=K, alpha=2.1, dmax=3000, seed=2)
+    drp, dcol, dX = dev(rp), dev(col), torch.rand(K, N, device='cuda')
+    nnz = col.shape[0]
+    C = torch.full((M, N), 3.0, device='cuda')
+    E = torch.full((M, N), 5, dtype=torch.int32, device='cuda')
+    need = lib.dgs_spmm_csr_workspace_bytes(1, M, N, nnz)
+    ws = torch.empty(max(need, lib.dgs_spmm_csr_workspace_bytes(0, M, N, nnz)), dtype=torch.uint8, device='cuda')
+    p = lambda t: t.data_ptr()  # noqa: E731
+    acc = lambda Cp, wsp, wsb, m=M: lib.dgs_spmm_csr_acc_f32(m, K, N, nnz, p(drp), p(dcol), None, p(dX), Cp, None, None, None,  # noqa: E731
+                                                            wsp, wsb, None)
+    accm = lambda Cp, Ep, wsp, wsb, nl=0, hlo=0: lib.dgs_spmm_csr_acc_max_f32(M, K, N, nnz, p(drp), p(dcol), None, p(dX), Cp, Ep,  # noqa: E731
+                                                                             None, 0, nl, hlo, None, None, wsp, wsb, None)
+    assert acc(None, p(ws), ws.numel()) == -1
+    assert acc(p(C), None, 0) == -2
+    assert acc(p(C), p(ws), ws.numel(), m=-1) == -1
+    assert accm(p(C), None, p(ws), ws.numel()) == -1  # max needs E
+    assert accm(p(C), p(E), None, 0) == -2
+    assert accm(p(C), p(E), p(ws), ws.numel(), nl=-1) == -1
+    assert accm(p(C), p(E), p(ws), ws.numel(), hlo=-3) == -1
+    assert lib.dgs_spmm_csr_acc_max_f32(M, K, N, 0, p(drp), p(dcol), None, p(dX), p(C), p(E), None, 0, 0, 0, None, None, None, 0,
+                                        None) == 0  # nothing to merge
+    torch.cuda.synchronize()
+    assert bool((C == 3.0).all()) and bool((E == 5).all())
+    with pytest.raises(TypeError):
+        capi.spmm_acc_max(drp, dcol, None, dX, C, E.long())
+    with pytest.raises(TypeError):
+        capi.spmm_acc(drp, dcol, None, dX, C[:, :32])
+    with pytest.raises(ValueError):
+        capi.spmm_acc_max(drp, dcol, None, dX, C, E, rowmap=torch.zeros(3, dtype=torch.int32, device='cuda'))
+
+
 def _threshold_graph(M, K, lens, seed):
     """CSR whose first rows have exactly the given lengths (duplicates allowed), the rest short random rows."""
     rng = np.random.default_rng(seed)
