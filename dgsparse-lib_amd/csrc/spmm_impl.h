@@ -885,7 +885,10 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
                                                        const int *__restrict__ parte, const AccArg aa) {
   constexpr int NG = kWave / G;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
-  constexpr int UP = 4;
+#ifndef DGS_COMBINE_UP
+#define DGS_COMBINE_UP 8  // partial rows in flight per lane: 4 -> 8 takes the fold of a 400-unit hub row from 25 to 13 dependent rounds (combine 13.6 -> ~8 us on the headline graph, 8.7 -> 6.5 us arxiv-shaped); 16 adds little
+#endif
+  constexpr int UP = DGS_COMBINE_UP;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane / G, l = lane % G;
   const int f0 = (blockIdx.y * G + l) * V;
