@@ -71,6 +71,15 @@ constexpr int kT1 = DGS_T1;   // rows up to this many nnz are streamed sequentia
 constexpr int kT2 = DGS_T2;   // rows in (T1, T2] would be reduced in place by the wave that owns their row block; the
                               // measured optimum is T2 == T1 (every row > T1 becomes units: better balance), so that
                               // in-place path is live only in spmm_small, where it handles ALL long rows
+#ifndef DGS_TRACE
+#define DGS_TRACE 0
+#endif
+#if DGS_TRACE
+__device__ unsigned long long *g_dgs_trace = nullptr;  // [wave][8] timestamps (experiment: per-wave timeline)
+#define DGS_TS(k) do { if (g_dgs_trace && lane == 0 && blockIdx.y == 0) g_dgs_trace[(size_t)trace_id * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define DGS_TS(k) do { } while (0)
+#endif
 constexpr int kCap = DGS_CAP; // (col,val) pairs per wave LDS tile of the row blocks (4 KiB per wave, 16 KiB per block)
 constexpr int kRowsPerWave = 64;
 #ifndef DGS_KU1
@@ -524,6 +533,8 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
   const int g = lane / G, l = lane % G;
   const int r0 = (bid * (kBlock / kWave) + wave) * rpw;  // rpw <= 64 rows per wave (fewer on small inputs)
   if (r0 >= M) return;  // wave-uniform
+  [[maybe_unused]] const int trace_id = bid * (kBlock / kWave) + wave;
+  DGS_TS(0);
   int2 *tile = lds.tile[wave];
   int4 *rows = lds.rows[wave];
   const int nrows = min(rpw, M - r0);
@@ -572,6 +583,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
     }
   }
 
+  DGS_TS(1);  // rowptr arrived (ballots above consumed it), row table in LDS, empty rows written
   int a = 0;
   while (a < nrows) {
     const int s_a = __shfl(s_i, a, 64);
@@ -589,19 +601,36 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
       continue;
     }
     __builtin_amdgcn_wave_barrier();
+    // (one pass per 64 entries; issuing all passes' loads before the first LDS store was tried after the per-wave
+    // timeline showed 24 % / 61 % of a row wave's life here (arxiv-shaped / headline graph): no change in that share - the
+    // wait is the queueing delay of a streaming load behind the CU's gathers, not a chain - and the 16 extra live
+    // registers cost the max kernel 4 %)
     for (int t = lane; t < cnt; t += kWave) {
       const int c = ld_stream(col + s_a + t);
       const float w = HAS_VAL ? ld_stream(val + s_a + t) : 1.0f;
       tile[t] = make_int2(c, __float_as_int(w));
     }
     __builtin_amdgcn_wave_barrier();
+    DGS_TS(2);  // (col,val) tile staged
     // row-end flag = sign bit of the column id of each live row's last nnz (column ids are < 2^31)
     if (live_i && lane >= a && lane < b) tile[e_i - 1 - s_a].x |= (int)0x80000000;
     __builtin_amdgcn_wave_barrier();
 
     // piece of group g: rows [ra, rb) where boundary(k) = first row r in [a,b] with start_r - s_a >= k*cnt/NG
     int ra, rb;
-    {
+    if constexpr (NG <= 16) {
+      // every lane still holds its row's start: boundary k is the first set bit of one ballot (no LDS round trips)
+      ra = a;
+      rb = b;
+      const bool in_run = lane >= a && lane < b;
+      for (int k = 1; k < NG; k++) {
+        const int tgt = (int)(((long long)k * cnt) / NG);
+        const unsigned long long m = __ballot(in_run && (s_i - s_a) >= tgt);
+        const int bk = m ? (__ffsll((long long)m) - 1) : b;
+        if (g == k) ra = bk;
+        if (g + 1 == k) rb = bk;
+      }
+    } else {
       const int tgt0 = (int)(((long long)g * cnt) / NG), tgt1 = (int)(((long long)(g + 1) * cnt) / NG);
       int lo = a, hi = b;  // first r in [a,b] with rows[r].x - s_a >= tgt0   (rows[b].x >= e_b by CSR monotonicity)
       while (lo < hi) {
@@ -619,6 +648,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
       }
       rb = (g == NG - 1) ? b : lo;
     }
+    DGS_TS(3);  // piece boundaries found
     if (ra < rb) {
       const int ps = rows[ra].x - s_a;
       const int pe = ((rb < b) ? rows[rb].x : e_b) - s_a;
@@ -698,8 +728,10 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
         }
       }
     }
+    DGS_TS(4);  // gather loop of the batch done
     a = b;
   }
+  DGS_TS(5);
 
   // medium rows (T1 < len <= T2): the whole wave reduces one row at a time, result written directly
   unsigned long long med = __ballot(long_i && !huge_i);

@@ -7,6 +7,9 @@ int spmm_run_v4_sum(int G, const SpmmArgs &a) { return dispatch_g<4>(G, a); }
 }  // namespace dgs
 
 using namespace dgs;
+#if DGS_TRACE
+extern "C" void dgs_debug_trace(unsigned long long *buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dgs_trace), &buf, sizeof(buf)); }
+#endif
 
 // Feature tiles as PASSES.  The row-stream schedule maps a row's N floats to one group of up to 64 lanes; wider rows
 // take gridDim.y tiles, and workgroups are dispatched x-fastest, so the tiles of one launch run one after the other.
