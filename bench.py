@@ -15,6 +15,8 @@ GPU, rendezvous on 127.0.0.1); under an existing launcher (WORLD_SIZE set) it ju
 Protocol: W warm-ups + K timed steps between barrier+synchronize (the contract's number); beside it
 the median of 5 repeats of the same K launches between HIP events on the launch stream, a unit-weight run, and seeds
 1..4 of the same generator (extra keys; --no-protocol skips them).
+Before the W warm-ups the step is launched --settle (default 50) more times, untimed and reported as settle_steps: an
+idle MI355X needs ~25 launches before its step time settles (0.404 -> 0.394 ms on the default workload).
 """
 import argparse
 import json
@@ -56,6 +58,8 @@ def parse():
     ap.add_argument('--plan', type=int, default=-1, help='1/0: force the cached locality plan on/off (default: auto)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-protocol', action='store_true', help='skip median-of-5 / unit-weight / seeds 1..4 extras')
+    ap.add_argument('--settle', type=int, default=50, help='untimed launches before the W warm-ups: an idle MI355X needs '
+                    '~25 launches (10 ms) before the step time settles (0.404 -> 0.393 ms); reported as settle_steps')
     ap.add_argument('--no-worst-case', action='store_true', help='N>1: skip the uniform-columns, locality-0 second run')
     ap.add_argument('--force-dist', action='store_true', help='run the partitioned code path even with one rank (testing)')
     ap.add_argument('--sweep', action='store_true', help='also time feat=32/128 and max (extra keys)')
@@ -267,6 +271,9 @@ def main():
         workload = f'synthetic power-law CSR {K}x{K} ({Mloc} rows/GPU, ~{a.deg}/row), cols={a.cols}, ' \
                    f'locality={a.locality}, SpMM-{a.reduce} feat={N}, 1-D row partition + halo all-to-all-v'
 
+    for _ in range(max(0, a.settle)):  # clocks / power state: see --settle; outside the W + K protocol below
+        step()
+    torch.cuda.synchronize()
     wall, ev = time_steps(step, a.steps, a.warmup, pg)
     t = torch.tensor([wall, ev], device=dev, dtype=torch.float64)
     if pg:
@@ -284,6 +291,7 @@ def main():
         'n_gpus': world,
         'steps': a.steps,
         'warmup': a.warmup,
+        'settle_steps': max(0, a.settle),
         'ms_per_step': round(ms, 5),
         'higher_is_better': True,
         'scaling': 'weak',
