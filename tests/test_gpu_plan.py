@@ -260,3 +260,49 @@ def test_accumulating_max_merges_two_column_subsets_exactly(capi, shape):
     torch.cuda.synchronize()
     assert_bitexact(C.cpu().numpy(), Co, 'merged max values')
     assert_bitexact(E.cpu().numpy(), Eo, 'merged arg ids (extended space)')
+
+
+@pytest.mark.parametrize('N', [128, 192])
+def test_wide_rows_run_as_64_float_feature_passes_on_operands_with_2e19_rows(capi, N):
+    """spmm_v4a.hip narrow_tiles: on an operand with >= 2^19 rows, N >= 128 (N % 64 == 0) is run as gridDim.y passes of
+    64-float tiles (G = 16) instead of one 32- or 64-lane group per row.  Same bars as everywhere: max / min values and arg
+    ids bit for bit, sum / mean within the sum bar, with a forced plan and plan-free, values present and absent; the masked
+    (backward) product goes through the same launcher."""
+    K = 1 << 19
+    rp, col, st = graphgen.powerlaw_csr(70000, 900000, K=K, alpha=1.9, dmax=20000, seed=31)
+    assert st['M'] > 65536
+    val = graphgen.weights(col.shape[0], 'tied', 4)
+    X = (np.random.default_rng(5).integers(-3, 4, (K, N)) / 8).astype(np.float32)
+    drp, dcol, dval, dX = dev(rp), dev(col), dev(val), dev(X)
+    assert capi.spmm_schedule(oracle.SUM, st['M'], K, N, col.shape[0]) == 'rows'
+    plan = capi.spmm_plan(drp, dcol, K, N, force=True)
+    assert plan is not None
+    C64 = oracle.spmm_sum_f64(rp, col, val, X)
+    S64 = oracle.spmm_sum_f64(rp, col, val, X, absval=True)
+    lens = np.diff(rp)
+    Emax = None
+    for reduce in ('sum', 'mean', 'max', 'min'):
+        Co, Eo = oracle.spmm(reduce, rp, col, val, X, fma=True)
+        for p in (plan, None):
+            C, E = capi.spmm(oracle.REDUCE[reduce], drp, dcol, dval, dX, plan=p)
+            tag = f'N={N} {reduce} plan={p is not None}'
+            if reduce in ('max', 'min'):
+                assert_bitexact(C.cpu().numpy(), Co, tag)
+                assert_bitexact(E.cpu().numpy(), Eo, tag + ' E')
+            else:
+                sc = 1 if reduce == 'sum' else np.maximum(lens, 1)[:, None]
+                assert_sum_parity(C.cpu().numpy(), Co, C64 / sc, S64 / sc, RTOL, ATOL, tag, lens=lens)
+        if reduce == 'max':
+            Emax = Eo
+    Cn, _ = capi.spmm(oracle.SUM, drp, dcol, None, dX, plan=plan)
+    Co1, _ = oracle.spmm('sum', rp, col, None, X, fma=True)
+    assert_sum_parity(Cn.cpu().numpy(), Co1, oracle.spmm_sum_f64(rp, col, None, X), oracle.spmm_sum_f64(rp, col, None, X, absval=True),
+                      RTOL, ATOL, f'N={N} sum without values', lens=lens)
+    # masked product on the CSC arrays (max backward w.r.t. the dense operand): Mout = K >= 2^19 rows out, operand = grad rows
+    G = (np.random.default_rng(6).integers(-3, 4, (st['M'], N)) / 8).astype(np.float32)
+    colptr, row, tval, _ = oracle.csr2csc(rp, col, val, K)
+    gX = capi.spmm_mask(dev(colptr), dev(row), dev(tval), dev(G), dev(Emax)).cpu().numpy()
+    ref = oracle.spmm_mask(colptr, row, tval, G, Emax, fma=True)
+    assert_sum_parity(gX, ref, oracle.spmm_mask_f64(colptr, row, tval, G, Emax),
+                      oracle.spmm_mask_f64(colptr, row, tval, G, Emax, absval=True), RTOL, ATOL, f'N={N} masked product',
+                      lens=np.diff(colptr))
