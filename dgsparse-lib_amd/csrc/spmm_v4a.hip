@@ -15,7 +15,7 @@ extern "C" void dgs_debug_trace(unsigned long long *buf) { (void)hipMemcpyToSymb
 // take gridDim.y tiles, and workgroups are dispatched x-fastest, so the tiles of one launch run one after the other.
 // On operands that overflow the L2s a NARROWER tile is the better trade: a pass over 64-float (256-byte) slices keeps
 // twice as many rows of the dense operand per XCD as one over 128-float slices, for one more read of (col, val).
-// Measured on the 1M-row power-law graph (plan, sum / max): N = 128: 830 -> 773 us / 1028 -> 973, N = 192: 1327 -> 1153,
+// Crossover at ~250 k columns.  Measured on the 1M-row power-law graph (plan, sum / max): N = 128: 830 -> 773 us / 1028 -> 973, N = 192: 1327 -> 1153,
 // N = 256: 1765 -> 1567 / 2066 -> 1903, N = 512: 3568 -> 3185; two 32-float passes at N = 64 lose (394 -> 434).
 // Mid-size graphs are latency- and issue-bound, more passes cost them: arxiv-shaped N = 128 76 -> 81 us with 64-float
 // tiles, but 128-float tiles win from N = 256 (142 -> 126 us; N = 512: 263 -> 254).  The column-panel schedule keeps
@@ -24,7 +24,7 @@ static FeatMap narrow_tiles(FeatMap fm, const SpmmArgs &a) {
   if (fm.V != 4 || a.N < 128 || !a.ws) return fm;
   if (!a.accumulate && fm.G >= 8 && panel_plan(a, fm.tiles, fm.G).use) return fm;
   int G = 0;
-  if (a.N % 64 == 0 && a.K >= (1 << 19)) G = 16;
+  if (a.N % 64 == 0 && a.K >= (1 << 18)) G = 16;  // crossover measured between 200 k (-2 %) and 300 k (+4 %) columns
   else if (a.N % 128 == 0 && a.N >= 256) G = 32;
   if (!G || G >= fm.G) return fm;
   fm.G = G;

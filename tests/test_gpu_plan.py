@@ -263,8 +263,8 @@ def test_accumulating_max_merges_two_column_subsets_exactly(capi, shape):
 
 
 @pytest.mark.parametrize('N', [128, 192])
-def test_wide_rows_run_as_64_float_feature_passes_on_operands_with_2e19_rows(capi, N):
-    """spmm_v4a.hip narrow_tiles: on an operand with >= 2^19 rows, N >= 128 (N % 64 == 0) is run as gridDim.y passes of
+def test_wide_rows_run_as_64_float_feature_passes_on_large_operands(capi, N):
+    """spmm_v4a.hip narrow_tiles: on an operand with >= 2^18 rows, N >= 128 (N % 64 == 0) is run as gridDim.y passes of
     64-float tiles (G = 16) instead of one 32- or 64-lane group per row.  Same bars as everywhere: max / min values and arg
     ids bit for bit, sum / mean within the sum bar, with a forced plan and plan-free, values present and absent; the masked
     (backward) product goes through the same launcher."""
