@@ -298,6 +298,20 @@ def test_wide_rows_run_as_64_float_feature_passes_on_large_operands(capi, N):
     Co1, _ = oracle.spmm('sum', rp, col, None, X, fma=True)
     assert_sum_parity(Cn.cpu().numpy(), Co1, oracle.spmm_sum_f64(rp, col, None, X), oracle.spmm_sum_f64(rp, col, None, X, absval=True),
                       RTOL, ATOL, f'N={N} sum without values', lens=lens)
+    # the accumulating variants take the same passes
+    C0 = (np.random.default_rng(8).integers(-4, 5, (st['M'], N)) / 4).astype(np.float32)
+    Cacc = dev(C0)
+    capi.spmm_acc(drp, dcol, dval, dX, Cacc, None, plan=plan)
+    live = lens > 0
+    Cs, _ = oracle.spmm('sum', rp, col, val, X, fma=True)
+    assert_sum_parity(Cacc.cpu().numpy()[live].astype(np.float64) - C0[live], Cs[live], C64[live], S64[live] + np.abs(C0[live]),
+                      RTOL, 4e-6, f'N={N} accumulating sum', lens=lens[live])
+    Cm = torch.full((st['M'], N), -1.0, device='cuda')
+    Em = torch.full((st['M'], N), -1, dtype=torch.int32, device='cuda')  # "nothing yet": the product must win everywhere it has entries
+    capi.spmm_acc_max(drp, dcol, dval, dX, Cm, Em, None, col_off=0, n_local=0, h_lo=0, plan=plan)
+    Cx, Ex = oracle.spmm('max', rp, col, val, X, fma=True)
+    assert_bitexact(Cm.cpu().numpy()[live], Cx[live], f'N={N} accumulating max into an empty pair')
+    assert_bitexact(Em.cpu().numpy()[live], Ex[live], f'N={N} accumulating max E')
     # masked product on the CSC arrays (max backward w.r.t. the dense operand): Mout = K >= 2^19 rows out, operand = grad rows
     G = (np.random.default_rng(6).integers(-3, 4, (st['M'], N)) / 8).astype(np.float32)
     colptr, row, tval, _ = oracle.csr2csc(rp, col, val, K)
