@@ -40,6 +40,8 @@ def one_case(rng, it):
     val = graphgen.weights(col.shape[0], kind, it) if kind else None
     X = (rng.integers(-3, 4, (K, N)) / 8).astype(np.float32)
     tag = f'it={it} M={M} K={K} N={N} nnz={col.shape[0]} maxdeg={st["max_deg"]} val={kind}'
+    if os.environ.get('FUZZ_VERBOSE'):
+        print('case', tag, flush=True)
     drp, dcol, dval, dX = dev(rp), dev(col), (None if val is None else dev(val)), dev(X)
     C64 = oracle.spmm_sum_f64(rp, col, val, X)
     S64 = oracle.spmm_sum_f64(rp, col, val, X, absval=True)
