@@ -149,6 +149,9 @@ def cpu_baseline(rp, col, val, X, flops, C_gpu=None):
             max_rel_err_rows_le_64nnz=float(rel[short].max()) if short.any() else 0.0,
             max_rel_err_rows_gt_64nnz=float(rel[~short].max()) if (~short).any() else 0.0,
             longest_row_nnz=int(lens.max()), within_1e_5=bool(rel.max() <= 1e-5))
+        far = rel > 1e-5  # where the two fp32 results differ by more than the bar: which one is off?
+        out['parity'].update(elements_beyond_1e_5=int(far.sum()), elements=int(rel.size),
+                             gpu_closer_to_fp64_on_all_of_them=bool((e_gpu[far] <= e_seq[far]).all()) if far.any() else True)
     nthr = min(os.cpu_count() or 1, oracle.max_threads())
     best = 1e30
     for _ in range(2):
