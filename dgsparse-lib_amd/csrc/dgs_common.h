@@ -28,7 +28,14 @@ __device__ __forceinline__ float reduce_init() {
 // One reduction step of algorithm 0 (include/cuda/spmm_cuda.cuh:37-43 + gspmm.h:16-17 macros, taken
 // literally so that NaN/tie behaviour is identical): t = w*x is ONE fp32 rounding; E takes the column
 // id on a strict improvement, so the first occurrence in CSR order wins ties.
-template <int OP>
+// FMA = false (strict no-contraction mode, DGS_ALG_STRICT_NOFMA): sum/mean as `res + (w * x)` with two roundings - what the
+// reference's host loop computes when g++ compiles it without FMA instructions (example/util/sp_util.hpp:73-83).
+template <bool FMA>
+__device__ __forceinline__ float chain_step(float w, float x, float acc) {
+  if constexpr (FMA) return __builtin_fmaf(w, x, acc);
+  else return __fadd_rn(acc, __fmul_rn(w, x));
+}
+template <int OP, bool FMA = true>
 __device__ __forceinline__ void reduce_step(float &res, int &eidx, float w, float x, int c) {
   if constexpr (OP == DGS_MAX) {
     const float t = w * x;
@@ -39,7 +46,7 @@ __device__ __forceinline__ void reduce_step(float &res, int &eidx, float w, floa
     if (res > t) eidx = c;
     res = (res < t) ? res : t;
   } else {
-    res = __builtin_fmaf(w, x, res);  // v_fmac_f32: the contraction nvcc applies to res + val*x
+    res = chain_step<FMA>(w, x, res);  // FMA: v_fmac_f32, the contraction nvcc applies to res + val*x
   }
 }
 
@@ -134,12 +141,16 @@ __device__ __forceinline__ void load_vec_gather(const float *p, float (&o)[V]) {
   load_vec<V>(p, o);
 #endif
 }
+typedef float dgs_f2 __attribute__((ext_vector_type(2)));
 template <int V>
 __device__ __forceinline__ void store_vec_stream(float *p, const float (&o)[V]) {
 #if DGS_NT
   if constexpr (V == 4) {
     dgs_f4 d = {o[0], o[1], o[2], o[3]};
     __builtin_nontemporal_store(d, reinterpret_cast<dgs_f4 *>(p));
+  } else if constexpr (V == 2) {
+    dgs_f2 d = {o[0], o[1]};
+    __builtin_nontemporal_store(d, reinterpret_cast<dgs_f2 *>(p));
   } else {
     __builtin_nontemporal_store(o[0], p);
   }

@@ -451,6 +451,10 @@ __device__ __forceinline__ void coop_accumulate(int p0, int p1, int lane, int g,
   }
 }
 
+}  // namespace dgs
+#include "spmm_strict.h"
+namespace dgs {
+
 // ---------------------------------------------------------------------------------------------------------
 // K1: short rows.  Per wave: 64 consecutive rows; runs of short rows are staged into LDS as (col | row-end flag,
 // val) pairs; the run's nnz stream is cut into NG nnz-balanced, row-aligned pieces, one per group; each group
@@ -519,13 +523,18 @@ __device__ __forceinline__ void acc_commit(float *__restrict__ C, int *__restric
 
 // ACC (sum only): C[out row] += result instead of C[row] = result, out row = rowmap[row] when a map is given (the
 // halo product of dgsparse.dist adds into the rows that have remote entries); rows without entries are left alone.
-template <int G, int V, int OP, bool HAS_VAL, bool INLINE, bool ACC = false>
+// STRICT (spmm_strict.h; sum / mean only): 0 = default; 1 = every row one sequential fmaf chain; 2 = the same without
+// contraction.  Here it only changes the arithmetic of the (already sequential) short rows and, in the single-launch
+// kernel, sends the long rows through strict_unit instead of the wave-cooperative tree.
+template <int G, int V, int OP, bool HAS_VAL, bool INLINE, bool ACC = false, int STRICT = 0>
 __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, int M, int N,
                                                const int *__restrict__ rowptr,
                                                const int *__restrict__ col, const float *__restrict__ val,
                                                const float *__restrict__ B, float *__restrict__ C,
-                                               int *__restrict__ E, const AccArg aa = AccArg{}) {
+                                               int *__restrict__ E, const AccArg aa = AccArg{},
+                                               float *strict_xb = nullptr) {
   static_assert(!ACC || OP == DGS_SUM || OP == DGS_MAX, "accumulation exists for sum and max");
+  static_assert(STRICT == 0 || ((OP == DGS_SUM || OP == DGS_MEAN) && !ACC), "strict order exists for plain sum and mean");
   const int *rowmap = aa.rowmap;
   constexpr int NG = kWave / G;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
@@ -695,7 +704,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
               if constexpr (OP == kOpMaskSum) {
                 if (mk[u][v] == r0 + cur) acc[v] = __builtin_fmaf(w, x[u][v], acc[v]);
               } else {
-                reduce_step<OP>(acc[v], ei[v], w, x[u][v], c);
+                reduce_step<OP, STRICT != 2>(acc[v], ei[v], w, x[u][v], c);
               }
             }
             if (cvu.x < 0) {  // last nnz of row `cur` (group-uniform)
@@ -739,6 +748,11 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
     const int r = __ffsll((long long)med) - 1;
     med &= med - 1;
     const int rs = __shfl(s_i, r, 64), re = __shfl(e_i, r, 64);
+    if constexpr (STRICT != 0) {
+      strict_unit<V, G, OP == DGS_MEAN, HAS_VAL, STRICT != 2>(r0 + r, rs, re - rs, blockIdx.y * G * V, 0, lane, N, col, val, B,
+                                                             C, strict_xb);
+      continue;
+    }
     float acc[V];
     int ei[V], ep[V], el[V];
 #pragma unroll
@@ -906,6 +920,43 @@ __global__ __launch_bounds__(kBlock) void spmm_small(int M, int N, int rpw, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Strict-order launches (spmm_strict.h): the fused launch with strict unit waves instead of the wave-cooperative tree, and
+// the single-launch kernel with its long rows as whole-tile strict units.  No combine.
+template <int G, int V, int OP, bool HAS_VAL, int STRICT>
+__global__ __launch_bounds__(kBlock, 4) void spmm_fused_strict(int M, int N, int nbu, int rpw, int cap,
+                                                               const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                               const float *__restrict__ val, const float *__restrict__ B,
+                                                               float *__restrict__ C, const SpmmWs *__restrict__ hdr,
+                                                               const int4 *__restrict__ units) {
+  __shared__ union U {
+    RowsLds r;
+    StrictLds s;
+    __device__ U() {}
+  } lds;
+  if ((int)blockIdx.x < nbu) {
+    spmm_units_strict_body<G, V, OP == DGS_MEAN, HAS_VAL, STRICT != 2>(blockIdx.x, nbu, lds.s, N, col, val, B, C, hdr, units, cap);
+  } else {
+    int rb = blockIdx.x - nbu;
+#if DGS_XCD_REMAP
+    const int nbr = gridDim.x - nbu;
+    const int per = nbr / 8;
+    if (rb < per * 8) rb = (rb % 8) * per + rb / 8;
+#endif
+    spmm_rows_body<G, V, OP, HAS_VAL, false, false, STRICT>(rb, rpw, lds.r, M, N, rowptr, col, val, B, C, nullptr);
+  }
+}
+
+template <int G, int V, int OP, bool HAS_VAL, int STRICT>
+__global__ __launch_bounds__(kBlock) void spmm_small_strict(int M, int N, int rpw, const int *__restrict__ rowptr,
+                                                            const int *__restrict__ col, const float *__restrict__ val,
+                                                            const float *__restrict__ B, float *__restrict__ C) {
+  __shared__ RowsLds lds;
+  __shared__ StrictLds sl;
+  spmm_rows_body<G, V, OP, HAS_VAL, true, false, STRICT>(blockIdx.x, rpw, lds, M, N, rowptr, col, val, B, C, nullptr, AccArg{},
+                                                         sl.x[threadIdx.x >> 6]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // K3: one wave per entry of the long-row table folds that row's partial rows in unit order (groups take interleaved
 // units, 4 independent partial loads in flight per lane, then the fixed cross-group tree).
 template <int G, int V, int OP, bool ACC = false>
@@ -1010,6 +1061,9 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
+#ifndef DGS_NBU
+#define DGS_NBU 1024  // persistent unit blocks of the fused launch
+#endif
 struct SpmmArgs {
   int64_t M, K, N, nnz;
   const int *rowptr, *col;
@@ -1163,9 +1217,6 @@ static int launch_impl(const SpmmArgs &a) {
   while (rpw > 8 && a.M / rpw < min_waves) rpw >>= 1;
   const int rows_per_block = (kBlock / kWave) * rpw;
   const int64_t nbr = (a.M + rows_per_block - 1) / rows_per_block;
-#ifndef DGS_NBU
-#define DGS_NBU 1024
-#endif
   if (a.plan) {
     // cached plan: the unit tables already exist (hub rows cut at column-slice boundaries, sorted by slice and first
     // column, one slice per XCD), so the call is fused + combine; the workspace only holds the partial rows
@@ -1215,6 +1266,91 @@ static int launch_impl(const SpmmArgs &a) {
                      a.E, ut, part, parte, a.acc);
   return check_launch();
 }
+
+#if defined(DGS_TU_STRICT)
+// Strict-order sum / mean (spmm_strict.h).  memset + classify_strict + ONE fused launch (no combine); dense graphs keep the
+// column-panel sweep for rows up to tlong nnz (its per-row accumulator is a sequential fmaf chain already) and send only
+// the longer rows through strict unit waves.
+template <int G, int V, int OP, bool HAS_VAL, int STRICT>
+static int launch_strict(const SpmmArgs &a) {
+  static_assert(OP == DGS_SUM || OP == DGS_MEAN, "strict order exists for sum and mean");
+  if (!a.ws) {
+    constexpr int NGc = kWave / G;
+    int rpw = kRowsPerWave;
+    while (rpw > NGc && rpw > 4 && (a.M + rpw - 1) / rpw < 2048) rpw >>= 1;
+    const int rpb = (kBlock / kWave) * rpw;
+    const dim3 grid((unsigned)((a.M + rpb - 1) / rpb), (unsigned)a.tiles);
+    hipLaunchKernelGGL((spmm_small_strict<G, V, OP, HAS_VAL, STRICT>), grid, dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, rpw,
+                       a.rowptr, a.col, a.val, a.B, a.C);
+    return check_launch();
+  }
+  const WsLayout L = ws_layout(a.reduce_op, a.N, a.nnz);
+  char *w = static_cast<char *>(a.ws);
+  SpmmWs *hdr = reinterpret_cast<SpmmWs *>(w);
+  int4 *units = reinterpret_cast<int4 *>(w + L.off_units);
+  const int cap = (int)L.max_units;
+  if (hipMemsetAsync(hdr, 0, sizeof(SpmmWs), a.st) != hipSuccess) return DGS_ELAUNCH;
+  const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
+  const int nbu = DGS_NBU;
+  if constexpr (V == 4 && G >= 8 && STRICT == 1) {
+    const PanelPlan P = panel_plan(a, a.tiles, G);
+    if (P.use) {
+      int tl = P.tlong > kStrictHub ? P.tlong : kStrictHub;
+      if (tl > 65534) tl = 65534;
+      hipLaunchKernelGGL(spmm_classify_strict, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, tl, tl, tl,
+                         strict_smid(G), strict_shub(G), cap, a.rowptr, hdr, units);
+      auto kern = spmm_panel<G, OP, HAS_VAL>;
+      static bool attr_set[64] = {};
+      int dev_id = 0;
+      if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) return DGS_ELAUNCH;
+      if (!attr_set[dev_id]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kPanelLdsBytes) != hipSuccess)
+          return DGS_ELAUNCH;
+        attr_set[dev_id] = true;
+      }
+      for (int64_t fb = 0; fb < a.N; fb += 256) {
+        const int W = (int)(a.N - fb < 256 ? a.N - fb : 256);
+        if (fb && hipMemsetAsync(&hdr->arrivals, 0, sizeof(int), a.st) != hipSuccess) return DGS_ELAUNCH;
+        hipLaunchKernelGGL(kern, dim3((unsigned)P.nwg), dim3(kPanelBlock), P.lds, a.st, (int)a.M, W, (int)a.N, P.R, tl,
+                           P.pcols, P.npanels, P.nsb, P.lead, a.rowptr, a.col, a.val, a.B + fb, a.C + fb,
+                           (int *)nullptr, &hdr->arrivals);
+      }
+      hipLaunchKernelGGL((spmm_fused_strict<G, V, OP, HAS_VAL, STRICT>), dim3((unsigned)nbu, (unsigned)a.tiles), dim3(kBlock),
+                         0, a.st, (int)a.M, (int)a.N, nbu, kRowsPerWave, cap, a.rowptr, a.col, a.val, a.B, a.C, hdr, units);
+      return check_launch();
+    }
+  }
+  int rpw = kRowsPerWave;
+  const int min_waves = env_int("DGS_MIN_WAVES", 8192);
+  while (rpw > 8 && a.M / rpw < min_waves) rpw >>= 1;
+  const int rows_per_block = (kBlock / kWave) * rpw;
+  const int64_t nbr = (a.M + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL(spmm_classify_strict, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, kT1, kStrictMid, kStrictHub,
+                     strict_smid(G), strict_shub(G), cap, a.rowptr, hdr, units);
+  hipLaunchKernelGGL((spmm_fused_strict<G, V, OP, HAS_VAL, STRICT>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles),
+                     dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, nbu, rpw, cap, a.rowptr, a.col, a.val, a.B, a.C, hdr, units);
+  return check_launch();
+}
+
+template <int G, int V, int OP>
+static int dispatch_strict_val(const SpmmArgs &a) {
+  const bool nofma = (a.hints & DGS_ALG_STRICT_NOFMA) != 0;
+  if (a.val) return nofma ? launch_strict<G, V, OP, true, 2>(a) : launch_strict<G, V, OP, true, 1>(a);
+  return launch_strict<G, V, OP, false, 1>(a);  // weight 1: fmaf(1, x, acc) == acc + x, one variant serves both
+}
+template <int V>
+static int dispatch_strict(int G, const SpmmArgs &a) {
+  const bool mean = a.reduce_op == DGS_MEAN;
+  switch (G) {
+#define DGS_STRICT_CASE(g) case g: return mean ? dispatch_strict_val<g, V, DGS_MEAN>(a) : dispatch_strict_val<g, V, DGS_SUM>(a);
+    DGS_STRICT_CASE(1) DGS_STRICT_CASE(2) DGS_STRICT_CASE(4) DGS_STRICT_CASE(8) DGS_STRICT_CASE(16) DGS_STRICT_CASE(32)
+    DGS_STRICT_CASE(64)
+#undef DGS_STRICT_CASE
+  }
+  return DGS_EINVAL;
+}
+#endif  // DGS_TU_STRICT
 
 template <int G, int V, int OP, bool HAS_VAL>
 static int launch_all(const SpmmArgs &a) {
@@ -1269,5 +1405,6 @@ static inline bool tiny_problem(int64_t M, int64_t nnz) { return nnz <= (1 << 18
 int spmm_run_v4_sum(int G, const SpmmArgs &a);  // V=4: sum, mean, masked sum
 int spmm_run_v4_arg(int G, const SpmmArgs &a);  // V=4: max, min
 int spmm_run_v1(int G, const SpmmArgs &a);      // V=1: all ops
+int spmm_run_strict(int G, int V, const SpmmArgs &a);  // strict-order sum / mean (spmm_strict.hip)
 
 }  // namespace dgs

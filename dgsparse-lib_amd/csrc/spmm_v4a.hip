@@ -35,6 +35,9 @@ static FeatMap narrow_tiles(FeatMap fm, const SpmmArgs &a) {
 static int run(FeatMap fm, SpmmArgs a) {
   fm = narrow_tiles(fm, a);
   a.tiles = fm.tiles;
+  if ((a.hints & (DGS_ALG_STRICT_SUM | DGS_ALG_STRICT_NOFMA)) && (a.reduce_op == DGS_SUM || a.reduce_op == DGS_MEAN) &&
+      !a.accumulate && !a.plan)
+    return spmm_run_strict(fm.G, fm.V, a);
   if (fm.V != 4) return spmm_run_v1(fm.G, a);
   return (a.reduce_op == DGS_MAX || a.reduce_op == DGS_MIN) ? spmm_run_v4_arg(fm.G, a) : spmm_run_v4_sum(fm.G, a);
 }

@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_HERE, 'libdgsparse_hip.so')
 
 SUM, MAX, MIN, MEAN = 0, 1, 2, 3  # include/gspmm.h:13 in the reference
 ALG_SHARED_GPU = 0x100  # `algorithm` hint bit: the GPU is shared with concurrently running kernels
+ALG_STRICT_SUM = 0x200  # sum / mean: one sequential fmaf chain per (row, feature) in CSR order, whatever the row length
+ALG_STRICT_NOFMA = 0x400  # ... with the product rounded before the add (= the reference's host loop under g++)
 
 if not os.path.exists(LIB_PATH):  # mirrors dgsparse/__init__.py:25 in the reference (ImportError, no fallback)
     raise ImportError(f"Could not find the HIP kernel library '{LIB_PATH}'. Build it with "
@@ -261,7 +263,8 @@ def spmm(reduce_op, rowptr, col, values, dense, algorithm=0, want_E=None, plan=N
                              plan.rowptr_ptr != rowptr.data_ptr()):
         raise ValueError('dgsparse: the plan was built for other (rowptr, col) arrays')
     with _on_device(dev):
-        if plan is not None and _lib.dgs_spmm_csr_schedule(int(reduce_op), M, K, N, nnz) == 1:
+        strict = (int(algorithm) & (ALG_STRICT_SUM | ALG_STRICT_NOFMA)) and reduce_op in (SUM, MEAN)
+        if plan is not None and not strict and _lib.dgs_spmm_csr_schedule(int(reduce_op), M, K, N, nnz) == 1:
             wsb = _lib.dgs_spmm_csr_plan_workspace_bytes(reduce_op, M, N, nnz, ctypes.byref(plan.info))
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             _check(_lib.dgs_spmm_csr_plan_f32(reduce_op, M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(dense),

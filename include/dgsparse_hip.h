@@ -59,8 +59,18 @@ const char *dgs_strerror(int code);
  *     DGS_ALG_SHARED_GPU  other kernels run concurrently on this GPU (e.g. an overlapped RCCL collective): do not take
  *                         the column-panel sweep, whose soft barrier assumes one workgroup per CU, all co-resident
  *                         (correct but several times slower when CUs are taken away).
+ *     DGS_ALG_STRICT_SUM  sum / mean: every (row, feature) is ONE sequential fmaf chain in CSR order whatever the row length -
+ *                         literally algorithm 0 (include/cuda/spmm_cuda.cuh:27-47 as nvcc contracts it), bit-exact for every
+ *                         row; long rows are spread over waves by FEATURE slices instead of being cut.
+ *                         Slower than the default on graphs with hub rows (a 50 k-nnz row is a 50 k-step dependent chain).
+ *     DGS_ALG_STRICT_NOFMA  the same with the product rounded before the add (res + (w*x), no contraction): bit-exact
+ *                         against the reference's host loop spmm_reference_host (example/util/sp_util.hpp:73-83) as g++
+ *                         compiles it.  Never takes the column-panel sweep.  Implies strict order.
+ *   The strict bits are ignored by max / min (always exact) and by the accumulating entries.
  */
 #define DGS_ALG_SHARED_GPU 0x100
+#define DGS_ALG_STRICT_SUM 0x200
+#define DGS_ALG_STRICT_NOFMA 0x400
 size_t dgs_spmm_csr_workspace_bytes(int reduce_op, int64_t M, int64_t N, int64_t nnz);
 int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz,
                      const int32_t *rowptr, const int32_t *col, const float *val, const float *B,

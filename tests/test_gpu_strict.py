@@ -1,0 +1,141 @@
+"""Strict-order sum / mean (DGS_ALG_STRICT_SUM / DGS_ALG_STRICT_NOFMA): every (row, feature) is ONE sequential chain in
+CSR order, i.e. literally algorithm 0 (/root/reference/include/cuda/spmm_cuda.cuh:27-47; host twin
+example/util/sp_util.hpp:73-83).  Bar: BIT-EXACT against the oracle's sequential chain for every row length and every
+feature mapping - fmaf chain for STRICT_SUM, separately rounded multiply and add for STRICT_NOFMA (the latter is also
+what the reference's own compiled host loop, oracle/_ref, produces)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from bench import graphgen
+from util import assert_bitexact
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def capi():
+    from dgsparse import _capi
+    return _capi
+
+
+def run(capi, op, rp, col, val, X, alg):
+    d = 'cuda'
+    C, _ = capi.spmm({'sum': capi.SUM, 'mean': capi.MEAN}[op], torch.from_numpy(rp).to(d), torch.from_numpy(col).to(d),
+                     None if val is None else torch.from_numpy(val).to(d), torch.from_numpy(X).to(d), algorithm=alg)
+    return C.cpu().numpy()
+
+
+def hub_graph(M=24000, nnz=700000, dmax=20000, seed=3, cols='powerlaw'):
+    rp, col, st = graphgen.powerlaw_csr(M, nnz, alpha=1.9, dmax=dmax, seed=seed, cols=cols)
+    deg = np.diff(rp)
+    # every row class of the strict schedule must be present: short, whole-tile units, 4-slice units, hub units
+    assert (deg <= 64).any() and ((deg > 64) & (deg <= 256)).any() and ((deg > 256) & (deg <= 2048)).any() and (deg > 2048).any()
+    return rp, col, st
+
+
+@pytest.mark.parametrize('N', [1, 3, 4, 8, 16, 20, 32, 33, 64, 128, 256, 384])
+@pytest.mark.parametrize('mode', ['fma', 'nofma'])
+def test_strict_sum_bitexact_every_feature_mapping(capi, N, mode):
+    rp, col, st = hub_graph()
+    val = graphgen.weights(col.shape[0], 'signed', 5)
+    X = graphgen.features(st['K'], N, 6) - 0.3
+    alg = capi.ALG_STRICT_SUM if mode == 'fma' else capi.ALG_STRICT_NOFMA
+    C = run(capi, 'sum', rp, col, val, X, alg)
+    ref, _ = oracle.spmm('sum', rp, col, val, X, fma=(mode == 'fma'), threads=oracle.max_threads())
+    assert_bitexact(C, ref, f'strict sum N={N} {mode}')
+
+
+@pytest.mark.parametrize('op,has_val', [('mean', True), ('sum', False), ('mean', False)])
+@pytest.mark.parametrize('N', [32, 64, 100])
+def test_strict_mean_and_unit_weights(capi, op, has_val, N):
+    rp, col, st = hub_graph(seed=4)
+    val = graphgen.weights(col.shape[0], 'uniform', 7) if has_val else None
+    X = graphgen.features(st['K'], N, 8)
+    for alg, fma in ((capi.ALG_STRICT_SUM, True), (capi.ALG_STRICT_NOFMA, False)):
+        C = run(capi, op, rp, col, val, X, alg)
+        ref, _ = oracle.spmm(op, rp, col, val, X, fma=fma, threads=oracle.max_threads())
+        assert_bitexact(C, ref, f'strict {op} N={N} val={has_val} fma={fma}')
+
+
+def test_strict_matches_the_reference_host_loop(capi):
+    """NOFMA mode against the reference's own spmm_reference_host compiled by g++ (oracle/_ref), all rows."""
+    if not oracle.have_ref():
+        pytest.skip('oracle/_ref not built')
+    rp, col, st = hub_graph(seed=9)
+    val = graphgen.weights(col.shape[0], 'uniform', 1)
+    X = graphgen.features(st['K'], 64, 2)
+    C = run(capi, 'sum', rp, col, val, X, capi.ALG_STRICT_NOFMA)
+    assert_bitexact(C, oracle.ref_spmm_sum(rp, col, val, X), 'strict nofma vs spmm_reference_host')
+
+
+def test_strict_small_single_launch_path(capi):
+    """Inputs that take the single-launch schedule: long rows are whole-tile strict units inside the row blocks."""
+    rp, col, st = graphgen.powerlaw_csr(3000, 60000, alpha=1.8, dmax=2500, seed=11)
+    assert np.diff(rp).max() > 1000
+    val = graphgen.weights(col.shape[0], 'signed', 2)
+    for N in (4, 16, 64, 65, 128):
+        X = graphgen.features(st['K'], N, 3) - 0.5
+        for op in ('sum', 'mean'):
+            for alg, fma in ((capi.ALG_STRICT_SUM, True), (capi.ALG_STRICT_NOFMA, False)):
+                C = run(capi, op, rp, col, val, X, alg)
+                ref, _ = oracle.spmm(op, rp, col, val, X, fma=fma)
+                assert_bitexact(C, ref, f'strict small {op} N={N} fma={fma}')
+
+
+def test_strict_on_the_column_panel_schedule(capi):
+    """Dense graph forced onto the column-panel sweep: rows up to tlong are sequential fmaf chains there already, the
+    longer ones go through strict unit waves (no combine)."""
+    rp, col, st = graphgen.powerlaw_csr(9000, 2_400_000, alpha=2.6, dmax=8000, seed=5)
+    val = graphgen.weights(col.shape[0], 'uniform', 3)
+    X = graphgen.features(st['K'], 64, 4)
+    old = {k: os.environ.get(k) for k in ('DGS_PANEL', 'DGS_PANEL_TLONG')}
+    os.environ['DGS_PANEL'] = '1'
+    os.environ['DGS_PANEL_TLONG'] = '2500'
+    try:
+        assert np.diff(rp).max() > 2500
+        C = run(capi, 'sum', rp, col, val, X, capi.ALG_STRICT_SUM)
+        Cn = run(capi, 'mean', rp, col, val, X, capi.ALG_STRICT_NOFMA)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    ref, _ = oracle.spmm('sum', rp, col, val, X, fma=True, threads=oracle.max_threads())
+    assert_bitexact(C, ref, 'strict sum on the panel schedule')
+    refn, _ = oracle.spmm('mean', rp, col, val, X, fma=False, threads=oracle.max_threads())
+    assert_bitexact(Cn, refn, 'strict nofma mean (never the panel schedule)')
+
+
+def test_strict_is_deterministic_and_ignored_by_max(capi):
+    rp, col, st = hub_graph(seed=12)
+    val = graphgen.weights(col.shape[0], 'tied', 1)
+    X = graphgen.features(st['K'], 64, 2)
+    a = run(capi, 'sum', rp, col, val, X, capi.ALG_STRICT_SUM)
+    b = run(capi, 'sum', rp, col, val, X, capi.ALG_STRICT_SUM)
+    assert_bitexact(a, b, 'strict run to run')
+    d = 'cuda'
+    args = (torch.from_numpy(rp).to(d), torch.from_numpy(col).to(d), torch.from_numpy(val).to(d), torch.from_numpy(X).to(d))
+    C0, E0 = capi.spmm(capi.MAX, *args)
+    C1, E1 = capi.spmm(capi.MAX, *args, algorithm=capi.ALG_STRICT_SUM)
+    assert torch.equal(C0, C1) and torch.equal(E0, E1)
+
+
+@pytest.mark.parametrize('N', [64, 128])
+def test_strict_headline_graph_all_rows(capi, N):
+    """The bench workload at full size (2^20 rows, ~16 nnz/row, max degree ~5e4): EVERY element bit-exact against the
+    sequential chain, so parity.within_1e_5 of `bench.py --strict` is true by construction."""
+    rp, col, st = graphgen.dataset_shaped('synth1m', seed=0, device='cuda', as_torch=True)
+    g = torch.Generator(device='cuda')
+    g.manual_seed(1)
+    val = torch.rand(st['nnz'], generator=g, device='cuda')
+    X = torch.rand((st['K'], N), generator=g, device='cuda')
+    rpc, colc, valc, Xc = rp.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy(), X.cpu().numpy()
+    for alg, fma in ((capi.ALG_STRICT_SUM, True), (capi.ALG_STRICT_NOFMA, False)):
+        C, _ = capi.spmm(capi.SUM, rp, col, val, X, algorithm=alg)
+        ref, _ = oracle.spmm('sum', rpc, colc, valc, Xc, fma=fma, threads=oracle.max_threads())
+        assert_bitexact(C.cpu().numpy(), ref, f'headline graph strict fma={fma} N={N}')
