@@ -56,6 +56,10 @@ def parse():
     ap.add_argument('--ncols', type=int, default=0, help='columns of A / rows of the dense operand (0 = square)')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--plan', type=int, default=-1, help='1/0: force the cached locality plan on/off (default: auto)')
+    ap.add_argument('--strict', default='', choices=['', 'fma', 'nofma'],
+                    help='time the strict-order schedule (DGS_ALG_STRICT_SUM / _NOFMA: every row one sequential chain, '
+                         'bit-exact against the sequential reference) instead of the default one; without the flag the '
+                         'strict schedule is still measured and checked beside the headline (key "strict")')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-protocol', action='store_true', help='skip median-of-5 / unit-weight / seeds 1..4 extras')
     ap.add_argument('--settle', type=int, default=50, help='untimed launches before the W warm-ups: an idle MI355X needs '
@@ -114,7 +118,7 @@ def event_ms(fn, steps):
     return ev0.elapsed_time(ev1) / steps
 
 
-def cpu_baseline(rp, col, val, X, flops, C_gpu=None):
+def cpu_baseline(rp, col, val, X, flops, C_gpu=None, C_strict=None):
     """The reference's own single-threaded CPU loop (oracle/_ref: spmm_reference_host, sp_util.hpp:63-84) when it
     was built, else the C restatement; plus the OpenMP restatement on all host cores.  Bounded: one pass each.
     The pass also yields the sequential fp32 result of EVERY row, so the GPU result of the timed tensors is compared
@@ -152,6 +156,21 @@ def cpu_baseline(rp, col, val, X, flops, C_gpu=None):
         far = rel > 1e-5  # where the two fp32 results differ by more than the bar: which one is off?
         out['parity'].update(elements_beyond_1e_5=int(far.sum()), elements=int(rel.size),
                              gpu_closer_to_fp64_on_all_of_them=bool((e_gpu[far] <= e_seq[far]).all()) if far.any() else True)
+    if C_strict and Cseq is not None:
+        # the strict-order schedule against the same sequential results: NOFMA is the reference's host loop bit for bit
+        # (g++ emits no fused multiply-add for it), FMA is the reference kernel's contraction (checked against the oracle's
+        # fmaf chain)
+        Cseq = np.asarray(Cseq).reshape(M, -1)
+        ps = {}
+        for mode, Cg in C_strict.items():
+            seq = Cseq if mode == 'nofma' else oracle.spmm('sum', rp, col, val, X, fma=True, threads=min(os.cpu_count() or 1, oracle.max_threads()))[0]
+            rel = np.abs(Cg.astype(np.float64) - Cseq) / np.maximum(np.abs(Cseq), 1e-6)
+            ps[mode] = dict(bit_exact_vs_its_sequential_chain=bool(np.array_equal(Cg.view(np.int32), np.asarray(seq).view(np.int32))),
+                            chain=('reference spmm_reference_host (mul, add)' if mode == 'nofma' and kind == 'reference' else
+                                   'oracle sequential ' + ('fmaf' if mode == 'fma' else 'mul, add')),
+                            max_rel_err_vs_sequential_reference=float(rel.max()), within_1e_5=bool(rel.max() <= 1e-5),
+                            elements_beyond_1e_5=int((rel > 1e-5).sum()), rows_checked=int(M))
+        out['parity_strict'] = ps
     nthr = min(os.cpu_count() or 1, oracle.max_threads())
     best = 1e30
     for _ in range(2):
@@ -205,10 +224,14 @@ def main():
         X_ = torch.rand((st_['K'], N), generator=g_, device=dev)
         return rp_, col_, st_, val_, X_
 
+    strict_alg = {'': 0, 'fma': _capi.ALG_STRICT_SUM, 'nofma': _capi.ALG_STRICT_NOFMA}[a.strict]
+
     def make_step(rp_, col_, val_, X_):
         """One SpMM through the C ABI; with a plan (Storage-cached locality plan, built once outside the timed region)
         when the library offers one for this shape."""
         plan = None
+        if strict_alg:
+            return (lambda: _capi.spmm(op, rp_, col_, val_, X_, algorithm=strict_alg)), False
         if a.plan != 0 and hasattr(_capi, 'spmm_plan'):
             plan = _capi.spmm_plan(rp_, col_, X_.shape[0], N, force=(a.plan == 1))
         if plan is not None:
@@ -250,7 +273,8 @@ def main():
         parallelism = 'single'
         workload = f'synthetic power-law CSR {Mloc}x{K}, nnz={nnz_total} (~{nnz_total / Mloc:.1f}/row, alpha={a.alpha}, ' \
                    f'max_deg={st["max_deg"]}), cols={a.cols}, SpMM-{a.reduce} feat={N}, fp32 values'
-        extra['schedule'] = _capi.spmm_schedule(op, Mloc, K, N, nnz_total) + ('+plan' if planned else '')
+        extra['schedule'] = _capi.spmm_schedule(op, Mloc, K, N, nnz_total) + ('+plan' if planned else '') + \
+            (f'+strict-{a.strict}' if strict_alg else '')
     else:
         from dgsparse import dist as ddist
         part = ddist.synthetic_partition(rank, world, Mloc, a.deg, cols=a.cols, locality=a.locality, seed=a.seed,
@@ -345,6 +369,56 @@ def main():
         prot['seeds'] = seeds
         res['protocol'] = prot
 
+    C_strict = {}
+    if not a.no_protocol and not use_dist:
+        # what the plan costs and what it buys: blocking C-ABI build incl. compaction, and the plan-free step
+        if planned:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _capi.spmm_plan(rp, col, K, N, force=(a.plan == 1))
+            torch.cuda.synchronize()
+            pfree = sorted(event_ms(lambda: _capi.spmm(op, rp, col, val, X), max(10, a.steps // 5)) for _ in range(3))[1]
+            res['plan'] = dict(build_ms_blocking=round((time.perf_counter() - t0) * 1e3, 3), planfree_ms_per_step=round(pfree, 5),
+                               planned_ms_per_step=res['protocol']['median_ms'],
+                               calls_to_break_even_blocking=round((time.perf_counter() - t0) * 1e3 / max(pfree - res['protocol']['median_ms'], 1e-6), 1),
+                               note='dgsparse.Storage builds it on a side stream from the 4th use of a matrix on (DGS_PLAN_AFTER), never blocking')
+        # the strict-order schedule on the same tensors (opt-in `algorithm` bits): time + full parity in cpu_baseline
+        if a.reduce in ('sum', 'mean'):
+            sd = {}
+            for mode, alg in (('fma', _capi.ALG_STRICT_SUM), ('nofma', _capi.ALG_STRICT_NOFMA)):
+                fn = (lambda alg=alg: _capi.spmm(op, rp, col, val, X, algorithm=alg))
+                Cs, _ = fn()
+                if a.reduce == 'sum' and not a.no_cpu_baseline:
+                    C_strict[mode] = Cs.cpu().numpy()
+                del Cs
+                ms_s = sorted(event_ms(fn, max(10, a.steps // 5)) for _ in range(3))[1]
+                sd[mode] = dict(ms_per_step=round(ms_s, 5), gflops=round(flops / (ms_s / 1e3) / 1e9, 1),
+                                frac=round(b_alg / (ms_s / 1e3) / 1e9 / HBM_PEAK_GBS, 4))
+            sd['algorithm_bits'] = dict(fma=hex(_capi.ALG_STRICT_SUM), nofma=hex(_capi.ALG_STRICT_NOFMA))
+            res['strict'] = sd
+        # the PUBLIC operator on the same graph (reference harness times this: benchmark/bench_spmm_time.py:35-45)
+        try:
+            fnp = {'sum': dgsparse.spmm_sum, 'mean': dgsparse.spmm_mean, 'max': dgsparse.spmm_max, 'min': dgsparse.spmm_min}[a.reduce]
+            A_pub = dgsparse.SparseTensor(rowptr=rp, col=col, values=val, has_value=True)
+            A_pub.storage.spmm_plan('csr', N, wait=True)
+            A_pub.storage.spmm_plan('csc', N, wait=True)
+            with torch.no_grad():
+                fnp(A_pub, X, 0)
+                pub_ng = sorted(event_ms(lambda: fnp(A_pub, X, 0), max(10, a.steps // 5)) for _ in range(3))[1]
+            Xg = X.clone().requires_grad_()
+
+            def fb():
+                o = fnp(A_pub, Xg, 0)
+                o.backward(o)
+                Xg.grad = None
+            fb()
+            pub_fb = sorted(event_ms(fb, max(5, a.steps // 10)) for _ in range(3))[1]
+            res['public_api_ms'] = dict(op=f'dgsparse.spmm_{a.reduce}', no_grad=round(pub_ng, 5), fwd_bwd_dense_grad=round(pub_fb, 5),
+                                        c_abi_step=res['protocol']['median_ms'])
+            del A_pub, Xg
+        except Exception as e:  # noqa: BLE001
+            res['public_api_ms'] = dict(error=repr(e))
+
     if pg and use_dist and not a.no_worst_case:
         # the same step on the exchange's worst case: uniform random columns, no locality (every edge leaves its
         # partition with probability (N-1)/N); extra keys, not the metric - and never allowed to lose the line above
@@ -395,7 +469,16 @@ def main():
                 workload=f"Reddit-shaped {st3['M']}x{st3['K']}, nnz {st3['nnz']}, feat 128, sum",
                 schedule=_capi.spmm_schedule(_capi.SUM, st3['M'], st3['K'], 128, st3['nnz']),
                 ms_per_step=round(w3 / 10 * 1e3, 4), gflops=round(2.0 * st3['nnz'] * 128 / (w3 / 10) / 1e9, 1),
-                alg_gbs=round(b3 / (e3 / 10) / 1e9, 1), frac=round(b3 / (e3 / 10) / 1e9 / HBM_PEAK_GBS, 4))
+                alg_gbs=round(b3 / (e3 / 10) / 1e9, 1), frac=round(b3 / (e3 / 10) / 1e9 / HBM_PEAK_GBS, 4),
+                alg_bytes_per_launch=int(b3))
+            try:
+                tj3 = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
+                if 'C3_sum_feat128_panel' in tj3:
+                    res['dense_graph']['traffic'] = tj3['C3_sum_feat128_panel']
+                    res['dense_graph']['traffic_source'] = 'profiles/hbm_traffic.json[C3_sum_feat128_panel] <- ' + \
+                        tj3.get('_source', {}).get('C3_sum_feat128_panel', 'see profiles/README.md')
+            except Exception:
+                pass
             del rp3, col3, val3, X3
         except Exception as e:
             res['dense_graph'] = dict(error=str(e))
@@ -403,7 +486,7 @@ def main():
     if rank == 0 and not use_dist and not a.no_cpu_baseline:
         try:
             res.update(cpu_baseline(rp.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy(), X.cpu().numpy(), flops,
-                                    C_check))
+                                    C_check, C_strict))
         except Exception as e:  # the baseline is a reported side figure; never lose the GPU line over it
             res['cpu_baseline'] = dict(value=None, unit='GFLOP/s', cores=0, kind='port', sample=f'failed: {e}')
     if rank == 0:

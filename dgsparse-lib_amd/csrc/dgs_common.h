@@ -32,8 +32,14 @@ __device__ __forceinline__ float reduce_init() {
 // reference's host loop computes when g++ compiles it without FMA instructions (example/util/sp_util.hpp:73-83).
 template <bool FMA>
 __device__ __forceinline__ float chain_step(float w, float x, float acc) {
-  if constexpr (FMA) return __builtin_fmaf(w, x, acc);
-  else return __fadd_rn(acc, __fmul_rn(w, x));
+  if constexpr (FMA) {
+    return __builtin_fmaf(w, x, acc);
+  } else {
+    // HIP's __fmul_rn / __fadd_rn are plain operators, which hipcc (-ffp-contract=fast-honor-pragmas) would fuse again
+#pragma clang fp contract(off)
+    const float t = w * x;
+    return acc + t;
+  }
 }
 template <int OP, bool FMA = true>
 __device__ __forceinline__ void reduce_step(float &res, int &eidx, float w, float x, int c) {

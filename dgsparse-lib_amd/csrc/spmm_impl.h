@@ -96,6 +96,7 @@ struct SpmmWs {       // workspace header (zeroed every call with one 16-byte me
   int n_pslots;       // partial-row slots handed out (multi-unit rows only)
   int arrivals;       // spmm_panel: panel steps finished, summed over workgroups (soft barrier)
   int n_long;         // K0 -> K2: number of multi-unit rows (entries of the long-row table)
+  int hub[8];         // strict schedule: units per length class of the hub rows (spmm_strict.h)
 };
 
 // Unit tables, as the kernels see them.  Two producers: spmm_classify (plan-free call: tables in the workspace, rebuilt
@@ -128,7 +129,9 @@ static inline WsLayout ws_layout(int reduce_op, int64_t N, int64_t nnz) {
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
   WsLayout L;
   L.ch = unit_len(nnz);
-  L.max_units = nnz / kT2 + nnz / L.ch + 2;          // sum over long rows of ceil(len/ch) <= nnz/ch + #long rows
+  // sum over long rows of ceil(len/ch) <= nnz/ch + #long rows; the strict schedule (spmm_strict.h) keeps its hub-row units
+  // in per-class regions behind nnz/kT1 + 2 front entries: another nnz/64 + 128 at most
+  L.max_units = 2 * (nnz / kT2) + nnz / L.ch + 160;
   L.max_pslots = 2 * (nnz / L.ch) + 2;               // same sum over rows longer than ch only (they need partials)
   L.max_long = nnz / L.ch + 2;                       // rows longer than ch
   L.off_units = up(sizeof(SpmmWs));
@@ -923,7 +926,7 @@ __global__ __launch_bounds__(kBlock) void spmm_small(int M, int N, int rpw, cons
 // Strict-order launches (spmm_strict.h): the fused launch with strict unit waves instead of the wave-cooperative tree, and
 // the single-launch kernel with its long rows as whole-tile strict units.  No combine.
 template <int G, int V, int OP, bool HAS_VAL, int STRICT>
-__global__ __launch_bounds__(kBlock, 4) void spmm_fused_strict(int M, int N, int nbu, int rpw, int cap,
+__global__ __launch_bounds__(kBlock, 4) void spmm_fused_strict(int M, int N, int nbu, int rpw, const HubTab ht,
                                                                const int *__restrict__ rowptr, const int *__restrict__ col,
                                                                const float *__restrict__ val, const float *__restrict__ B,
                                                                float *__restrict__ C, const SpmmWs *__restrict__ hdr,
@@ -934,7 +937,7 @@ __global__ __launch_bounds__(kBlock, 4) void spmm_fused_strict(int M, int N, int
     __device__ U() {}
   } lds;
   if ((int)blockIdx.x < nbu) {
-    spmm_units_strict_body<G, V, OP == DGS_MEAN, HAS_VAL, STRICT != 2>(blockIdx.x, nbu, lds.s, N, col, val, B, C, hdr, units, cap);
+    spmm_units_strict_body<G, V, OP == DGS_MEAN, HAS_VAL, STRICT != 2>(blockIdx.x, nbu, lds.s, N, col, val, B, C, hdr, units, ht);
   } else {
     int rb = blockIdx.x - nbu;
 #if DGS_XCD_REMAP
@@ -1288,17 +1291,24 @@ static int launch_strict(const SpmmArgs &a) {
   char *w = static_cast<char *>(a.ws);
   SpmmWs *hdr = reinterpret_cast<SpmmWs *>(w);
   int4 *units = reinterpret_cast<int4 *>(w + L.off_units);
-  const int cap = (int)L.max_units;
+  // (DGS_STRICT_MID / _HUB: experiment overrides of the slicing thresholds; the table capacities assume hub >= kStrictHub)
+  int tmid = env_int("DGS_STRICT_MID", kStrictMid), thub = env_int("DGS_STRICT_HUB", kStrictHub);
+  if (thub < kStrictHub) thub = kStrictHub;
+  if (tmid < kStrictMid) tmid = kStrictMid;
+  if (tmid > thub) tmid = thub;
   if (hipMemsetAsync(hdr, 0, sizeof(SpmmWs), a.st) != hipSuccess) return DGS_ELAUNCH;
   const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
-  const int nbu = DGS_NBU;
+  // unit blocks: the kernel runs 4 workgroups per CU (LDS); two of them for the units leaves two for the row blocks, which
+  // would otherwise only start when the last unit block has drained
+  const int nbu = (env_int("DGS_STRICT_NBU", 2 * cu_count()) + 7) & ~7;  // a multiple of 8: one share per XCD
   if constexpr (V == 4 && G >= 8 && STRICT == 1) {
     const PanelPlan P = panel_plan(a, a.tiles, G);
     if (P.use) {
       int tl = P.tlong > kStrictHub ? P.tlong : kStrictHub;
       if (tl > 65534) tl = 65534;
+      const HubTab ht = hub_tab(a.nnz, strict_shub(G), tl);
       hipLaunchKernelGGL(spmm_classify_strict, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, tl, tl, tl,
-                         strict_smid(G), strict_shub(G), cap, a.rowptr, hdr, units);
+                         strict_smid(G), strict_shub(G), ht, a.rowptr, hdr, units);
       auto kern = spmm_panel<G, OP, HAS_VAL>;
       static bool attr_set[64] = {};
       int dev_id = 0;
@@ -1317,7 +1327,7 @@ static int launch_strict(const SpmmArgs &a) {
                            (int *)nullptr, &hdr->arrivals);
       }
       hipLaunchKernelGGL((spmm_fused_strict<G, V, OP, HAS_VAL, STRICT>), dim3((unsigned)nbu, (unsigned)a.tiles), dim3(kBlock),
-                         0, a.st, (int)a.M, (int)a.N, nbu, kRowsPerWave, cap, a.rowptr, a.col, a.val, a.B, a.C, hdr, units);
+                         0, a.st, (int)a.M, (int)a.N, nbu, kRowsPerWave, ht, a.rowptr, a.col, a.val, a.B, a.C, hdr, units);
       return check_launch();
     }
   }
@@ -1326,10 +1336,11 @@ static int launch_strict(const SpmmArgs &a) {
   while (rpw > 8 && a.M / rpw < min_waves) rpw >>= 1;
   const int rows_per_block = (kBlock / kWave) * rpw;
   const int64_t nbr = (a.M + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL(spmm_classify_strict, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, kT1, kStrictMid, kStrictHub,
-                     strict_smid(G), strict_shub(G), cap, a.rowptr, hdr, units);
+  const HubTab ht = hub_tab(a.nnz, strict_shub(G), thub);
+  hipLaunchKernelGGL(spmm_classify_strict, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, kT1, tmid, thub,
+                     strict_smid(G), strict_shub(G), ht, a.rowptr, hdr, units);
   hipLaunchKernelGGL((spmm_fused_strict<G, V, OP, HAS_VAL, STRICT>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles),
-                     dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, nbu, rpw, cap, a.rowptr, a.col, a.val, a.B, a.C, hdr, units);
+                     dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, nbu, rpw, ht, a.rowptr, a.col, a.val, a.B, a.C, hdr, units);
   return check_launch();
 }
 

@@ -23,6 +23,9 @@
 
 namespace dgs {
 
+// the plan lists rows longer than kT1 as units while the fused kernel hands rows to the unit table from kT2: one threshold
+static_assert(kT1 == kT2, "spmm_plan.hip assumes DGS_T2 == DGS_T1 (rows in (T1, T2] would be computed twice)");
+
 struct PlanWs {  // build-time counters (zeroed by the first memset)
   int n_longlist;
   int pad[3];
@@ -67,9 +70,12 @@ static PlanWsLayout plan_ws_layout(int64_t K, int64_t nnz) {
 }
 
 // ---- kernels ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void plan_hist(int nnz, const int *__restrict__ col, int *__restrict__ cnt) {
+__global__ __launch_bounds__(kBlock) void plan_hist(int nnz, int K, const int *__restrict__ col, int *__restrict__ cnt) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  for (int p = i; p < nnz; p += gridDim.x * kBlock) atomicAdd(&cnt[col[p]], 1);
+  for (int p = i; p < nnz; p += gridDim.x * kBlock) {
+    const int c = col[p];
+    if ((unsigned)c < (unsigned)K) atomicAdd(&cnt[c], 1);  // a bad column id must not become an out-of-bounds WRITE
+  }
 }
 
 // Column grid: kPlanCells cells with equal reference counts; bounds[c] = first column with (references to columns
@@ -337,7 +343,7 @@ extern "C" int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int3
   if (hipMemsetAsync(keys_in, 0xFF, (size_t)PL.max_units * 8, st) != hipSuccess) return DGS_ELAUNCH;  // unused = last
   if (hipMemsetAsync(units_in, 0, (size_t)PL.max_units * 16, st) != hipSuccess) return DGS_ELAUNCH;
 
-  hipLaunchKernelGGL(plan_hist, dim3(2048), dim3(kBlock), 0, st, (int)nnz, col, cnt);
+  hipLaunchKernelGGL(plan_hist, dim3(2048), dim3(kBlock), 0, st, (int)nnz, (int)K, col, cnt);
   size_t tb = WL.tmp_bytes;
   if (rocprim::exclusive_scan(tmp, tb, cnt, cum, 0, (size_t)(K + 1), rocprim::plus<int>(), st, false) != hipSuccess)
     return DGS_ELAUNCH;
@@ -375,6 +381,25 @@ extern "C" int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int3
   return DGS_OK;
 }
 
+// The counts of a finished build from a HOST copy of the plan buffer's first 256 bytes (the device-resident header).  Lets a
+// caller build without the blocking copy: dgs_spmm_plan_build(..., info = NULL, stream), an async copy of the header into
+// pinned memory behind it, an event - and this call once the event has completed.
+extern "C" int dgs_spmm_plan_info_from_header(const void *host_header, size_t bytes, dgsSpmmPlanInfo *info) {
+  if (!host_header || !info || bytes < sizeof(PlanHdr)) return DGS_EINVAL;
+  PlanHdr h;
+  memcpy(&h, host_header, sizeof(PlanHdr));
+  if (h.magic != kPlanMagic) return DGS_EINVAL;
+  info->n_units = h.n_units;
+  info->n_long = h.n_long;
+  info->n_pslots = h.n_pslots;
+  info->has_pcol = 0;
+  info->tslice = h.tslice;
+  info->off_long = 0;
+  info->reserved = 0;
+  for (int x = 0; x < 9; x++) info->xcd_start[x] = h.xcd_start[x];
+  return DGS_OK;
+}
+
 extern "C" size_t dgs_spmm_csr_plan_workspace_bytes(int reduce_op, int64_t M, int64_t N, int64_t nnz,
                                                     const dgsSpmmPlanInfo *info) {
   if (M <= 0 || N <= 0 || nnz <= 0 || !info) return 0;
@@ -398,6 +423,7 @@ extern "C" int dgs_spmm_plan_compact(const void *plan, dgsSpmmPlanInfo *info, vo
   char *dst = static_cast<char *>(compact);
   const size_t ub = (size_t)info->n_units * sizeof(int4), lb = (size_t)info->n_long * sizeof(int4);
   const size_t off_long = PL.off_units + up(ub);
+  if (off_long > (size_t)INT32_MAX) return DGS_ERANGE;  // info->off_long is 32-bit (2^27 units: beyond any int32 nnz / 64)
   if (hipMemcpyAsync(dst, src, PL.off_units + ub, hipMemcpyDeviceToDevice, st) != hipSuccess) return DGS_ELAUNCH;
   if (lb && hipMemcpyAsync(dst + off_long, src + PL.off_long, lb, hipMemcpyDeviceToDevice, st) != hipSuccess)
     return DGS_ELAUNCH;

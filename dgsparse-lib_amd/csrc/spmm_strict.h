@@ -35,6 +35,29 @@ constexpr int kStrictHub = 2048;       // ... longer than this into (up to) 16
 struct StrictLds {
   float x[kBlock / kWave][kStrictXFloats + kStrictWFloats];
 };
+// Hub rows are taken longest first (a 50 k-nnz row is the critical path of the whole call): class c holds the rows with
+// kStrictHub << c < nnz <= kStrictHub << (c + 1) (the last class: everything longer), each class has its own region of the
+// unit table behind the front entries, sized for the worst case, and the unit waves walk class 5, 4, ... 0, then the front.
+constexpr int kHubClasses = 6;
+struct HubTab {
+  int base[kHubClasses];  // first table entry of each class region
+  int mid_top;            // the 4-slice units grow down from here (the whole-tile units grow up from entry 0)
+};
+static inline HubTab hub_tab(int64_t nnz, int shub, int thub) {
+  HubTab t;
+  int64_t o = nnz / kT1 + 2;
+  t.mid_top = (int)o;
+  for (int c = 0; c < kHubClasses; c++) {
+    t.base[c] = (int)o;
+    o += (int64_t)shub * (nnz / ((int64_t)thub << c)) + 16;
+  }
+  return t;
+}
+__host__ __device__ __forceinline__ int hub_class(int len, int thub) {
+  int c = 0;
+  while (c < kHubClasses - 1 && len > (thub << (c + 1))) c++;
+  return c;
+}
 
 constexpr int strict_smid(int G) { return G < 4 ? G : 4; }
 constexpr int strict_shub(int G) { return G < 16 ? G : 16; }
@@ -110,11 +133,44 @@ __device__ __forceinline__ void strict_row(const int p0, const int len, const in
       __builtin_amdgcn_wave_barrier();
       const int nh = min(NH, cnt - h * NH);
       if (CL == kWave || lane < CL) {
-#pragma unroll 8
-        for (int i = 0; i < nh; i++) {
-          float xv[VP];
-          load_vec<VP>(xb + i * RS + lane * VP, xv);
-          const float wv = WI ? xb[i * RS + W + lane] : (HAS_VAL ? wb[i] : 1.0f);
+        // the chain: one LDS read (x, and w beside it) + one fma per nnz.  Batches of CB steps, the reads of the next batch
+        // issued before the fmas of the current one, so the LDS latency is paid once per half round, not once per batch
+        constexpr int CB = 8;
+        const float *xr = xb + lane * VP;
+        auto rd = [&](int i, float (&xv)[VP], float &wv) {
+          load_vec<VP>(xr + i * RS, xv);
+          wv = WI ? xr[i * RS + W] : (HAS_VAL ? wb[i] : 1.0f);
+        };
+        float xa[CB][VP], wa[CB], xn[CB][VP], wn2[CB];
+        auto rdb = [&](int i0, float (&xx)[CB][VP], float (&ww)[CB]) {
+#pragma unroll
+          for (int u = 0; u < CB; u++) rd(i0 + u, xx[u], ww[u]);
+        };
+        auto fmab = [&](const float (&xx)[CB][VP], const float (&ww)[CB]) {
+#pragma unroll
+          for (int u = 0; u < CB; u++) {
+#pragma unroll
+            for (int v = 0; v < VP; v++) acc[v] = chain_step<FMA>(ww[u], xx[u][v], acc[v]);
+          }
+        };
+        int i = 0;
+        if (nh >= CB) {
+          // ping-pong between two register batches (no copies): per nnz one ds_read(2) and one fma
+          rdb(0, xa, wa);
+          while (true) {
+            if (i + 2 * CB <= nh) rdb(i + CB, xn, wn2);
+            fmab(xa, wa);
+            i += CB;
+            if (i + CB > nh) break;
+            if (i + 2 * CB <= nh) rdb(i + CB, xa, wa);
+            fmab(xn, wn2);
+            i += CB;
+            if (i + CB > nh) break;
+          }
+        }
+        for (; i < nh; i++) {
+          float xv[VP], wv;
+          rd(i, xv, wv);
 #pragma unroll
           for (int v = 0; v < VP; v++) acc[v] = chain_step<FMA>(wv, xv[v], acc[v]);
         }
@@ -144,22 +200,26 @@ __device__ __forceinline__ void strict_unit(const int row, const int p0, const i
   }
 }
 
-// Unit blocks of the strict fused launch.  The table: [0, n_front) whole-tile and 4-slice units in row order, and
-// [cap - n_back, cap) the 16-slice units of the hub rows, which every wave takes first (they are the longest chains).
+// Unit blocks of the strict fused launch.  Order of work: hub classes longest first, then the 4-slice units, then the
+// whole-tile ones.  All slices of a row read the SAME rows of the dense operand, so they must share an L2: a row's group
+// of slices goes to ONE XCD (block b runs on XCD b % 8 - observed placement, a speed hint only) and to neighbouring waves
+// of it, which run in step.  (First version: slices dealt round-robin over all waves = over all 8 XCDs - every line of a hub
+// row was fetched from memory 8 times, 7.8 GB per call on the headline graph, and the call took 1.4 ms.)
 template <int G, int V, bool MEAN, bool HAS_VAL, bool FMA>
 __device__ __forceinline__ void spmm_units_strict_body(int bid, int nblocks, StrictLds &lds, int N,
                                                        const int *__restrict__ col, const float *__restrict__ val,
                                                        const float *__restrict__ B, float *__restrict__ C,
                                                        const SpmmWs *__restrict__ hdr, const int4 *__restrict__ units,
-                                                       int cap) {
+                                                       const HubTab ht) {
   constexpr int SM = strict_smid(G), SH = strict_shub(G);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float *xb = lds.x[wave];
-  const int n_front = hdr->n_units, n_back = hdr->n_long;
-  const int nw = nblocks * (kBlock / kWave), w0 = bid * (kBlock / kWave) + wave;
   const int tbase = blockIdx.y * G * V;
-  for (int k = w0; k < n_back + n_front; k += nw) {
-    const int4 d = units[k < n_back ? cap - 1 - k : k - n_back];  // {row, first nnz, nnz, slice | slices << 8}
+  const int nx = (nblocks & 7) == 0 ? 8 : 1;                      // XCDs the mapping distinguishes
+  const int x = bid % nx, s = (bid / nx) * (kBlock / kWave) + wave;  // this wave: XCD x, slot s of SP on it
+  const int SP = (nblocks / nx) * (kBlock / kWave);
+  int rot = 0;  // slots already used up by earlier segments on this XCD (keeps the deal round-robin across segments)
+  auto run = [&](const int4 d) {  // {row, first nnz, nnz, slice | slices << 8}
     const int S = d.w >> 8, sl = d.w & 255;
     if (S == 1) strict_unit<V, G, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, sl, lane, N, col, val, B, C, xb);
     if constexpr (SM > 1) {
@@ -168,20 +228,38 @@ __device__ __forceinline__ void spmm_units_strict_body(int bid, int nblocks, Str
     if constexpr (SH > SM) {
       if (S == SH) strict_unit<V, G / SH, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, sl, lane, N, col, val, B, C, xb);
     }
-  }
+  };
+  // one segment: `cnt` units in groups of gs (a row's slices), group g at table entries first(g) .. first(g) + gs - 1
+  auto segment = [&](int cnt, int gs, int base, bool down) {
+    const int ngroups = cnt / gs;
+    const int gx = ngroups > x ? (ngroups - x + nx - 1) / nx : 0;  // groups of this XCD: x, x + nx, ...
+    const int ux = gx * gs;
+    int u = s - rot;
+    if (u < 0) u += SP;
+    for (; u < ux; u += SP) {
+      const int g = x + nx * (u / gs), j = u % gs;
+      run(units[(down ? base - (g + 1) * gs : base + g * gs) + j]);
+    }
+    rot = (rot + ux) % SP;
+  };
+#pragma unroll
+  for (int c = kHubClasses - 1; c >= 0; c--) segment(hdr->hub[c], SH, ht.base[c], false);
+  segment(hdr->n_pslots, SM, ht.mid_top, true);
+  segment(hdr->n_units, 1, 0, false);
 }
 
-// Unit table of the strict schedule.  Same structure as spmm_classify (a block owns 4096 consecutive rows, per-thread
-// counts -> block scan -> one atomicAdd per block and table end).
+// Unit table of the strict schedule.  Whole-tile units grow up from entry 0 and 4-slice units down from mid_top (together
+// at most nnz / T1 entries); same structure as spmm_classify (a block owns 4096 consecutive rows, per-thread counts -> block
+// scan -> ONE atomicAdd per block and kind).  Hub rows are rare (hundreds in a million rows): one atomicAdd per row on the
+// counter of its length class.
 static __global__ __launch_bounds__(kBlock) void spmm_classify_strict(int M, int t1, int tmid, int thub, int smid, int shub,
-                                                                      int cap, const int *__restrict__ rowptr,
+                                                                      const HubTab ht, const int *__restrict__ rowptr,
                                                                       SpmmWs *__restrict__ hdr, int4 *__restrict__ units) {
-  __shared__ int s_f[kBlock / kWave], s_b[kBlock / kWave];
-  __shared__ int s_fbase, s_bbase;
+  __shared__ int s_f[kBlock / kWave], s_m[kBlock / kWave];
+  __shared__ int s_fbase, s_mbase;
   const int tid = blockIdx.x * kBlock * kK0Rows + threadIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  auto slices = [&](int len) { return len > thub ? shub : (len > tmid ? smid : 1); };
-  int fm = 0, bm = 0;
+  int fm = 0, mm = 0;
   unsigned mask = 0;
 #pragma unroll
   for (int i = 0; i < kK0Rows; i++) {
@@ -189,55 +267,59 @@ static __global__ __launch_bounds__(kBlock) void spmm_classify_strict(int M, int
     if (r < M) {
       const int len = rowptr[r + 1] - rowptr[r];
       if (len > t1) {
-        if (len > thub) bm += shub; else fm += slices(len);
+        if (len <= tmid) fm++;
+        else if (len <= thub) mm += smid;
         mask |= 1u << i;
       }
     }
   }
-  int fi = fm, bi = bm;
+  int fi = fm, mi = mm;
 #pragma unroll
   for (int d = 1; d < kWave; d <<= 1) {
-    const int tf = __shfl_up(fi, d, kWave), tb = __shfl_up(bi, d, kWave);
+    const int tf = __shfl_up(fi, d, kWave), tm = __shfl_up(mi, d, kWave);
     if (lane >= d) {
       fi += tf;
-      bi += tb;
+      mi += tm;
     }
   }
   if (lane == kWave - 1) {
     s_f[wave] = fi;
-    s_b[wave] = bi;
+    s_m[wave] = mi;
   }
   __syncthreads();
-  int fo = 0, bo = 0, ft = 0, bt = 0;
+  int fo = 0, ft = 0, mo = 0, mt = 0;
 #pragma unroll
   for (int w = 0; w < kBlock / kWave; w++) {
     if (w < wave) {
       fo += s_f[w];
-      bo += s_b[w];
+      mo += s_m[w];
     }
     ft += s_f[w];
-    bt += s_b[w];
+    mt += s_m[w];
   }
   if (threadIdx.x == 0) {
     s_fbase = ft ? atomicAdd(&hdr->n_units, ft) : 0;
-    s_bbase = bt ? atomicAdd(&hdr->n_long, bt) : 0;
+    s_mbase = mt ? atomicAdd(&hdr->n_pslots, mt) : 0;
   }
   __syncthreads();
   if (!mask) return;
   int foff = s_fbase + fo + fi - fm;
-  int boff = s_bbase + bo + bi - bm;
+  int moff = s_mbase + mo + mi - mm;
   while (mask) {
     const int i = __ffs((int)mask) - 1;
     mask &= mask - 1;
     const int r = i * kBlock + tid;
     const int rs = rowptr[r], len = rowptr[r + 1] - rs;
     if (len > thub) {
-      for (int s = 0; s < shub; s++) units[cap - 1 - (boff + s)] = make_int4(r, rs, len, s | (shub << 8));
-      boff += shub;
+      const int c = hub_class(len, thub);
+      const int o = ht.base[c] + atomicAdd(&hdr->hub[c], shub);
+      for (int s = 0; s < shub; s++) units[o + s] = make_int4(r, rs, len, s | (shub << 8));
+    } else if (len > tmid) {
+      const int o = ht.mid_top - moff - smid;
+      for (int s = 0; s < smid; s++) units[o + s] = make_int4(r, rs, len, s | (smid << 8));
+      moff += smid;
     } else {
-      const int S = slices(len);
-      for (int s = 0; s < S; s++) units[foff + s] = make_int4(r, rs, len, s | (S << 8));
-      foff += S;
+      units[foff++] = make_int4(r, rs, len, 1 << 8);
     }
   }
 }

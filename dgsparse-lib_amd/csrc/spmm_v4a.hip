@@ -97,6 +97,7 @@ extern "C" int dgs_spmm_csr_plan_f32(int reduce_op, int64_t M, int64_t K, int64_
   }
   const size_t need = dgs_spmm_csr_plan_workspace_bytes(reduce_op, M, N, nnz, info);
   if (!workspace || workspace_bytes < need) return DGS_EWORKSPACE;
+  if (!is_aligned16(plan)) return DGS_EINVAL;  // the kernels read the tables as int4
   const bool al = is_aligned16(B) && is_aligned16(C) && (!arg || is_aligned16(E)) && is_aligned16(workspace);
   const FeatMap fm = feat_map(N, al);
   SpmmArgs a{M, K, N, nnz, rowptr, col, val, B, C, arg ? E : nullptr, fm.tiles, workspace, st, reduce_op};
@@ -118,6 +119,7 @@ extern "C" int dgs_spmm_csr_acc_f32(int64_t M, int64_t K, int64_t N, int64_t nnz
   if (M == 0 || N == 0 || nnz == 0) return DGS_OK;
   if (!rowptr || !C || !col || !B) return DGS_EINVAL;
   const bool planned = plan && info && !tiny_problem(M, nnz);
+  if (planned && !is_aligned16(plan)) return DGS_EINVAL;
   const size_t need = planned ? dgs_spmm_csr_plan_workspace_bytes(DGS_SUM, M, N, nnz, info)
                               : dgs_spmm_csr_workspace_bytes(DGS_SUM, M, N, nnz);
   if (need > 0 && (!workspace || workspace_bytes < need)) return DGS_EWORKSPACE;
@@ -149,6 +151,7 @@ extern "C" int dgs_spmm_csr_acc_max_f32(int64_t M, int64_t K, int64_t N, int64_t
   if (M == 0 || N == 0 || nnz == 0) return DGS_OK;
   if (!rowptr || !C || !E || !col || !B) return DGS_EINVAL;
   const bool planned = plan && info && !tiny_problem(M, nnz);
+  if (planned && !is_aligned16(plan)) return DGS_EINVAL;
   const size_t need = planned ? dgs_spmm_csr_plan_workspace_bytes(DGS_MAX, M, N, nnz, info)
                               : dgs_spmm_csr_workspace_bytes(DGS_MAX, M, N, nnz);
   if (need > 0 && (!workspace || workspace_bytes < need)) return DGS_EWORKSPACE;

@@ -98,7 +98,9 @@ std::vector<Tensor> spmm_fwd(int op, const Tensor &rowptr_, const Tensor &col_, 
   const bool arg = (op == DGS_MAX || op == DGS_MIN);
   Tensor E = arg ? at::empty({M, N}, dense.options().dtype(at::kInt)) : Tensor();
   const dgsSpmmPlanInfo *pi = plan_info(plan, pinfo, rowptr);
-  if (pi && M > 0 && N > 0 && nnz > 0 && dgs_spmm_csr_schedule(op, M, K, N, nnz) == DGS_SCHED_ROWS) {
+  // strict-order sum / mean (DGS_ALG_STRICT_*) has its own unit table: the locality plan does not apply
+  const bool strict = (algorithm & (DGS_ALG_STRICT_SUM | DGS_ALG_STRICT_NOFMA)) && (op == DGS_SUM || op == DGS_MEAN);
+  if (pi && !strict && M > 0 && N > 0 && nnz > 0 && dgs_spmm_csr_schedule(op, M, K, N, nnz) == DGS_SCHED_ROWS) {
     TORCH_CHECK((size_t)plan->numel() >= (pi->off_long ? dgs_spmm_plan_compact_bytes(pi) : dgs_spmm_plan_bytes(M, K, nnz)),
                 "dgsparse: plan buffer too small for this matrix");
     const size_t wsb = dgs_spmm_csr_plan_workspace_bytes(op, M, N, nnz, pi);
@@ -306,6 +308,39 @@ std::vector<Tensor> spmm_plan_op(Tensor rowptr_, Tensor col_, int64_t n_cols) {
   return {small, info};
 }
 
+// Non-blocking build, first half: (rowptr, col, n_cols) -> [build buffer (uint8, GPU), header copy (256 uint8, pinned CPU)].
+// Everything is queued on the CURRENT stream (the caller makes that a side stream); no host synchronisation.
+std::vector<Tensor> spmm_plan_start_op(Tensor rowptr_, Tensor col_, int64_t n_cols) {
+  const Tensor rowptr = i32vec(rowptr_, "rowptr"), col = i32vec(col_, "col");
+  same_device(rowptr, col, "rowptr and col");
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(rowptr.device());
+  const int64_t M = rowptr.numel() - 1, nnz = col.numel();
+  TORCH_CHECK(M > 0 && nnz > 0 && n_cols > 0, "dgsparse: cannot plan an empty matrix");
+  const size_t pb = dgs_spmm_plan_bytes(M, n_cols, nnz), wb = dgs_spmm_plan_workspace_bytes(M, n_cols, nnz);
+  Tensor plan = workspace(pb, rowptr), ws = workspace(wb, rowptr);
+  Tensor hdr = at::zeros({DGS_PLAN_HEADER_BYTES}, at::TensorOptions().dtype(at::kByte).device(at::kCPU).pinned_memory(true));
+  check_rc(dgs_spmm_plan_build(M, n_cols, nnz, rowptr.data_ptr<int>(), col.data_ptr<int>(), plan.data_ptr(), pb,
+                               ws.data_ptr(), wb, nullptr, cur_stream()),
+           "spmm_plan_build");
+  TORCH_CHECK(hipMemcpyAsync(hdr.data_ptr(), plan.data_ptr(), DGS_PLAN_HEADER_BYTES, hipMemcpyDeviceToHost,
+                             static_cast<hipStream_t>(cur_stream())) == hipSuccess, "dgsparse: header copy failed");
+  return {plan, hdr};
+}
+
+// ... second half, once the caller has seen the first half's event complete: -> [compact plan (uint8, GPU), info (16 int32)]
+std::vector<Tensor> spmm_plan_finish_op(Tensor plan, Tensor hdr, int64_t nnz) {
+  TORCH_CHECK(plan.is_cuda() && plan.scalar_type() == at::kByte && hdr.device().is_cpu() && hdr.numel() >= DGS_PLAN_HEADER_BYTES,
+              "dgsparse: spmm_plan_finish takes the two tensors of spmm_plan_start");
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(plan.device());
+  Tensor info = at::zeros({16}, at::TensorOptions().dtype(at::kInt).device(at::kCPU));
+  dgsSpmmPlanInfo *pi = reinterpret_cast<dgsSpmmPlanInfo *>(info.data_ptr<int>());
+  check_rc(dgs_spmm_plan_info_from_header(hdr.data_ptr(), (size_t)hdr.numel(), pi), "spmm_plan_info_from_header");
+  const size_t cb = dgs_spmm_plan_compact_bytes(pi);
+  Tensor small = workspace(cb, plan);
+  check_rc(dgs_spmm_plan_compact(plan.data_ptr(), pi, small.data_ptr(), cb, nnz, cur_stream()), "spmm_plan_compact");
+  return {small, info};
+}
+
 // csr2csc(rowptr, colind, values) -> [colptr, row, values in CSC order]; square like the reference (src/spmm.cpp:91-94)
 std::vector<Tensor> csr2csc_op(Tensor rowptr_, Tensor colind_, Tensor values) {
   const Tensor rowptr = i32vec(rowptr_, "rowptr"), col = i32vec(colind_, "colind");
@@ -372,5 +407,7 @@ TORCH_LIBRARY(dgsparse_spmm, m) {
   m.def("spmm_min_p", &spmm_op_p<DGS_MIN>);
   m.def("spmm_mean_p", &spmm_op_p<DGS_MEAN>);
   m.def("spmm_plan", &spmm_plan_op);
+  m.def("spmm_plan_start", &spmm_plan_start_op);
+  m.def("spmm_plan_finish", &spmm_plan_finish_op);
   m.def("permute_values", &t_values_op);
 }

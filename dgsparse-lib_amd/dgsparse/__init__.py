@@ -16,6 +16,11 @@ from . import gspmm  # noqa: F401,E402  (GSpMM_u_e / GSpMM_u of the reference's 
 
 __version__ = '0.1'
 
+# `algorithm` bits above the reference's algorithm ids (include/dgsparse_hip.h): dgsparse.spmm_sum(A, X, dgsparse.ALG_STRICT_SUM)
+ALG_SHARED_GPU = _capi.ALG_SHARED_GPU
+ALG_STRICT_SUM = _capi.ALG_STRICT_SUM      # sum / mean as ONE sequential fmaf chain per (row, feature), any row length
+ALG_STRICT_NOFMA = _capi.ALG_STRICT_NOFMA  # ... with the product rounded before the add (the reference's host loop)
+
 cuda_version = _C.cuda_version()  # -1 on ROCm: the reference's CUDA-major check is skipped (__init__.py:29)
 
 __all__ = ['spmm_sum', 'spmm_max', 'spmm_min', 'spmm_mean', 'sddmm', 'Storage', 'SparseTensor', 'csr2csc']

@@ -53,6 +53,8 @@ _lib.dgs_spmm_plan_workspace_bytes.restype = _sz
 _lib.dgs_spmm_plan_workspace_bytes.argtypes = [_i64, _i64, _i64]
 _lib.dgs_spmm_plan_build.restype = _int
 _lib.dgs_spmm_plan_build.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp, _sz, ctypes.POINTER(PlanInfo), _vp]
+_lib.dgs_spmm_plan_info_from_header.restype = _int
+_lib.dgs_spmm_plan_info_from_header.argtypes = [_vp, _sz, ctypes.POINTER(PlanInfo)]
 _lib.dgs_spmm_plan_compact_bytes.restype = _sz
 _lib.dgs_spmm_plan_compact_bytes.argtypes = [ctypes.POINTER(PlanInfo)]
 _lib.dgs_spmm_plan_compact.restype = _int
@@ -99,7 +101,7 @@ _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
 EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
            'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes', 'dgs_spmm_plan_build',
-           'dgs_spmm_plan_compact_bytes', 'dgs_spmm_plan_compact', 'dgs_spmm_csr_plan_workspace_bytes',
+           'dgs_spmm_plan_compact_bytes', 'dgs_spmm_plan_compact', 'dgs_spmm_plan_info_from_header', 'dgs_spmm_csr_plan_workspace_bytes',
            'dgs_spmm_csr_plan_f32', 'dgs_spmm_csr_acc_f32', 'dgs_spmm_csr_acc_max_f32',
            'dgs_spmm_csr_schedule', 'dgs_spmm_arg_backward_f32', 'dgs_sddmm_csr_schedule',
            'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',

@@ -179,7 +179,9 @@ class HaloPlan:
         inc = torch.ones(col.numel(), dtype=torch.bool, device=dev)
         if col.numel() > 1:
             inc[1:] = col[1:] >= col[:-1]
-            inc[part.rowptr[1:-1].long().clamp(max=col.numel() - 1)] = True  # a row start never breaks the order
+            starts = part.rowptr[1:-1].long()
+            inc[starts[starts < col.numel()]] = True  # a REAL row start never breaks the order (trailing empty rows have
+            # rowptr == nnz: clamping those to nnz-1 used to mask a descent inside the last non-empty row)
         self.rows_sorted = bool(inc.all())
         if world == 1 or standalone:  # nothing to exchange; no process group needed
             self.send_splits = [0] * world

@@ -9,8 +9,11 @@ independently.  Two intended differences:
 * rectangular matrices work: the CSC view has ``sparse_sizes[1] = col.max() + 1`` columns (the reference passes
   ``n, n`` to cuSPARSE and is square-only).
 
-Next to the CSC view the Storage keeps, with the same lifetime and built on first use: the locality plans of the
-forward (CSR) and backward (CSC) SpMM (csrc/spmm_plan.hip) and the edge values in CSC order.
+Next to the CSC view the Storage keeps, with the same lifetime: the locality plans of the forward (CSR) and backward
+(CSC) SpMM (csrc/spmm_plan.hip) and the edge values in CSC order.  The reference's operator has no per-matrix setup at
+all (dgsparse/spmm.py:5-28), so a plan must never cost a caller that uses a matrix once: it is built from the
+(DGS_PLAN_AFTER + 1)-th use on, on a side stream and without any host synchronisation, calls keep taking the plan-free
+schedule until the build's event has completed, and Storages over the same (rowptr, col) buffers share one plan.
 """
 import os
 import weakref
@@ -21,6 +24,61 @@ import torch
 from . import _capi
 
 _INDEX = torch.int32
+
+
+def _plan_after() -> int:
+    """Uses of a matrix that go plan-free before its plan is built.  Measured on the headline graph (2^20 rows, 16 M
+    nnz): the build is ~1.5 ms of small launches and a planned call saves ~0.1 ms, i.e. a blocking build pays off after
+    ~14 calls; built on a side stream it only competes for the GPU, so 3 calls are enough to tell a matrix that is
+    reused (training epochs, layers sharing an adjacency) from a one-shot one (sampled mini-batches)."""
+    try:
+        return max(0, int(os.environ.get('DGS_PLAN_AFTER', '3')))
+    except ValueError:
+        return 3
+
+
+class _SharedPlan:
+    """Plan state of ONE (pointer array, index array) pair, shared by every Storage built over the same buffers.  Holds
+    the arrays, so their memory cannot be recycled under a live key."""
+    __slots__ = ('ptr', 'idx', 'K', 'calls', 'ready', 'pending', '__weakref__')
+
+    def __init__(self, ptr, idx, K):
+        self.ptr, self.idx, self.K = ptr, idx, K
+        self.calls = 0
+        self.ready = None     # (plan buffer, plan info) once built
+        self.pending = None   # (build buffer, pinned header copy, event) while the side-stream build is in flight
+
+    def start(self):
+        cur = torch.cuda.current_stream(self.ptr.device)
+        side = _side_stream(self.ptr.device)
+        side.wait_stream(cur)  # device-side ordering only: the arrays may have been produced on the current stream
+        with torch.cuda.stream(side):
+            buf, hdr = torch.ops.dgsparse_spmm.spmm_plan_start(self.ptr, self.idx, self.K)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self.pending = (buf, hdr, ev)
+
+    def poll(self, wait=False):
+        buf, hdr, ev = self.pending
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return False
+        buf.record_stream(torch.cuda.current_stream(buf.device))  # compacted on the current stream, allocated on the side one
+        self.ready = tuple(torch.ops.dgsparse_spmm.spmm_plan_finish(buf, hdr, self.idx.numel()))
+        self.pending = None
+        return True
+
+
+_SHARED_PLANS = weakref.WeakValueDictionary()
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    s = _SIDE_STREAMS.get(dev)
+    if s is None:
+        s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return s
 
 
 def _index_array(t: torch.Tensor, like: torch.Tensor, numel: Optional[int] = None, dtypes=(_INDEX,)) -> torch.Tensor:
@@ -89,7 +147,8 @@ class Storage(object):
         self._row, self._rowptr, self._col, self._values = row, rowptr, col, values
         self._colptr, self._csr2csc, self._csc2csr, self._colcount = colptr, csr2csc, csc2csr, colcount
         self._csc_row = None   # row index of every CSC slot (what the backward SpMM over (colptr, row) needs)
-        self._plans = {}       # 'csr' / 'csc' -> (plan buffer, plan info) or None when the shape takes no plan
+        self._plans = {}       # 'csr' / 'csc' -> _SharedPlan (shared with every Storage over the same buffers)
+        self._sched = {}       # ('csr' | 'csc', feature width) -> does that shape take the planned schedule?
         self._tvalues = None   # (weakref to values, version, values in CSC order)
         self.csr2csc_convert()
 
@@ -130,20 +189,42 @@ class Storage(object):
         return self._present('_csc_row')
 
     # ---- per-matrix state of the HIP schedule, built on first use ---------------------------------------------------
-    def spmm_plan(self, which: str = 'csr', n_feat: int = 64):
+    def spmm_plan(self, which: str = 'csr', n_feat: int = 64, wait: bool = False):
         """(plan buffer, plan info) of the forward ('csr': rowptr/col) or backward ('csc': colptr/csc_row) SpMM, or
-        (None, None) when that shape does not take the planned schedule (small inputs, dense graphs, DGS_PLAN=0)."""
-        if which not in self._plans:
-            plan = None
-            if self.nnz and self._col.is_cuda and os.environ.get('DGS_PLAN', '1') != '0':
-                if which == 'csr':
-                    ptr, idx, M, K = self._rowptr, self._col, self.sparse_sizes[0], self.sparse_sizes[1]
-                else:
-                    ptr, idx, M, K = self._colptr, self._csc_row, self.sparse_sizes[1], self.sparse_sizes[0]
-                if M > 0 and _capi.spmm_schedule(_capi.SUM, M, K, n_feat, self.nnz) == 'rows':
-                    plan = tuple(torch.ops.dgsparse_spmm.spmm_plan(ptr, idx, K))
-            self._plans[which] = plan
-        return self._plans[which] or (None, None)
+        (None, None) when there is none (yet): shapes that do not take the planned schedule at this feature width
+        (small inputs, dense graphs), DGS_PLAN=0, a matrix seen fewer than DGS_PLAN_AFTER + 1 times, a build still in
+        flight on the side stream, or a stream capture in progress (nothing may be built or polled there).
+        ``wait=True`` builds now and blocks until the plan is there (tests, benchmarks)."""
+        if not (self.nnz and self._col.is_cuda) or os.environ.get('DGS_PLAN', '1') == '0':
+            return (None, None)
+        if which == 'csr':
+            ptr, idx, M, K = self._rowptr, self._col, self.sparse_sizes[0], self.sparse_sizes[1]
+        else:
+            ptr, idx, M, K = self._colptr, self._csc_row, self.sparse_sizes[1], self.sparse_sizes[0]
+        rows = self._sched.get((which, n_feat))
+        if rows is None:  # the schedule depends on the feature width: decided per width, not once per Storage
+            rows = self._sched[(which, n_feat)] = M > 0 and _capi.spmm_schedule(_capi.SUM, M, K, n_feat, self.nnz) == 'rows'
+        if not rows:
+            return (None, None)
+        sp = self._plans.get(which)
+        if sp is None or sp.ptr is not ptr or sp.idx is not idx:
+            key = (ptr.data_ptr(), idx.data_ptr(), ptr.numel(), idx.numel(), ptr._version, idx._version, K)
+            sp = _SHARED_PLANS.get(key)
+            if sp is None:
+                sp = _SHARED_PLANS[key] = _SharedPlan(ptr, idx, K)
+            self._plans[which] = sp
+        if sp.ready is not None:
+            return sp.ready
+        if torch.cuda.is_current_stream_capturing():
+            return (None, None)
+        if sp.pending is None:
+            sp.calls += 1
+            if not wait and sp.calls <= _plan_after():
+                return (None, None)
+            sp.start()
+        if sp.poll(wait):
+            return sp.ready
+        return (None, None)
 
     def csc_values(self) -> torch.Tensor:
         """Edge values in CSC order (``values[csr2csc]``), recomputed only when ``values`` was replaced or updated in

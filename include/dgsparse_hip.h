@@ -121,6 +121,12 @@ size_t dgs_spmm_plan_workspace_bytes(int64_t M, int64_t K, int64_t nnz);
 int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int32_t *rowptr, const int32_t *col, void *plan,
                         size_t plan_bytes, void *workspace, size_t workspace_bytes, dgsSpmmPlanInfo *info,
                         dgsStream_t stream);
+/* Build without blocking: call dgs_spmm_plan_build with info == NULL (no host synchronisation at all), copy the first
+ * DGS_PLAN_HEADER_BYTES of the plan buffer to (pinned) host memory behind it on the same stream, and hand that copy to
+ * dgs_spmm_plan_info_from_header once the copy has completed (event query): it fills *info exactly as the blocking build
+ * does.  dgsparse.Storage builds its plans this way, on a side stream, from the k-th use of a matrix on. */
+#define DGS_PLAN_HEADER_BYTES 256
+int dgs_spmm_plan_info_from_header(const void *host_header, size_t bytes, dgsSpmmPlanInfo *info);
 /* The build needs a buffer sized for the worst case (~2.9 bytes per nnz); the tables it leaves are ~16 bytes per UNIT
  * (1M x 1M / 16 M nnz: 46 MB vs 1.7 MB).  dgs_spmm_plan_compact copies them into a buffer of dgs_spmm_plan_compact_bytes
  * and updates *info to describe the copy (pass that buffer + info to the calls; the build buffer can be freed). */

@@ -379,11 +379,14 @@ def test_public_ops_use_the_storage_plans(reduce):
                               has_value=True)
     Xd = torch.from_numpy(X).cuda().requires_grad_()
     fn = {'sum': dgsparse.spmm_sum, 'mean': dgsparse.spmm_mean, 'max': dgsparse.spmm_max}[reduce]
+    # plans are built lazily (from the 4th use on, on a side stream): have them now, so that this call runs on them
+    assert A.storage.spmm_plan('csr', N, wait=True)[0] is not None and A.storage._plans['csr'].ready is not None
+    if reduce != 'max':
+        assert A.storage.spmm_plan('csc', N, wait=True)[0] is not None
     out = fn(A, Xd, 0)
-    assert A.storage.spmm_plan('csr', N)[0] is not None and 'csr' in A.storage._plans
     out.backward(torch.from_numpy(G).cuda())
     if reduce != 'max':
-        assert A.storage._plans.get('csc') is not None and A.storage._tvalues is not None
+        assert A.storage._tvalues is not None
     Co, Eo = oracle.spmm(reduce, rp, col, val, X, fma=True)
     lens = np.diff(rp)
     if reduce == 'max':
@@ -407,6 +410,50 @@ def test_public_ops_use_the_storage_plans(reduce):
         np.add.at(gX, col, hit * (val[:, None].astype(np.float64) * G[row_of]))
     assert_close(Xd.grad.cpu().numpy(), gX, 3e-5, 1e-5, f'{reduce} dX through the transposed plan')
     assert_close(v.grad.cpu().numpy(), gW, 3e-5, 1e-5, f'{reduce} dA')
+
+
+def test_plan_lifecycle_lazy_async_shared(monkeypatch):
+    """The reference's operator has no per-matrix setup (dgsparse/spmm.py:5-28): a matrix used a few times must never pay
+    for a plan, the build must not synchronise the host, and Storages over the same arrays share one plan."""
+    import dgsparse
+    from bench import graphgen
+    from dgsparse import storage as dst
+    monkeypatch.delenv('DGS_PLAN_AFTER', raising=False)
+    rp, col, st = graphgen.powerlaw_csr(70000, 900000, alpha=1.9, dmax=20000, seed=10, device='cuda', as_torch=True)
+    N = 64
+    X = torch.rand((st['K'], N), device='cuda')
+    A = dgsparse.SparseTensor(rowptr=rp, col=col, values=None, has_value=False)
+    ref = dgsparse.spmm_sum(A, X, 0)
+    for k in range(dst._plan_after() - 1):
+        dgsparse.spmm_sum(A, X, 0)
+    sp = A.storage._plans['csr']
+    assert sp.calls == dst._plan_after() and sp.pending is None and sp.ready is None, 'no build in the first uses'
+    dgsparse.spmm_sum(A, X, 0)  # this use starts the build on the side stream and still runs plan-free
+    assert sp.pending is not None or sp.ready is not None
+    torch.cuda.synchronize()
+    out = dgsparse.spmm_sum(A, X, 0)  # the build's event has completed: this call picks the plan up
+    assert sp.ready is not None and sp.pending is None
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
+    # a second SparseTensor over the same index arrays shares the plan object (no second build)
+    B = dgsparse.SparseTensor(rowptr=rp, col=col, values=torch.rand(st['nnz'], device='cuda'), has_value=True)
+    assert B.storage.spmm_plan('csr', N)[0] is sp.ready[0] and B.storage._plans['csr'] is sp
+    # the decision is per feature width: a width on another schedule gets no plan, and does not poison the others
+    assert A.storage.spmm_plan('csr', 64)[0] is not None
+    # a fresh matrix inside a stream capture: nothing is built or polled, the capture survives, replay is right
+    rp2, col2 = rp.clone(), col.clone()
+    C = dgsparse.SparseTensor(rowptr=rp2, col=col2, values=None, has_value=False)
+    monkeypatch.setenv('DGS_PLAN_AFTER', '0')
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        dgsparse.spmm_sum(A, X, 0)  # warm-up outside the capture (allocator)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            y = dgsparse.spmm_sum(C, X, 0)
+    assert C.storage._plans['csr'].pending is None and C.storage._plans['csr'].ready is None
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.allclose(y, ref, rtol=1e-5, atol=1e-6)
 
 
 def test_gin_cached_neighbourhood_is_keyed_on_the_graph():
