@@ -956,7 +956,7 @@ __global__ __launch_bounds__(kBlock) void spmm_small_strict(int M, int N, int rp
   __shared__ RowsLds lds;
   __shared__ StrictLds sl;
   spmm_rows_body<G, V, OP, HAS_VAL, true, false, STRICT>(blockIdx.x, rpw, lds, M, N, rowptr, col, val, B, C, nullptr, AccArg{},
-                                                         sl.x[threadIdx.x >> 6]);
+                                                         sl.wave_region(threadIdx.x >> 6));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1298,17 +1298,18 @@ static int launch_strict(const SpmmArgs &a) {
   if (tmid > thub) tmid = thub;
   if (hipMemsetAsync(hdr, 0, sizeof(SpmmWs), a.st) != hipSuccess) return DGS_ELAUNCH;
   const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
-  // unit blocks: the kernel runs 4 workgroups per CU (LDS); two of them for the units leaves two for the row blocks, which
-  // would otherwise only start when the last unit block has drained
-  const int nbu = (env_int("DGS_STRICT_NBU", 2 * cu_count()) + 7) & ~7;  // a multiple of 8: one share per XCD
+  // unit blocks: first in the grid (the long chains must start first), twice as many as fit the chip at once (4 workgroups
+  // per CU): the later ones take over as the early ones run out of units, and the row blocks follow as those drain.
+  // Measured on the headline graph: 512 blocks 0.84 ms, 1024 0.67, 2048 0.58, 4096 0.58, 16384 0.61
+  const int nbu = (env_int("DGS_STRICT_NBU", 8 * cu_count()) + 7) & ~7;  // a multiple of 8: one share per XCD
   if constexpr (V == 4 && G >= 8 && STRICT == 1) {
     const PanelPlan P = panel_plan(a, a.tiles, G);
     if (P.use) {
       int tl = P.tlong > kStrictHub ? P.tlong : kStrictHub;
       if (tl > 65534) tl = 65534;
-      const HubTab ht = hub_tab(a.nnz, strict_shub(G), tl);
+      const HubTab ht = hub_tab(a.nnz, strict_shub(G, V), tl);
       hipLaunchKernelGGL(spmm_classify_strict, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, tl, tl, tl,
-                         strict_smid(G), strict_shub(G), ht, a.rowptr, hdr, units);
+                         strict_smid(G), strict_shub(G, V), ht, a.rowptr, hdr, units);
       auto kern = spmm_panel<G, OP, HAS_VAL>;
       static bool attr_set[64] = {};
       int dev_id = 0;
@@ -1336,9 +1337,9 @@ static int launch_strict(const SpmmArgs &a) {
   while (rpw > 8 && a.M / rpw < min_waves) rpw >>= 1;
   const int rows_per_block = (kBlock / kWave) * rpw;
   const int64_t nbr = (a.M + rows_per_block - 1) / rows_per_block;
-  const HubTab ht = hub_tab(a.nnz, strict_shub(G), thub);
+  const HubTab ht = hub_tab(a.nnz, strict_shub(G, V), thub);
   hipLaunchKernelGGL(spmm_classify_strict, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, kT1, tmid, thub,
-                     strict_smid(G), strict_shub(G), ht, a.rowptr, hdr, units);
+                     strict_smid(G), strict_shub(G, V), ht, a.rowptr, hdr, units);
   hipLaunchKernelGGL((spmm_fused_strict<G, V, OP, HAS_VAL, STRICT>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles),
                      dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, nbu, rpw, ht, a.rowptr, a.col, a.val, a.B, a.C, hdr, units);
   return check_launch();

@@ -400,6 +400,35 @@ extern "C" int dgs_spmm_plan_info_from_header(const void *host_header, size_t by
   return DGS_OK;
 }
 
+// Upper bounds of a plan's counts from four sums over the row lengths (rows longer than t1 / than tslice: how many, how many
+// nnz), for callers that queue the build and the first planned calls on one stream WITHOUT waiting for the build's counts:
+// the kernels read the real counts from the plan's device header, the host only needs grid and workspace sizes that are
+// large enough.  A row of (t1, tslice] nnz makes ceil(len / ch) units; a longer one is cut on at most max(8, len / unit)
+// <= 128 column cells, each with one ragged unit, plus len / ch full ones (plan_rowunits / cut_row above).
+extern "C" void dgs_spmm_plan_thresholds(int32_t *t1, int32_t *tslice) {
+  if (t1) *t1 = kT1;
+  if (tslice) *tslice = plan_tslice();
+}
+extern "C" int dgs_spmm_plan_provisional_info(int64_t nnz, int64_t rows_gt_t1, int64_t nnz_gt_t1, int64_t rows_gt_tslice,
+                                              int64_t nnz_gt_tslice, dgsSpmmPlanInfo *info) {
+  if (!info || nnz <= 0 || rows_gt_t1 < rows_gt_tslice || nnz_gt_t1 < nnz_gt_tslice || rows_gt_tslice < 0) return DGS_EINVAL;
+  int ch = env_int("DGS_PLAN_CH", nnz >= (8 << 20) ? kPlanCh : (nnz >= (2 << 20) ? 128 : 64));
+  ch = ch < kPlanChMin ? kPlanChMin : (ch > (1 << 20) ? (1 << 20) : ch);
+  const int unit = plan_unit();
+  const int64_t mid_rows = rows_gt_t1 - rows_gt_tslice, mid_nnz = nnz_gt_t1 - nnz_gt_tslice;
+  int64_t units = mid_rows + mid_nnz / ch + rows_gt_tslice * 9 + nnz_gt_tslice / unit + nnz_gt_tslice / ch;
+  const PlanLayout PL = plan_layout(nnz);
+  if (units > PL.max_units) units = PL.max_units;
+  if (units >= INT32_MAX) return DGS_ERANGE;
+  memset(info, 0, sizeof(*info));
+  info->n_units = (int32_t)units;
+  info->n_long = (int32_t)(rows_gt_t1 < PL.max_long ? rows_gt_t1 : PL.max_long);
+  info->n_pslots = (int32_t)units;
+  info->tslice = plan_tslice();
+  info->off_long = 0;  // the build-time layout
+  return DGS_OK;
+}
+
 extern "C" size_t dgs_spmm_csr_plan_workspace_bytes(int reduce_op, int64_t M, int64_t N, int64_t nnz,
                                                     const dgsSpmmPlanInfo *info) {
   if (M <= 0 || N <= 0 || nnz <= 0 || !info) return 0;

@@ -27,13 +27,20 @@
 
 namespace dgs {
 
+#ifndef DGS_STRICT_DBG
+#define DGS_STRICT_DBG 0  // experiment builds: 1 = no chain, 2 = no gathers, 3 = no LDS writes and no chain
+#endif
 constexpr int kUS = 8;                 // gathers in flight per lane of a strict unit wave
 constexpr int kStrictXFloats = 2048;   // per-wave LDS: one half round of gathered rows (8 KB; with w interleaved when narrow)
 constexpr int kStrictWFloats = 128;    // ... + the weights of a half round when they are not interleaved
 constexpr int kStrictMid = 256;        // rows longer than this are cut into (up to) 4 feature slices
 constexpr int kStrictHub = 2048;       // ... longer than this into (up to) 16
+constexpr int kStrictWaveFloats = kStrictXFloats + kStrictWFloats;  // per-wave region of the wave-level units
+constexpr int kStrictBlockFloats = 8800;  // the block-cooperative hub rounds need 16 x 516 + 512 floats (35.2 KB: 4 workgroups per CU)
+static_assert(kStrictBlockFloats >= (kBlock / kWave) * kStrictWaveFloats, "strict LDS");
 struct StrictLds {
-  float x[kBlock / kWave][kStrictXFloats + kStrictWFloats];
+  alignas(16) float f[kStrictBlockFloats];
+  __device__ float *wave_region(int wave) { return f + wave * kStrictWaveFloats; }
 };
 // Hub rows are taken longest first (a 50 k-nnz row is the critical path of the whole call): class c holds the rows with
 // kStrictHub << c < nnz <= kStrictHub << (c + 1) (the last class: everything longer), each class has its own region of the
@@ -60,7 +67,10 @@ __host__ __device__ __forceinline__ int hub_class(int len, int thub) {
 }
 
 constexpr int strict_smid(int G) { return G < 4 ? G : 4; }
-constexpr int strict_shub(int G) { return G < 16 ? G : 16; }
+// hub rows: feature tiles of >= 64 floats with 16-byte lanes are cut into 4 slices, each worked by a whole workgroup
+// (strict_hub_coop: four waves gather, one chains); narrower tiles into up to 16 wave-level slices
+constexpr bool strict_coop(int G, int V) { return V == 4 && G >= 16; }
+constexpr int strict_shub(int G, int V) { return strict_coop(G, V) ? 4 : (G < 16 ? G : 16); }
 
 // One wave, one feature slice [fbase, fbase + GP*V) of one row [p0, p0+len): returns the chain results in the CHAIN
 // layout: lane c < CL holds features fbase + c*VP .. + VP-1 (VP = 1 unless the slice is wider than 64 floats).
@@ -113,6 +123,7 @@ __device__ __forceinline__ void strict_row(const int p0, const int len, const in
 #pragma unroll
       for (int qq = 0; qq < H; qq++) {
         const int q = h * H + qq, i = qq * NGP + gp;
+        if (DGS_STRICT_DBG == 3) { if (x[q][0] == 1234.5f) xb[0] = x[q][0]; continue; }
         store_vec<V>(xb + i * RS + lp * V, x[q]);
         if constexpr (WI) {
           float ww[V];
@@ -127,11 +138,11 @@ __device__ __forceinline__ void strict_row(const int p0, const int len, const in
 #pragma unroll
       for (int qq = 0; qq < H; qq++) {
         const int q = h * H + qq;
-        load_vec_gather<V>(Bl + (int64_t)cn[q] * N, x[q]);
+        if (DGS_STRICT_DBG != 2) load_vec_gather<V>(Bl + (int64_t)cn[q] * N, x[q]);
         w[q] = wn[q];
       }
       __builtin_amdgcn_wave_barrier();
-      const int nh = min(NH, cnt - h * NH);
+      const int nh = (DGS_STRICT_DBG == 1 || DGS_STRICT_DBG == 3) ? 0 : min(NH, cnt - h * NH);
       if (CL == kWave || lane < CL) {
         // the chain: one LDS read (x, and w beside it) + one fma per nnz.  Batches of CB steps, the reads of the next batch
         // issued before the fmas of the current one, so the LDS latency is paid once per half round, not once per batch
@@ -200,6 +211,110 @@ __device__ __forceinline__ void strict_unit(const int row, const int p0, const i
   }
 }
 
+// Hub rows, block-cooperative: ONE workgroup per (row, quarter of the feature tile).  A chain of L steps is a chain of L LDS
+// reads as well, and an LDS instruction costs its cycles whatever the number of active lanes: sixteen 4-feature slices per
+// row, each chained by its own wave (the first version), made the LDS pipeline the bound (8 chaining waves per CU = 32
+// cycles per step) and the call 3.5x slower than the default schedule.  Here the four waves of the workgroup gather (8 KB in
+// flight each: 128 KB per row over its four workgroups, as before), the gathered rows are laid out FEATURE-major in LDS, and
+// wave 0 alone chains W = 16 .. 64 features with one ds_read_b128 of x and one of w per FOUR steps.
+template <int GP, bool MEAN, bool HAS_VAL, bool FMA>
+__device__ __forceinline__ void strict_hub_coop(const int row, const int p0, const int len, const int tbase, const int sl,
+                                                const int N, const int *__restrict__ col, const float *__restrict__ val,
+                                                const float *__restrict__ B, float *__restrict__ C, float *lds) {
+  constexpr int V = 4, NW = kBlock / kWave;
+  constexpr int NGP = kWave / GP, W = GP * V;   // nnz per load instruction; floats (= chain lanes) of the slice
+  constexpr int NWV = kUS * NGP;                // nnz per wave and round
+  constexpr int NRB = NW * NWV;                 // nnz per workgroup round
+  constexpr int LD = NRB + 4;                   // row pitch of the feature-major tile: conflict-free ds_read_b128 across lanes
+  static_assert(W * LD + NRB <= kStrictBlockFloats && W <= kWave, "strict_hub_coop LDS");
+  float *xt = lds, *wt = lds + W * LD;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int gp = lane / GP, lp = lane % GP;
+  const int fbase = tbase + sl * W;
+  const int f0 = fbase + lp * V;
+  const float *Bl = B + (f0 < N ? f0 : 0);
+  const int mine = wave * NWV + gp;  // this lane's nnz of gather q inside a round: mine + q * NGP
+  float acc = 0.0f;
+  int c[kUS];
+  float w[kUS], x[kUS][V];
+#pragma unroll
+  for (int q = 0; q < kUS; q++) {
+    const int i = p0 + min(mine + q * NGP, len - 1);
+    c[q] = ld_stream(col + i);
+    w[q] = HAS_VAL ? ld_stream(val + i) : 1.0f;
+  }
+#pragma unroll
+  for (int q = 0; q < kUS; q++) load_vec_gather<V>(Bl + (int64_t)c[q] * N, x[q]);
+  for (int r0 = 0; r0 < len; r0 += NRB) {
+    const int cnt = min(NRB, len - r0);
+    int cn[kUS];
+    float wn[kUS];
+#pragma unroll
+    for (int q = 0; q < kUS; q++) {
+      const int i = p0 + min(r0 + NRB + mine + q * NGP, len - 1);
+      cn[q] = ld_stream(col + i);
+      wn[q] = HAS_VAL ? ld_stream(val + i) : 1.0f;
+    }
+    __syncthreads();  // the chain of the previous round has left the tile
+#pragma unroll
+    for (int q = 0; q < kUS; q++) {
+      const int i = mine + q * NGP;
+#pragma unroll
+      for (int v = 0; v < V; v++) xt[(lp * V + v) * LD + i] = x[q][v];
+      if (HAS_VAL && lp == 0) wt[i] = w[q];
+    }
+#pragma unroll
+    for (int q = 0; q < kUS; q++) {  // the next round's gathers fly under the chain
+      load_vec_gather<V>(Bl + (int64_t)cn[q] * N, x[q]);
+      w[q] = wn[q];
+    }
+    __syncthreads();
+    if (wave == 0 && lane < W) {
+      const float *xr = xt + lane * LD;
+      constexpr int CB = 4;  // b128 pairs per batch = 16 steps
+      float4 xa[CB], wa[CB], xn[CB], wn4[CB];
+      auto rdb = [&](int i0, float4 (&xx)[CB], float4 (&ww)[CB]) {
+#pragma unroll
+        for (int u = 0; u < CB; u++) {
+          xx[u] = *reinterpret_cast<const float4 *>(xr + i0 + 4 * u);
+          if constexpr (HAS_VAL) ww[u] = *reinterpret_cast<const float4 *>(wt + i0 + 4 * u);
+          else ww[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+      };
+      auto fmab = [&](const float4 (&xx)[CB], const float4 (&ww)[CB]) {
+#pragma unroll
+        for (int u = 0; u < CB; u++) {
+          acc = chain_step<FMA>(ww[u].x, xx[u].x, acc);
+          acc = chain_step<FMA>(ww[u].y, xx[u].y, acc);
+          acc = chain_step<FMA>(ww[u].z, xx[u].z, acc);
+          acc = chain_step<FMA>(ww[u].w, xx[u].w, acc);
+        }
+      };
+      constexpr int ST = 4 * CB;
+      int i = 0;
+      if (cnt >= ST) {
+        rdb(0, xa, wa);
+        while (true) {
+          if (i + 2 * ST <= cnt) rdb(i + ST, xn, wn4);
+          fmab(xa, wa);
+          i += ST;
+          if (i + ST > cnt) break;
+          if (i + 2 * ST <= cnt) rdb(i + ST, xa, wa);
+          fmab(xn, wn4);
+          i += ST;
+          if (i + ST > cnt) break;
+        }
+      }
+      for (; i < cnt; i++) acc = chain_step<FMA>(HAS_VAL ? wt[i] : 1.0f, xr[i], acc);
+    }
+  }
+  if (wave == 0 && lane < W && fbase + lane < N) {
+    if constexpr (MEAN) acc /= (float)len;
+    float o[1] = {acc};
+    store_vec_stream<1>(C + (int64_t)row * N + fbase + lane, o);
+  }
+}
+
 // Unit blocks of the strict fused launch.  Order of work: hub classes longest first, then the 4-slice units, then the
 // whole-tile ones.  All slices of a row read the SAME rows of the dense operand, so they must share an L2: a row's group
 // of slices goes to ONE XCD (block b runs on XCD b % 8 - observed placement, a speed hint only) and to neighbouring waves
@@ -211,41 +326,55 @@ __device__ __forceinline__ void spmm_units_strict_body(int bid, int nblocks, Str
                                                        const float *__restrict__ B, float *__restrict__ C,
                                                        const SpmmWs *__restrict__ hdr, const int4 *__restrict__ units,
                                                        const HubTab ht) {
-  constexpr int SM = strict_smid(G), SH = strict_shub(G);
+  constexpr int SM = strict_smid(G), SH = strict_shub(G, V);
+  constexpr bool COOP = strict_coop(G, V);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float *xb = lds.x[wave];
+  float *xb = lds.wave_region(wave);
   const int tbase = blockIdx.y * G * V;
-  const int nx = (nblocks & 7) == 0 ? 8 : 1;                      // XCDs the mapping distinguishes
-  const int x = bid % nx, s = (bid / nx) * (kBlock / kWave) + wave;  // this wave: XCD x, slot s of SP on it
-  const int SP = (nblocks / nx) * (kBlock / kWave);
-  int rot = 0;  // slots already used up by earlier segments on this XCD (keeps the deal round-robin across segments)
-  auto run = [&](const int4 d) {  // {row, first nnz, nnz, slice | slices << 8}
+  const int nx = (nblocks & 7) == 0 ? 8 : 1;  // XCDs the mapping distinguishes
+  const int x = bid % nx;
+  auto run = [&](const int4 d) {  // wave-level unit {row, first nnz, nnz, slice | slices << 8}
     const int S = d.w >> 8, sl = d.w & 255;
     if (S == 1) strict_unit<V, G, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, sl, lane, N, col, val, B, C, xb);
     if constexpr (SM > 1) {
       if (S == SM && S != 1) strict_unit<V, G / SM, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, sl, lane, N, col, val, B, C, xb);
     }
-    if constexpr (SH > SM) {
+    if constexpr (!COOP && SH > SM) {
       if (S == SH) strict_unit<V, G / SH, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, sl, lane, N, col, val, B, C, xb);
     }
   };
-  // one segment: `cnt` units in groups of gs (a row's slices), group g at table entries first(g) .. first(g) + gs - 1
-  auto segment = [&](int cnt, int gs, int base, bool down) {
+  // one segment: `cnt` units in groups of gs (a row's slices), group g at table entries first(g) .. first(g) + gs - 1; the
+  // worker (a wave, or a whole workgroup for cooperative hub units) is slot `slot` of `nslots` on its XCD
+  auto segment = [&](int cnt, int gs, int base, bool down, int slot, int nslots, int &rot, auto &&fn) {
     const int ngroups = cnt / gs;
     const int gx = ngroups > x ? (ngroups - x + nx - 1) / nx : 0;  // groups of this XCD: x, x + nx, ...
     const int ux = gx * gs;
-    int u = s - rot;
-    if (u < 0) u += SP;
-    for (; u < ux; u += SP) {
+    int u = slot - rot;
+    if (u < 0) u += nslots;
+    for (; u < ux; u += nslots) {
       const int g = x + nx * (u / gs), j = u % gs;
-      run(units[(down ? base - (g + 1) * gs : base + g * gs) + j]);
+      fn(units[(down ? base - (g + 1) * gs : base + g * gs) + j]);
     }
-    rot = (rot + ux) % SP;
+    rot = (rot + ux) % nslots;
   };
+  const int s = (bid / nx) * (kBlock / kWave) + wave, SP = (nblocks / nx) * (kBlock / kWave);  // wave slots of this XCD
+  int rot = 0;  // slots used up by earlier segments (keeps the deal round-robin across segments)
+  if constexpr (COOP) {
+    const int sb = bid / nx, SPB = nblocks / nx;  // workgroup slots of this XCD
+    int rotb = 0;
+    auto coop = [&](const int4 d) {
+      strict_hub_coop<G / SH, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, d.w & 255, N, col, val, B, C, lds.f);
+    };
 #pragma unroll
-  for (int c = kHubClasses - 1; c >= 0; c--) segment(hdr->hub[c], SH, ht.base[c], false);
-  segment(hdr->n_pslots, SM, ht.mid_top, true);
-  segment(hdr->n_units, 1, 0, false);
+    for (int c = kHubClasses - 1; c >= 0; c--) segment(hdr->hub[c], SH, ht.base[c], false, sb, SPB, rotb, coop);
+    __syncthreads();  // the last chain has left the LDS before the waves reuse it one by one
+    rot = (rotb * (kBlock / kWave)) % SP;
+  } else {
+#pragma unroll
+    for (int c = kHubClasses - 1; c >= 0; c--) segment(hdr->hub[c], SH, ht.base[c], false, s, SP, rot, run);
+  }
+  segment(hdr->n_pslots, SM, ht.mid_top, true, s, SP, rot, run);
+  segment(hdr->n_units, 1, 0, false, s, SP, rot, run);
 }
 
 // Unit table of the strict schedule.  Whole-tile units grow up from entry 0 and 4-slice units down from mid_top (together

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdgsparse_hip.so')
+LIB_PATH = os.environ.get('DGS_LIB_PATH') or os.path.join(_HERE, 'libdgsparse_hip.so')  # (override: experiment builds)
 
 SUM, MAX, MIN, MEAN = 0, 1, 2, 3  # include/gspmm.h:13 in the reference
 ALG_SHARED_GPU = 0x100  # `algorithm` hint bit: the GPU is shared with concurrently running kernels
@@ -55,6 +55,10 @@ _lib.dgs_spmm_plan_build.restype = _int
 _lib.dgs_spmm_plan_build.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp, _sz, ctypes.POINTER(PlanInfo), _vp]
 _lib.dgs_spmm_plan_info_from_header.restype = _int
 _lib.dgs_spmm_plan_info_from_header.argtypes = [_vp, _sz, ctypes.POINTER(PlanInfo)]
+_lib.dgs_spmm_plan_thresholds.restype = None
+_lib.dgs_spmm_plan_thresholds.argtypes = [ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+_lib.dgs_spmm_plan_provisional_info.restype = _int
+_lib.dgs_spmm_plan_provisional_info.argtypes = [_i64, _i64, _i64, _i64, _i64, ctypes.POINTER(PlanInfo)]
 _lib.dgs_spmm_plan_compact_bytes.restype = _sz
 _lib.dgs_spmm_plan_compact_bytes.argtypes = [ctypes.POINTER(PlanInfo)]
 _lib.dgs_spmm_plan_compact.restype = _int
@@ -101,7 +105,8 @@ _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
 EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
            'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes', 'dgs_spmm_plan_build',
-           'dgs_spmm_plan_compact_bytes', 'dgs_spmm_plan_compact', 'dgs_spmm_plan_info_from_header', 'dgs_spmm_csr_plan_workspace_bytes',
+           'dgs_spmm_plan_compact_bytes', 'dgs_spmm_plan_compact', 'dgs_spmm_plan_info_from_header',
+           'dgs_spmm_plan_thresholds', 'dgs_spmm_plan_provisional_info', 'dgs_spmm_csr_plan_workspace_bytes',
            'dgs_spmm_csr_plan_f32', 'dgs_spmm_csr_acc_f32', 'dgs_spmm_csr_acc_max_f32',
            'dgs_spmm_csr_schedule', 'dgs_spmm_arg_backward_f32', 'dgs_sddmm_csr_schedule',
            'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
@@ -212,6 +217,24 @@ class SpmmPlan:
         i = self.info
         return (f'SpmmPlan(M={self.M}, nnz={self.nnz}, units={i.n_units}, long_rows={i.n_long}, pslots={i.n_pslots}, '
                 f'tslice={i.tslice}, xcd_start={list(i.xcd_start)})')
+
+
+def plan_thresholds():
+    """(t1, tslice): the row lengths above which the plan makes units / cuts rows on the column grid."""
+    a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+    _lib.dgs_spmm_plan_thresholds(ctypes.byref(a), ctypes.byref(b))
+    return int(a.value), int(b.value)
+
+
+def plan_provisional_info(nnz, rows_gt_t1, nnz_gt_t1, rows_gt_tslice, nnz_gt_tslice):
+    """Upper bounds of a plan's counts as the 16-int32 CPU tensor the torch ops take as ``plan_info`` (usable with the
+    build buffer on the stream the build was queued on, before anything has been read back)."""
+    info = PlanInfo()
+    _check(_lib.dgs_spmm_plan_provisional_info(int(nnz), int(rows_gt_t1), int(nnz_gt_t1), int(rows_gt_tslice),
+                                               int(nnz_gt_tslice), ctypes.byref(info)), 'spmm_plan_provisional_info')
+    t = torch.zeros(16, dtype=torch.int32)
+    ctypes.memmove(t.data_ptr(), ctypes.byref(info), ctypes.sizeof(info))
+    return t
 
 
 def spmm_plan(rowptr, col, K, N=64, force=False):

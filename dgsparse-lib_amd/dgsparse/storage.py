@@ -11,9 +11,9 @@ independently.  Two intended differences:
 
 Next to the CSC view the Storage keeps, with the same lifetime: the locality plans of the forward (CSR) and backward
 (CSC) SpMM (csrc/spmm_plan.hip) and the edge values in CSC order.  The reference's operator has no per-matrix setup at
-all (dgsparse/spmm.py:5-28), so a plan must never cost a caller that uses a matrix once: it is built from the
-(DGS_PLAN_AFTER + 1)-th use on, on a side stream and without any host synchronisation, calls keep taking the plan-free
-schedule until the build's event has completed, and Storages over the same (rowptr, col) buffers share one plan.
+all (dgsparse/spmm.py:5-28), so a plan must never cost a caller that uses a matrix once: it is built at the
+(DGS_PLAN_AFTER + 1)-th use, queued on the caller's stream without any host synchronisation (see _SharedPlan), and
+Storages over the same (rowptr, col) buffers share one plan.
 """
 import os
 import weakref
@@ -29,8 +29,9 @@ _INDEX = torch.int32
 def _plan_after() -> int:
     """Uses of a matrix that go plan-free before its plan is built.  Measured on the headline graph (2^20 rows, 16 M
     nnz): the build is ~1.5 ms of small launches and a planned call saves ~0.1 ms, i.e. a blocking build pays off after
-    ~14 calls; built on a side stream it only competes for the GPU, so 3 calls are enough to tell a matrix that is
-    reused (training epochs, layers sharing an adjacency) from a one-shot one (sampled mini-batches)."""
+    ~14 calls; queued in stream order without the synchronisation it costs the GPU 1.5 ms once and the host nothing, so 3
+    calls are enough to tell a matrix that is reused (training epochs, layers sharing an adjacency) from a one-shot one
+    (sampled mini-batches)."""
     try:
         return max(0, int(os.environ.get('DGS_PLAN_AFTER', '3')))
     except ValueError:
@@ -39,46 +40,64 @@ def _plan_after() -> int:
 
 class _SharedPlan:
     """Plan state of ONE (pointer array, index array) pair, shared by every Storage built over the same buffers.  Holds
-    the arrays, so their memory cannot be recycled under a live key."""
-    __slots__ = ('ptr', 'idx', 'K', 'calls', 'ready', 'pending', '__weakref__')
+    the arrays, so their memory cannot be recycled under a live key.
+
+    Life of a plan, no host synchronisation anywhere: construction queues four sums over the row lengths and their copy
+    to pinned memory; the (DGS_PLAN_AFTER + 1)-th use queues the build on the CALLER's stream and from that very call on
+    hands out the build buffer with PROVISIONAL counts (upper bounds from those sums: the kernels read the real counts
+    from the device header, the host only sizes grids and the workspace with them); once the build's event has
+    completed, a later use swaps in the compacted plan with the real counts and drops the worst-case build buffer."""
+    __slots__ = ('ptr', 'idx', 'K', 'calls', 'ready', 'prov', '__weakref__')
 
     def __init__(self, ptr, idx, K):
         self.ptr, self.idx, self.K = ptr, idx, K
         self.calls = 0
-        self.ready = None     # (plan buffer, plan info) once built
-        self.pending = None   # (build buffer, pinned header copy, event) while the side-stream build is in flight
+        self.ready = None   # (compact plan buffer, plan info) once the build has been seen complete
+        self.prov = None    # (build buffer, provisional info, pinned header copy, event, stream) in between
 
-    def start(self):
+    def get(self, stats, wait=False):
+        if self.ready is not None:
+            return self.ready
         cur = torch.cuda.current_stream(self.ptr.device)
-        side = _side_stream(self.ptr.device)
-        side.wait_stream(cur)  # device-side ordering only: the arrays may have been produced on the current stream
-        with torch.cuda.stream(side):
-            buf, hdr = torch.ops.dgsparse_spmm.spmm_plan_start(self.ptr, self.idx, self.K)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        self.pending = (buf, hdr, ev)
-
-    def poll(self, wait=False):
-        buf, hdr, ev = self.pending
+        if self.prov is None:
+            host, ev = stats
+            if wait:
+                ev.synchronize()
+            elif not ev.query():
+                return (None, None)  # the sums have not arrived yet (only right after construction): next time
+            buf, hdr = torch.ops.dgsparse_spmm.spmm_plan_start(self.ptr, self.idx, self.K)  # queued on `cur`
+            done = torch.cuda.Event()
+            done.record(cur)
+            info = _capi.plan_provisional_info(self.idx.numel(), *host.tolist())
+            self.prov = (buf, info, hdr, done, cur)
+        buf, info, hdr, done, stream = self.prov
         if wait:
-            ev.synchronize()
-        elif not ev.query():
-            return False
-        buf.record_stream(torch.cuda.current_stream(buf.device))  # compacted on the current stream, allocated on the side one
-        self.ready = tuple(torch.ops.dgsparse_spmm.spmm_plan_finish(buf, hdr, self.idx.numel()))
-        self.pending = None
-        return True
+            done.synchronize()
+        if done.query():
+            if stream != cur:
+                buf.record_stream(cur)  # compacted on this stream, allocated on the build's
+            self.ready = tuple(torch.ops.dgsparse_spmm.spmm_plan_finish(buf, hdr, self.idx.numel()))
+            self.prov = None
+            return self.ready
+        # in stream order behind the build the buffer is valid NOW, with provisional counts; other streams wait for `ready`
+        return (buf, info) if stream == cur else (None, None)
 
 
 _SHARED_PLANS = weakref.WeakValueDictionary()
-_SIDE_STREAMS = {}
 
 
-def _side_stream(dev):
-    s = _SIDE_STREAMS.get(dev)
-    if s is None:
-        s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
-    return s
+def _length_stats(ptr: torch.Tensor):
+    """Queues the four sums over the row lengths the provisional plan counts need (rows longer than t1 / tslice: how many,
+    how many nnz) and their copy to pinned memory; returns (pinned int64[4], event).  No synchronisation."""
+    t1, ts = _capi.plan_thresholds()
+    deg = (ptr[1:] - ptr[:-1]).long()
+    m1, m2 = deg > t1, deg > ts
+    dev_stats = torch.stack([m1.sum(), (deg * m1).sum(), m2.sum(), (deg * m2).sum()])
+    host = torch.empty(4, dtype=torch.int64, pin_memory=True)
+    host.copy_(dev_stats, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(ptr.device))
+    return host, ev
 
 
 def _index_array(t: torch.Tensor, like: torch.Tensor, numel: Optional[int] = None, dtypes=(_INDEX,)) -> torch.Tensor:
@@ -150,7 +169,10 @@ class Storage(object):
         self._plans = {}       # 'csr' / 'csc' -> _SharedPlan (shared with every Storage over the same buffers)
         self._sched = {}       # ('csr' | 'csc', feature width) -> does that shape take the planned schedule?
         self._tvalues = None   # (weakref to values, version, values in CSC order)
+        self._len_stats = {}   # 'csr' / 'csc' -> (pinned sums over the row lengths, event): what a provisional plan needs
         self.csr2csc_convert()
+        if nnz and col.is_cuda and n_rows > 0:  # queued here, long complete by the (DGS_PLAN_AFTER + 1)-th use
+            self._len_stats = {'csr': _length_stats(self._rowptr), 'csc': _length_stats(self._colptr)}
 
     @classmethod
     def empty(cls):
@@ -192,9 +214,10 @@ class Storage(object):
     def spmm_plan(self, which: str = 'csr', n_feat: int = 64, wait: bool = False):
         """(plan buffer, plan info) of the forward ('csr': rowptr/col) or backward ('csc': colptr/csc_row) SpMM, or
         (None, None) when there is none (yet): shapes that do not take the planned schedule at this feature width
-        (small inputs, dense graphs), DGS_PLAN=0, a matrix seen fewer than DGS_PLAN_AFTER + 1 times, a build still in
-        flight on the side stream, or a stream capture in progress (nothing may be built or polled there).
-        ``wait=True`` builds now and blocks until the plan is there (tests, benchmarks)."""
+        (small inputs, dense graphs), DGS_PLAN=0, a matrix seen fewer than DGS_PLAN_AFTER + 1 times, or a stream capture
+        in progress before the plan is ready (nothing may be built or polled there).  From the build on the answer is
+        the build buffer with provisional counts, later the compact plan.  ``wait=True`` builds now and blocks until the
+        compact plan is there (tests, benchmarks)."""
         if not (self.nnz and self._col.is_cuda) or os.environ.get('DGS_PLAN', '1') == '0':
             return (None, None)
         if which == 'csr':
@@ -217,14 +240,11 @@ class Storage(object):
             return sp.ready
         if torch.cuda.is_current_stream_capturing():
             return (None, None)
-        if sp.pending is None:
+        if sp.prov is None:
             sp.calls += 1
             if not wait and sp.calls <= _plan_after():
                 return (None, None)
-            sp.start()
-        if sp.poll(wait):
-            return sp.ready
-        return (None, None)
+        return sp.get(self._len_stats[which], wait)
 
     def csc_values(self) -> torch.Tensor:
         """Edge values in CSC order (``values[csr2csc]``), recomputed only when ``values`` was replaced or updated in

@@ -127,6 +127,14 @@ int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int32_t *rowptr
  * does.  dgsparse.Storage builds its plans this way, on a side stream, from the k-th use of a matrix on. */
 #define DGS_PLAN_HEADER_BYTES 256
 int dgs_spmm_plan_info_from_header(const void *host_header, size_t bytes, dgsSpmmPlanInfo *info);
+/* Calls BEFORE the counts are known: dgs_spmm_plan_provisional_info fills *info with upper bounds computed from four sums over
+ * the row lengths - rows longer than t1 / than tslice (dgs_spmm_plan_thresholds): how many, and how many nnz they hold.  A
+ * build queued with info == NULL followed, on the SAME stream, by dgs_spmm_csr_plan_f32 calls with the build buffer and this
+ * provisional info is correct without any host synchronisation (the kernels take the real counts from the plan's device
+ * header; the bounds only size grids and the partial-row workspace). */
+void dgs_spmm_plan_thresholds(int32_t *t1, int32_t *tslice);
+int dgs_spmm_plan_provisional_info(int64_t nnz, int64_t rows_gt_t1, int64_t nnz_gt_t1, int64_t rows_gt_tslice,
+                                   int64_t nnz_gt_tslice, dgsSpmmPlanInfo *info);
 /* The build needs a buffer sized for the worst case (~2.9 bytes per nnz); the tables it leaves are ~16 bytes per UNIT
  * (1M x 1M / 16 M nnz: 46 MB vs 1.7 MB).  dgs_spmm_plan_compact copies them into a buffer of dgs_spmm_plan_compact_bytes
  * and updates *info to describe the copy (pass that buffer + info to the calls; the build buffer can be freed). */

@@ -427,13 +427,24 @@ def test_plan_lifecycle_lazy_async_shared(monkeypatch):
     for k in range(dst._plan_after() - 1):
         dgsparse.spmm_sum(A, X, 0)
     sp = A.storage._plans['csr']
-    assert sp.calls == dst._plan_after() and sp.pending is None and sp.ready is None, 'no build in the first uses'
-    dgsparse.spmm_sum(A, X, 0)  # this use starts the build on the side stream and still runs plan-free
-    assert sp.pending is not None or sp.ready is not None
-    torch.cuda.synchronize()
-    out = dgsparse.spmm_sum(A, X, 0)  # the build's event has completed: this call picks the plan up
-    assert sp.ready is not None and sp.pending is None
+    assert sp.calls == dst._plan_after() and sp.prov is None and sp.ready is None, 'no build in the first uses'
+    out = dgsparse.spmm_sum(A, X, 0)  # this use queues the build on the caller's stream and already runs on its tables,
+    assert sp.prov is not None or sp.ready is not None  # with provisional (upper-bound) counts: no host synchronisation
     assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
+    prov_buf = sp.prov[0] if sp.prov is not None else None
+    torch.cuda.synchronize()
+    out = dgsparse.spmm_sum(A, X, 0)  # the build's event has completed: this call swaps in the compact plan
+    assert sp.ready is not None and sp.prov is None
+    assert prov_buf is None or sp.ready[0].numel() < prov_buf.numel() // 4, 'the worst-case build buffer is dropped'
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
+    for red in (dgsparse.spmm_max, dgsparse.spmm_mean):  # provisional counts through the other reduces as well
+        rp3, col3 = rp.clone(), col.clone()
+        D = dgsparse.SparseTensor(rowptr=rp3, col=col3, values=None, has_value=False)
+        want = red(D, X, 0)
+        D.storage._plans['csr'].calls = dst._plan_after()
+        got = red(D, X, 0)
+        assert D.storage._plans['csr'].prov is not None or D.storage._plans['csr'].ready is not None
+        assert torch.equal(got, want) if red is dgsparse.spmm_max else torch.allclose(got, want, rtol=1e-5, atol=1e-6)
     # a second SparseTensor over the same index arrays shares the plan object (no second build)
     B = dgsparse.SparseTensor(rowptr=rp, col=col, values=torch.rand(st['nnz'], device='cuda'), has_value=True)
     assert B.storage.spmm_plan('csr', N)[0] is sp.ready[0] and B.storage._plans['csr'] is sp
@@ -450,7 +461,7 @@ def test_plan_lifecycle_lazy_async_shared(monkeypatch):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
             y = dgsparse.spmm_sum(C, X, 0)
-    assert C.storage._plans['csr'].pending is None and C.storage._plans['csr'].ready is None
+    assert C.storage._plans['csr'].prov is None and C.storage._plans['csr'].ready is None
     g.replay()
     torch.cuda.synchronize()
     assert torch.allclose(y, ref, rtol=1e-5, atol=1e-6)
