@@ -76,7 +76,9 @@ def main():
         sched = ''
         if op == 'sddmm':
             D1 = torch.rand((M, N), generator=g, device='cuda')
-            t = timeit(lambda: _capi.sddmm(rp, col, D1, X), iters=it)
+            plan = None if a.no_plan else _capi.spmm_plan(rp, col, K, N)
+            sched = 'nnz-balanced' if plan is None or _capi._lib.dgs_sddmm_csr_schedule(M, K, N, nnz, 0) == 2 else 'fused rows+units over the plan'
+            t = timeit(lambda: _capi.sddmm(rp, col, D1, X, plan=plan), iters=it)
             balg = 4 * (M + 1) + 8 * nnz + 4 * (M + K) * N
         else:
             o = {'sum': 0, 'max': 1, 'min': 2, 'mean': 3}[op]

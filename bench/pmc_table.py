@@ -15,7 +15,7 @@ def main():
         d = defaultdict(dict)
         for line in open(f):
             if line.startswith('dgs::'):
-                k = re.sub(r'\s+\[grid.*', '', line.strip())
+                k = line.strip()
             elif 'mean/dispatch' in line and k:
                 p = line.split()
                 d[k][p[0]] = float(p[2])
@@ -28,7 +28,7 @@ def main():
             gb = (2 * fe + wr) * 1024 / 1e9
             hit, req = v.get('TCC_HIT_sum', 0), v.get('TCC_HIT_sum', 0) + v.get('TCC_MISS_sum', 0)
             wc = v.get('SQ_WAVE_CYCLES', 0)
-            print(f'  {k[:60]:60s} {us:9.1f} us  hbm-side {gb:7.3f} GB ({gb / us * 1e3 if us else 0:5.2f} TB/s)  '
+            print(f'  {k[:72]:72s} {us:9.1f} us  hbm-side {gb:7.3f} GB ({gb / us * 1e3 if us else 0:5.2f} TB/s)  '
                   f'rdreq {v.get("TCC_EA0_RDREQ_sum", 0) / 1e6:8.2f} M  L2 hit {100 * hit / req if req else 0:5.1f} %  '
                   f'wait {100 * v.get("SQ_WAIT_ANY", 0) / wc if wc else 0:5.1f} %  valu/wave {v.get("SQ_INSTS_VALU", 0) / max(v.get("SQ_WAVES", 1), 1):8.0f}')
 

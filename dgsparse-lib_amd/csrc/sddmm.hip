@@ -17,6 +17,7 @@
 
 #include "dgs_common.h"
 #include "sddmm_panel.h"
+#include "sddmm_fused.h"
 
 namespace dgs {
 
@@ -441,6 +442,39 @@ extern "C" int dgs_sddmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t F,
   if (reduce_op == DGS_MEAN) return run_sddmm<true, false>(M, K, F, nnz, rowptr, col, D1, D2, nullptr, out, st);
   if (reduce_op == DGS_SUM) return run_sddmm<false, false>(M, K, F, nnz, rowptr, col, D1, D2, nullptr, out, st);
   return DGS_EINVAL;
+}
+
+// SDDMM over the cached locality plan of (rowptr, col) (sddmm_fused.h).  Shapes the fused kernel does not cover - dense
+// graphs (column-panel schedule), feature widths that need several tiles or scalar lanes, tiny inputs - take the plan-free path.
+extern "C" int dgs_sddmm_csr_plan_f32(int reduce_op, int64_t M, int64_t K, int64_t F, int64_t nnz, const int32_t *rowptr,
+                                      const int32_t *col, const float *D1, const float *D2, float *out, const void *plan,
+                                      const dgsSpmmPlanInfo *info, dgsStream_t stream) {
+  if (reduce_op != DGS_SUM && reduce_op != DGS_MEAN) return DGS_EINVAL;
+  if (M < 0 || K < 0 || F < 0 || nnz < 0) return DGS_EINVAL;
+  if (M >= INT32_MAX || K >= INT32_MAX || F >= INT32_MAX || nnz >= INT32_MAX) return DGS_ERANGE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  bool fused = plan && info && M > 0 && nnz > 0 && F >= 32 && F <= 256 && F % 4 == 0 && rowptr && col && D1 && D2 && out &&
+               is_aligned16(plan) && is_aligned16(D1) && is_aligned16(D2) && !tiny_problem(M, nnz);
+  if (fused) {
+    const FeatMap fm = feat_map(F, true);
+    // worth it on hub-heavy graphs, where the units of the column-cut rows (n_pslots of them, ~64..256 nnz each) hold about a
+    // third of the nnz or more: 1M-row power-law graph (alpha 2.1) 493 -> 465 us; products-shaped (alpha 2.4, 0.0031 cut
+    // units per nnz) 2232 -> 2280 us, so that one stays on the nnz-balanced kernel.  DGS_SDDMM_FUSED=0/1 overrides.
+    const int force = sd_env_int("DGS_SDDMM_FUSED", -1);
+    fused = fm.tiles == 1 && fm.V == 4 && fm.G >= 8 && !sd_panel_plan(M, K, F, nnz, fm.tiles, fm.G, fm.V, false).use &&
+            force != 0 && (force == 1 || (int64_t)info->n_pslots * 256 >= nnz);
+    if (fused) {
+      const PlanHdr *ph = static_cast<const PlanHdr *>(plan);
+      const bool mean = reduce_op == DGS_MEAN;
+      switch (fm.G) {
+#define DGS_SF_CASE(g) case g: return mean ? launch_sddmm_fused<g, true>(M, F, nnz, rowptr, col, D1, D2, out, ph, info, st) \
+                                           : launch_sddmm_fused<g, false>(M, F, nnz, rowptr, col, D1, D2, out, ph, info, st);
+        DGS_SF_CASE(8) DGS_SF_CASE(16) DGS_SF_CASE(32) DGS_SF_CASE(64)
+#undef DGS_SF_CASE
+      }
+    }
+  }
+  return dgs_sddmm_csr_f32(reduce_op, M, K, F, nnz, rowptr, col, D1, D2, out, stream);
 }
 
 extern "C" int dgs_sddmm_csr_mask_f32(int64_t M, int64_t K, int64_t F, int64_t nnz, const int32_t *rowptr,

@@ -120,7 +120,8 @@ std::vector<Tensor> spmm_fwd(int op, const Tensor &rowptr_, const Tensor &col_, 
   return {out, E};
 }
 
-Tensor sddmm_impl(const Tensor &rowptr_, const Tensor &col_, const Tensor &D1_, const Tensor &D2_, int op, const Tensor &E) {
+Tensor sddmm_impl(const Tensor &rowptr_, const Tensor &col_, const Tensor &D1_, const Tensor &D2_, int op, const Tensor &E,
+                  const OptTensor &plan = c10::nullopt, const OptTensor &pinfo = c10::nullopt) {
   const Tensor rowptr = i32vec(rowptr_, "rowptr"), col = i32vec(col_, "col"), D1 = f32mat(D1_, "D1"), D2 = f32mat(D2_, "D2");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(D1.device());
   const int64_t M = rowptr.numel() - 1, nnz = col.numel(), F = D1.size(1);
@@ -143,9 +144,19 @@ Tensor sddmm_impl(const Tensor &rowptr_, const Tensor &col_, const Tensor &D1_, 
                                     D2.data_ptr<float>(), Ec.data_ptr<int>(), out.data_ptr<float>(), cur_stream()),
              "sddmm_mask");
   } else {
-    check_rc(dgs_sddmm_csr_f32(op, M, D2.size(0), F, nnz, rowptr.data_ptr<int>(), col.data_ptr<int>(), D1.data_ptr<float>(),
-                               D2.data_ptr<float>(), out.data_ptr<float>(), cur_stream()),
-             "sddmm");
+    const dgsSpmmPlanInfo *pi = (M > 0 && nnz > 0) ? plan_info(plan, pinfo, rowptr) : nullptr;
+    if (pi) {  // the forward plan of (rowptr, col): fused row-block / unit schedule where it applies (sddmm_fused.h)
+      TORCH_CHECK((size_t)plan->numel() >= (pi->off_long ? dgs_spmm_plan_compact_bytes(pi) : dgs_spmm_plan_bytes(M, D2.size(0), nnz)),
+                  "dgsparse: plan buffer too small for this matrix");
+      check_rc(dgs_sddmm_csr_plan_f32(op, M, D2.size(0), F, nnz, rowptr.data_ptr<int>(), col.data_ptr<int>(),
+                                      D1.data_ptr<float>(), D2.data_ptr<float>(), out.data_ptr<float>(), plan->data_ptr(), pi,
+                                      cur_stream()),
+               "sddmm (plan)");
+    } else {
+      check_rc(dgs_sddmm_csr_f32(op, M, D2.size(0), F, nnz, rowptr.data_ptr<int>(), col.data_ptr<int>(), D1.data_ptr<float>(),
+                                 D2.data_ptr<float>(), out.data_ptr<float>(), cur_stream()),
+               "sddmm");
+    }
   }
   return out;
 }
@@ -211,9 +222,10 @@ struct SpMM : public torch::autograd::Function<SpMM<OP>> {
     ctx->saved_data["algorithm"] = algorithm;
     const Tensor none;
     tensor_list sv = {rowptr, col, values, colptr, row, csr2csc, dense, (OP == DGS_MAX || OP == DGS_MIN) ? out[1] : none,
-                      has(tvalues) ? *tvalues : none, has(plan_t) ? *plan_t : none};
+                      has(tvalues) ? *tvalues : none, has(plan_t) ? *plan_t : none, has(plan) ? *plan : none};
     ctx->save_for_backward(sv);
     if (has(pinfo_t)) ctx->saved_data["pinfo_t"] = *pinfo_t;  // CPU tensor: plain data, not a graph input
+    if (has(pinfo)) ctx->saved_data["pinfo"] = *pinfo;        // the forward plan serves the SDDMM of the value gradient
     return out[0];
   }
 
@@ -228,6 +240,11 @@ struct SpMM : public torch::autograd::Function<SpMM<OP>> {
     if (saved[9].defined() && ctx->saved_data.count("pinfo_t")) {
       plan_t = saved[9];
       pinfo_t = ctx->saved_data["pinfo_t"].toTensor();
+    }
+    OptTensor plan_f, pinfo_f;
+    if (saved[10].defined() && ctx->saved_data.count("pinfo")) {
+      plan_f = saved[10];
+      pinfo_f = ctx->saved_data["pinfo"].toTensor();
     }
     auto tv = [&]() { return saved[8].defined() ? saved[8] : t_values(values, csr2csc, has_value); };
     TORCH_CHECK(grad_out.dim() == 2 && grad_out.size(0) == rowptr.numel() - 1 && grad_out.size(1) == dense.size(1),
@@ -257,13 +274,13 @@ struct SpMM : public torch::autograd::Function<SpMM<OP>> {
         if (need_d) grad_dense = spmm_mask_impl(colptr, row, tv(), has_value, grad_out, E, dense.size(0));
       }
     } else if (OP == DGS_MEAN) {
-      if (need_v) grad_value = sddmm_impl(rowptr, col, grad_out, dense, DGS_MEAN, Tensor()).view_as(values);
+      if (need_v) grad_value = sddmm_impl(rowptr, col, grad_out, dense, DGS_MEAN, Tensor(), plan_f, pinfo_f).view_as(values);
       if (need_d) {  // A^T diag(1/deg) dC: scale grad rows by 1/deg(source row), then a plain transposed SpMM
         const Tensor deg = (rowptr.slice(0, 1) - rowptr.slice(0, 0, -1)).clamp_min(1).to(at::kFloat);
         grad_dense = pad_rows(spmm_fwd(DGS_SUM, colptr, row, tv(), grad_out / deg.unsqueeze(1), has_value, algorithm, plan_t, pinfo_t)[0], dense.size(0));
       }
     } else {
-      if (need_v) grad_value = sddmm_impl(rowptr, col, grad_out, dense, DGS_SUM, Tensor()).view_as(values);
+      if (need_v) grad_value = sddmm_impl(rowptr, col, grad_out, dense, DGS_SUM, Tensor(), plan_f, pinfo_f).view_as(values);
       if (need_d) grad_dense = pad_rows(spmm_fwd(DGS_SUM, colptr, row, tv(), grad_out, has_value, algorithm, plan_t, pinfo_t)[0], dense.size(0));
     }
     return {Tensor(), Tensor(), grad_value, Tensor(), Tensor(), Tensor(), grad_dense, Tensor(), Tensor(),

@@ -84,6 +84,8 @@ _lib.dgs_sddmm_csr_schedule.restype = _int
 _lib.dgs_sddmm_csr_schedule.argtypes = [_i64, _i64, _i64, _i64, _int]
 _lib.dgs_sddmm_csr_f32.restype = _int
 _lib.dgs_sddmm_csr_f32.argtypes = [_int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]
+_lib.dgs_sddmm_csr_plan_f32.restype = _int
+_lib.dgs_sddmm_csr_plan_f32.argtypes = [_int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(PlanInfo), _vp]
 _lib.dgs_sddmm_csr_mask_f32.restype = _int
 _lib.dgs_sddmm_csr_mask_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
 _lib.dgs_csr2csc_workspace_bytes.restype = _sz
@@ -109,7 +111,7 @@ EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_by
            'dgs_spmm_plan_thresholds', 'dgs_spmm_plan_provisional_info', 'dgs_spmm_csr_plan_workspace_bytes',
            'dgs_spmm_csr_plan_f32', 'dgs_spmm_csr_acc_f32', 'dgs_spmm_csr_acc_max_f32',
            'dgs_spmm_csr_schedule', 'dgs_spmm_arg_backward_f32', 'dgs_sddmm_csr_schedule',
-           'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
+           'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_plan_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
            'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'dgs_relabel_i32', 'dgs_sddmm_coo_f32', 'dgs_gspmm_csr_workspace_bytes', 'dgs_gspmm_csr_f32', 'gespmmCsrSpMM',
            'spmm_cuda', 'spmm_cuda_no_edge_value', 'sddmm_cuda_csr', 'sddmm_cuda_coo', 'gespmmAlgSel',
            'csrspmm_parreduce_rowbalance', 'csrspmm_parreduce_nnzbalance', 'csrspmm_seqreduce_rowbalance',
@@ -426,8 +428,9 @@ def spmm_arg_backward(rowptr, col, values, E, grad, dense, need_dense=True, need
     return gX, gW
 
 
-def sddmm(rowptr, col, D1, D2, reduce_op=SUM, E=None):
-    """out[e] = <D1[row(e)], D2[col(e)]> (mean-scaled / arg-masked variants)."""
+def sddmm(rowptr, col, D1, D2, reduce_op=SUM, E=None, plan=None):
+    """out[e] = <D1[row(e)], D2[col(e)]> (mean-scaled / arg-masked variants).  ``plan``: the SpmmPlan of exactly these
+    (rowptr, col) arrays (the unmasked product then takes the fused row-block / unit schedule where it applies)."""
     dev = _need_gpu(rowptr, col, D1, D2, E)
     rowptr = _i32(rowptr, 'rowptr')
     col = _i32(col, 'col')
@@ -444,8 +447,14 @@ def sddmm(rowptr, col, D1, D2, reduce_op=SUM, E=None):
             Ep[:, :F] = E
         return sddmm(rowptr, col, _pad4(D1), _pad4(D2), reduce_op, Ep)
     out = torch.empty(nnz, dtype=torch.float32, device=dev)
+    if plan is not None and (plan.M != M or plan.nnz != nnz or plan.col_ptr != col.data_ptr() or
+                             plan.rowptr_ptr != rowptr.data_ptr()):
+        raise ValueError('dgsparse: the plan was built for other (rowptr, col) arrays')
     with _on_device(dev):
-        if E is not None:
+        if E is None and plan is not None:
+            _check(_lib.dgs_sddmm_csr_plan_f32(reduce_op, M, D2.shape[0], F, nnz, _p(rowptr), _p(col), _p(D1), _p(D2),
+                                               _p(out), _p(plan.buf), ctypes.byref(plan.info), _stream(dev)), 'sddmm_plan')
+        elif E is not None:
             if E.dtype != torch.int32 or E.shape != D1.shape:
                 raise TypeError('dgsparse: E must be int32 with the shape of D1')
             _check(_lib.dgs_sddmm_csr_mask_f32(M, D2.shape[0], F, nnz, _p(rowptr), _p(col), _p(D1), _p(D2),

@@ -205,6 +205,15 @@ int dgs_sddmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t F, int64_t nn
                       const int32_t *rowptr, const int32_t *col, const float *D1, const float *D2,
                       float *out, dgsStream_t stream);
 
+/* The same product over the cached locality plan of (rowptr, col) - the plan dgs_spmm_plan_build makes for the SpMM, whose
+ * backward w.r.t. the edge values this SDDMM is (src/spmm.cpp:52-80): rows up to 64 nnz in row blocks (the D1 slice is read
+ * once per row, not once per nnz), longer rows as the plan's units in column-slice order, one slice per XCD; no workspace.
+ * plan / info as for dgs_spmm_csr_plan_f32 (provisional info included).  Shapes the fused kernel does not cover (dense graphs
+ * on the column-panel schedule, F outside 32..256 or not a multiple of 4, tiny inputs) silently take dgs_sddmm_csr_f32. */
+int dgs_sddmm_csr_plan_f32(int reduce_op, int64_t M, int64_t K, int64_t F, int64_t nnz, const int32_t *rowptr,
+                           const int32_t *col, const float *D1, const float *D2, float *out, const void *plan,
+                           const dgsSpmmPlanInfo *info, dgsStream_t stream);
+
 /* Which schedule dgs_sddmm_csr_f32 / dgs_sddmm_csr_mask_f32 (masked != 0) take for these sizes with 16-byte aligned
  * operands: DGS_SCHED_ROWS (nnz-balanced kernel) or DGS_SCHED_PANEL (column-panel sweep, dense graphs).  Introspection,
  * no reference counterpart; see dgs_spmm_csr_schedule. */

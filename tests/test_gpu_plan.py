@@ -320,3 +320,52 @@ def test_wide_rows_run_as_64_float_feature_passes_on_large_operands(capi, N):
     assert_sum_parity(gX, ref, oracle.spmm_mask_f64(colptr, row, tval, G, Emax),
                       oracle.spmm_mask_f64(colptr, row, tval, G, Emax, absval=True), RTOL, ATOL, f'N={N} masked product',
                       lens=np.diff(colptr))
+
+
+@pytest.mark.parametrize('F', [32, 64, 128, 256])
+@pytest.mark.parametrize('mean', [False, True])
+def test_sddmm_over_the_plan_vs_oracle(capi, F, mean, monkeypatch):
+    """SDDMM on the fused row-block / unit schedule (csrc/sddmm_fused.h) over the SpMM plan of the same arrays: every nnz
+    written exactly once, within 1e-5 of the sequential host loop (the reference's bar, sddmm_reference_host), for graphs
+    with empty rows, short rows, rows on both sides of the unit threshold and hub rows cut on the column grid."""
+    import oracle
+    monkeypatch.setenv('DGS_SDDMM_FUSED', '1')  # the dispatch rule would send a graph this small elsewhere on some seeds
+    rp, col, st = graphgen.powerlaw_csr(60000, 900000, alpha=1.9, dmax=15000, seed=21)
+    deg = np.diff(rp)
+    assert (deg == 0).any() and (deg > 256).any() and ((deg > 64) & (deg <= 256)).any()
+    M, K = st['M'], st['K']
+    D1 = graphgen.features(M, F, 31) - 0.4
+    D2 = graphgen.features(K, F, 32) - 0.6
+    d = 'cuda'
+    rpt, colt = torch.from_numpy(rp).to(d), torch.from_numpy(col).to(d)
+    plan = capi.spmm_plan(rpt, colt, K, F, force=True)
+    assert plan is not None
+    out = torch.full((col.shape[0],), float('nan'), device=d)
+    got = capi.sddmm(rpt, colt, torch.from_numpy(D1).to(d), torch.from_numpy(D2).to(d), reduce_op=capi.MEAN if mean else capi.SUM,
+                     plan=plan)
+    assert got.shape == out.shape and not torch.isnan(got).any()
+    ref = oracle.sddmm(rp, col, D1, D2, reduce='mean' if mean else 'sum', threads=oracle.max_threads())
+    S = oracle.sddmm(rp, col, np.abs(D1), np.abs(D2), reduce='mean' if mean else 'sum', threads=oracle.max_threads())
+    err = np.abs(got.cpu().numpy().astype(np.float64) - ref)
+    assert (err <= 1e-5 * np.abs(ref) + 2e-6 * np.maximum(S, 1e-3)).all(), f'max err {err.max()}'
+    free = capi.sddmm(rpt, colt, torch.from_numpy(D1).to(d), torch.from_numpy(D2).to(d), reduce_op=capi.MEAN if mean else capi.SUM)
+    assert torch.allclose(got, free, rtol=1e-5, atol=2e-5)
+
+
+def test_sddmm_plan_unsorted_and_duplicate_columns(capi, monkeypatch):
+    import oracle
+    monkeypatch.setenv('DGS_SDDMM_FUSED', '1')
+    rng = np.random.default_rng(5)
+    M, K, F = 30000, 30000, 64
+    deg = np.minimum(rng.zipf(1.6, M), 9000)
+    deg[rng.integers(0, M, 2000)] = 0
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    col = rng.integers(0, K, rp[-1]).astype(np.int32)  # unsorted, with duplicates
+    D1 = rng.random((M, F), dtype=np.float32)
+    D2 = rng.random((K, F), dtype=np.float32)
+    d = 'cuda'
+    rpt, colt = torch.from_numpy(rp).to(d), torch.from_numpy(col).to(d)
+    plan = capi.spmm_plan(rpt, colt, K, F, force=True)
+    got = capi.sddmm(rpt, colt, torch.from_numpy(D1).to(d), torch.from_numpy(D2).to(d), plan=plan)
+    ref = oracle.sddmm(rp, col, D1, D2, threads=oracle.max_threads())
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
