@@ -118,6 +118,46 @@ EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_by
            'csrspmm_seqreduce_nnzbalance', 'csrspmm_rowcaching_rowbalance', 'csrspmm_rowcaching_nnzbalance']
 
 
+# ---- DGS_CANARY=1 (debug): every output and workspace this module allocates sits between two 4 KiB guard bands of a
+# known pattern; canary_check() synchronises and verifies them.  The library writes through raw pointers into caller-sized
+# buffers, so an overrun would otherwise be silent (tests/fuzz_gpu.py runs its campaigns with it).
+_CANARY = os.environ.get('DGS_CANARY') == '1'
+_GUARD, _PATTERN = 4096, 0xA5
+_guarded = []
+
+
+def _new(shape, dtype=torch.float32, device=None):
+    if not _CANARY:
+        return torch.empty(shape, dtype=dtype, device=device)
+    shape = (shape,) if isinstance(shape, int) else tuple(shape)
+    n = 1
+    for d in shape:
+        n *= int(d)
+    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    flat = torch.full((_GUARD + nbytes + _GUARD,), _PATTERN, dtype=torch.uint8, device=device)
+    _guarded.append((flat, nbytes))
+    return flat[_GUARD:_GUARD + nbytes].view(dtype).view(shape)
+
+
+def canary_check(what=''):
+    """Verifies (and forgets) the guard bands of everything allocated since the last check; no-op without DGS_CANARY=1."""
+    if not _guarded:
+        return 0
+    torch.cuda.synchronize()
+    n = len(_guarded)
+    for flat, nbytes in _guarded:
+        lo, hi = flat[:_GUARD], flat[_GUARD + nbytes:]
+        if not (bool((lo == _PATTERN).all()) and bool((hi == _PATTERN).all())):
+            bad_lo = int((lo != _PATTERN).sum())
+            bad_hi = int((hi != _PATTERN).sum())
+            first_hi = int((hi != _PATTERN).nonzero()[0]) if bad_hi else -1
+            _guarded.clear()
+            raise AssertionError(f'dgsparse canary: {what}: buffer of {nbytes} bytes overrun: {bad_lo} guard bytes changed '
+                                 f'below it, {bad_hi} above (first at +{first_hi})')
+    _guarded.clear()
+    return n
+
+
 def version() -> int:
     return int(_lib.dgs_version())
 
@@ -254,14 +294,14 @@ def spmm_plan(rowptr, col, K, N=64, force=False):
     with _on_device(dev):
         pb = _lib.dgs_spmm_plan_bytes(M, int(K), nnz)
         wb = _lib.dgs_spmm_plan_workspace_bytes(M, int(K), nnz)
-        buf = torch.empty(pb, dtype=torch.uint8, device=dev)
-        ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+        buf = _new(pb, dtype=torch.uint8, device=dev)
+        ws = _new(wb, dtype=torch.uint8, device=dev)
         info = PlanInfo()
         _check(_lib.dgs_spmm_plan_build(M, int(K), nnz, _p(rowptr), _p(col), _p(buf), pb, _p(ws), wb,
                                         ctypes.byref(info), _stream(dev)), 'spmm_plan_build')
         # the build buffer is sized for the worst case (~2.9 B per nnz); keep a copy that is as large as the tables
         cb = _lib.dgs_spmm_plan_compact_bytes(ctypes.byref(info))
-        small = torch.empty(cb, dtype=torch.uint8, device=dev)
+        small = _new(cb, dtype=torch.uint8, device=dev)
         _check(_lib.dgs_spmm_plan_compact(_p(buf), ctypes.byref(info), _p(small), cb, nnz, _stream(dev)), 'spmm_plan_compact')
     return SpmmPlan(small, info, M, int(K), nnz, rowptr.data_ptr(), col.data_ptr())
 
@@ -284,8 +324,8 @@ def spmm(reduce_op, rowptr, col, values, dense, algorithm=0, want_E=None, plan=N
         return C[:, :N].contiguous(), (None if E is None else E[:, :N].contiguous())
     values = _f32vec(values, 'values', nnz)
     arg = reduce_op in (MAX, MIN) if want_E is None else want_E
-    out = torch.empty((M, N), dtype=torch.float32, device=dev)
-    E = torch.empty((M, N), dtype=torch.int32, device=dev) if arg else None
+    out = _new((M, N), dtype=torch.float32, device=dev)
+    E = _new((M, N), dtype=torch.int32, device=dev) if arg else None
     if plan is not None and (plan.M != M or plan.nnz != nnz or plan.col_ptr != col.data_ptr() or
                              plan.rowptr_ptr != rowptr.data_ptr()):
         raise ValueError('dgsparse: the plan was built for other (rowptr, col) arrays')
@@ -293,13 +333,13 @@ def spmm(reduce_op, rowptr, col, values, dense, algorithm=0, want_E=None, plan=N
         strict = (int(algorithm) & (ALG_STRICT_SUM | ALG_STRICT_NOFMA)) and reduce_op in (SUM, MEAN)
         if plan is not None and not strict and _lib.dgs_spmm_csr_schedule(int(reduce_op), M, K, N, nnz) == 1:
             wsb = _lib.dgs_spmm_csr_plan_workspace_bytes(reduce_op, M, N, nnz, ctypes.byref(plan.info))
-            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            ws = _new(wsb, dtype=torch.uint8, device=dev)
             _check(_lib.dgs_spmm_csr_plan_f32(reduce_op, M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(dense),
                                               _p(out), _p(E), _p(plan.buf), ctypes.byref(plan.info), _p(ws), wsb,
                                               _stream(dev)), 'spmm_plan')
             return out, E
         wsb = _lib.dgs_spmm_csr_workspace_bytes(reduce_op, M, N, nnz)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        ws = _new(wsb, dtype=torch.uint8, device=dev) if wsb else None
         _check(_lib.dgs_spmm_csr_f32(reduce_op, M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(dense), _p(out),
                                      _p(E), int(algorithm), _p(ws), wsb, _stream(dev)), 'spmm')
     return out, E
@@ -330,7 +370,7 @@ def spmm_acc(rowptr, col, values, dense, C, rowmap=None, plan=None):
             wsb = _lib.dgs_spmm_csr_plan_workspace_bytes(SUM, M, N, nnz, ctypes.byref(plan.info))
         else:
             wsb = _lib.dgs_spmm_csr_workspace_bytes(SUM, M, N, nnz)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        ws = _new(wsb, dtype=torch.uint8, device=dev) if wsb else None
         _check(_lib.dgs_spmm_csr_acc_f32(M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(dense), _p(C), _p(rowmap),
                                          _p(plan.buf) if plan is not None else None,
                                          ctypes.byref(plan.info) if plan is not None else None, _p(ws), wsb, _stream(dev)),
@@ -366,7 +406,7 @@ def spmm_acc_max(rowptr, col, values, dense, C, E, rowmap=None, col_off=0, n_loc
             wsb = _lib.dgs_spmm_csr_plan_workspace_bytes(MAX, M, N, nnz, ctypes.byref(plan.info))
         else:
             wsb = _lib.dgs_spmm_csr_workspace_bytes(MAX, M, N, nnz)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        ws = _new(wsb, dtype=torch.uint8, device=dev) if wsb else None
         _check(_lib.dgs_spmm_csr_acc_max_f32(M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(dense), _p(C), _p(E),
                                              _p(rowmap), int(col_off), int(n_local), int(h_lo),
                                              _p(plan.buf) if plan is not None else None,
@@ -396,12 +436,12 @@ def spmm_mask(ptr, idx, values, grad, E, n_out=None):
     Mo, nnz, (Mi, N) = ptr.numel() - 1, idx.numel(), grad.shape
     values = _f32vec(values, 'values', nnz)
     rows = Mo if n_out is None else max(int(n_out), Mo)
-    out = torch.empty((rows, N), dtype=torch.float32, device=dev)
+    out = _new((rows, N), dtype=torch.float32, device=dev)
     if rows > Mo:
         out[Mo:].zero_()
     with _on_device(dev):
         wsb = _lib.dgs_spmm_csr_mask_workspace_bytes(Mo, N, nnz)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        ws = _new(wsb, dtype=torch.uint8, device=dev) if wsb else None
         _check(_lib.dgs_spmm_csr_mask_f32(Mo, Mi, N, nnz, _p(ptr), _p(idx), _p(values), _p(grad), _p(E), _p(out),
                                           _p(ws), wsb, _stream(dev)), 'spmm_mask')
     return out
@@ -420,8 +460,8 @@ def spmm_arg_backward(rowptr, col, values, E, grad, dense, need_dense=True, need
         raise TypeError('dgsparse: E must be int32 [M,N] and grad float32 [M,N]')
     E = E.contiguous()
     values = _f32vec(values, 'values', nnz)
-    gX = torch.empty((K, N), dtype=torch.float32, device=dev) if need_dense else None
-    gW = torch.empty(nnz, dtype=torch.float32, device=dev) if (need_values and values is not None) else None
+    gX = _new((K, N), dtype=torch.float32, device=dev) if need_dense else None
+    gW = _new(nnz, dtype=torch.float32, device=dev) if (need_values and values is not None) else None
     with _on_device(dev):
         _check(_lib.dgs_spmm_arg_backward_f32(M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(E), _p(grad), _p(dense),
                                               _p(gX), _p(gW), _stream(dev)), 'spmm_arg_backward')
@@ -446,7 +486,7 @@ def sddmm(rowptr, col, D1, D2, reduce_op=SUM, E=None, plan=None):
             Ep = torch.full((E.shape[0], (F + 3) & ~3), -1, dtype=torch.int32, device=dev)
             Ep[:, :F] = E
         return sddmm(rowptr, col, _pad4(D1), _pad4(D2), reduce_op, Ep)
-    out = torch.empty(nnz, dtype=torch.float32, device=dev)
+    out = _new(nnz, dtype=torch.float32, device=dev)
     if plan is not None and (plan.M != M or plan.nnz != nnz or plan.col_ptr != col.data_ptr() or
                              plan.rowptr_ptr != rowptr.data_ptr()):
         raise ValueError('dgsparse: the plan was built for other (rowptr, col) arrays')
@@ -473,10 +513,10 @@ def gspmm(reduce_op, compute_op, rowptr, col, values, dense):
     dense = _f32mat(dense, 'dense')
     M, nnz, (K, N) = rowptr.numel() - 1, col.numel(), dense.shape
     values = _f32vec(values, 'values', nnz)
-    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    out = _new((M, N), dtype=torch.float32, device=dev)
     with _on_device(dev):
         wsb = _lib.dgs_gspmm_csr_workspace_bytes(reduce_op, compute_op, M, N, nnz)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        ws = _new(wsb, dtype=torch.uint8, device=dev) if wsb else None
         _check(_lib.dgs_gspmm_csr_f32(reduce_op, compute_op, M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(dense),
                                       _p(out), _p(ws), wsb, _stream(dev)), 'gspmm')
     return out
@@ -491,7 +531,7 @@ def sddmm_coo(rowind, colind, D1, D2):
     D2 = _f32mat(D2, 'D2')
     if rowind.numel() != colind.numel() or D1.shape[1] != D2.shape[1]:
         raise ValueError('dgsparse: sddmm_coo shape mismatch')
-    out = torch.empty(rowind.numel(), dtype=torch.float32, device=dev)
+    out = _new(rowind.numel(), dtype=torch.float32, device=dev)
     with _on_device(dev):
         _check(_lib.dgs_sddmm_coo_f32(D1.shape[1], rowind.numel(), _p(rowind), _p(colind), _p(D1), _p(D2), _p(out),
                                       _stream(dev)), 'sddmm_coo')
@@ -505,13 +545,13 @@ def csr2csc(rowptr, col, values, n_cols, want_perm=True):
     col = _i32(col, 'col')
     M, nnz = rowptr.numel() - 1, col.numel()
     values = _f32vec(values, 'values', nnz)
-    colptr = torch.empty(n_cols + 1, dtype=torch.int32, device=dev)
-    row = torch.empty(nnz, dtype=torch.int32, device=dev)
-    cscval = torch.empty(nnz, dtype=torch.float32, device=dev) if values is not None else None
-    perm = torch.empty(nnz, dtype=torch.int32, device=dev) if want_perm else None
+    colptr = _new(n_cols + 1, dtype=torch.int32, device=dev)
+    row = _new(nnz, dtype=torch.int32, device=dev)
+    cscval = _new(nnz, dtype=torch.float32, device=dev) if values is not None else None
+    perm = _new(nnz, dtype=torch.int32, device=dev) if want_perm else None
     with _on_device(dev):
         wsb = _lib.dgs_csr2csc_workspace_bytes(M, n_cols, nnz)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        ws = _new(wsb, dtype=torch.uint8, device=dev)
         _check(_lib.dgs_csr2csc_i32(M, n_cols, nnz, _p(rowptr), _p(col), _p(values), _p(colptr), _p(row), _p(cscval),
                                     _p(perm), _p(ws), wsb, _stream(dev)), 'csr2csc')
     return colptr, row, cscval, perm
@@ -521,7 +561,7 @@ def gather_rows(src, ids):
     dev = _need_gpu(src, ids)
     src = _f32mat(src, 'src')
     ids = _i32(ids, 'ids')
-    out = torch.empty((ids.numel(), src.shape[1]), dtype=torch.float32, device=dev)
+    out = _new((ids.numel(), src.shape[1]), dtype=torch.float32, device=dev)
     with _on_device(dev):
         _check(_lib.dgs_gather_rows_f32(ids.numel(), src.shape[1], _p(ids), _p(src), _p(out), _stream(dev)), 'gather')
     return out

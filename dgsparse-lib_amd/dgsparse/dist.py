@@ -56,14 +56,34 @@ class RowPartition:
         return int(self.col.numel())
 
 
-def partition_csr(rowptr, col, val, world: int) -> List[RowPartition]:
-    """Split a global CSR (numpy or torch, square) into ``world`` contiguous equal row blocks."""
+def row_offsets(rowptr, world: int, balance: str = 'rows') -> List[int]:
+    """Boundaries of ``world`` CONTIGUOUS row blocks.  'rows': equal row counts.  'nnz': block g ends at the first row
+    whose prefix nnz reaches (g + 1) * nnz / world - on a power-law graph in a degree-correlated order equal row blocks
+    give one rank the hubs (the reference's own load-balance idea, nnz-balanced work: src/ge-spmm/
+    csrspmm_rowcaching.cu:121-294, applied to the partition).  The rows of B and C follow the same boundaries."""
+    rowptr = torch.as_tensor(rowptr)
+    M = rowptr.numel() - 1
+    if balance == 'rows':
+        per = (M + world - 1) // world
+        return [min(M, i * per) for i in range(world + 1)]
+    if balance != 'nnz':
+        raise ValueError(balance)
+    nnz = int(rowptr[-1])
+    targets = torch.tensor([(nnz * g) // world for g in range(1, world)], dtype=rowptr.dtype, device=rowptr.device)
+    cuts = torch.searchsorted(rowptr.contiguous(), targets, right=False).clamp_(0, M).tolist() if world > 1 else []
+    offs = [0] + [int(c) for c in cuts] + [M]
+    for i in range(1, len(offs)):  # monotone even with runs of empty rows
+        offs[i] = max(offs[i], offs[i - 1])
+    return offs
+
+
+def partition_csr(rowptr, col, val, world: int, balance: str = 'rows') -> List[RowPartition]:
+    """Split a global CSR (numpy or torch, square) into ``world`` contiguous row blocks: equal row counts
+    (``balance='rows'``) or equal nnz (``'nnz'``, see row_offsets)."""
     rowptr = torch.as_tensor(rowptr)
     col = torch.as_tensor(col)
     val = None if val is None else torch.as_tensor(val)
-    M = rowptr.numel() - 1
-    per = (M + world - 1) // world
-    offs = [min(M, i * per) for i in range(world + 1)]
+    offs = row_offsets(rowptr, world, balance)
     parts = []
     for r in range(world):
         s, e = int(rowptr[offs[r]]), int(rowptr[offs[r + 1]])
@@ -270,6 +290,22 @@ class DistSpMM:
         self.last_E = None       # global column ids of the last max/min
         self.last_E_ext = None   # the same in the extended index space (what the backward needs)
 
+    def imbalance(self) -> dict:
+        """Per-rank load figures gathered over the group: nnz, rows, halo rows in, feature rows out (max / mean = the
+        imbalance a step waits for).  Collective (one small all_gather); standalone engines report themselves only."""
+        p, plan = self.part, self.plan
+        mine = torch.tensor([p.nnz, p.n_local, self.n_halo, int(plan.send_ids.numel())], dtype=torch.int64,
+                            device=p.col.device)
+        if p.world > 1 and not self.standalone:
+            allv = [torch.empty_like(mine) for _ in range(p.world)]
+            dist.all_gather(allv, mine, group=self.group)
+            t = torch.stack(allv).double()
+        else:
+            t = mine.double()[None]
+        names = ('nnz', 'rows', 'halo_rows_in', 'rows_out')
+        return {n: dict(max=int(t[:, i].max()), mean=float(t[:, i].mean()),
+                        max_over_mean=round(float(t[:, i].max() / max(t[:, i].mean(), 1.0)), 3)) for i, n in enumerate(names)}
+
     def local_features(self) -> torch.Tensor:
         """View of the first n_local rows of the exchange buffer: fill it in place to skip the copy in spmm()."""
         return self.B_ext[:self.part.n_local]
@@ -361,6 +397,24 @@ class DistSpMM:
                 off += n
         return g_loc
 
+    def _send_halo_grads(self, g_halo: torch.Tensor):
+        """Starts the reversed all-to-all-v of the halo rows' gradients; returns (receive buffer, work handle)."""
+        plan = self.plan
+        back = torch.empty((int(plan.send_ids.numel()), g_halo.shape[1]), dtype=torch.float32, device=g_halo.device)
+        self._g_halo = g_halo.contiguous()  # kept alive until waited
+        work = dist.all_to_all_single(back, self._g_halo, plan.send_splits, plan.recv_splits, group=self.group, async_op=True)
+        return back, work
+
+    def _add_halo_grads(self, g_loc: torch.Tensor, back: torch.Tensor, work) -> torch.Tensor:
+        if work is not None:
+            work.wait()
+        off = 0
+        for n in self.plan.send_splits:  # one peer at a time, fixed order: deterministic
+            if n:
+                self.ops.scatter_add_rows(g_loc, self.plan.send_ids[off:off + n].contiguous(), back[off:off + n].contiguous())
+            off += n
+        return g_loc
+
     def spmm_sum_backward_dense(self, grad_C: torch.Tensor) -> torch.Tensor:
         """grad w.r.t. this rank's rows of B for the sum product: A_ext^T grad_C, halo parts sent home."""
         return self.backward(grad_C, 'sum', need_values=False)[0]
@@ -394,8 +448,23 @@ class DistSpMM:
             g_val = self.ops.sddmm(p.rowptr, self.plan.col_ext, grad_C, B_ext)
         if need_dense:
             colptr, row, tval = self._transposed(None if val is p.val else val)
-            g_ext, _ = self.ops.spmm(0, colptr, row, tval, grad_C)  # [n_local + n_halo, N]
-            g_loc = self._return_halo_grads(g_ext)
+            if self.overlap and p.world > 1 and not self.standalone and self.n_halo > 0:
+                # rows of A_ext^T = extended columns [local | halo slots], contiguous in the CSC arrays: the halo rows first,
+                # their gradients start home (reversed all-to-all-v) while the local rows are computed, then the scatter-add
+                nl = p.n_local
+                if getattr(self, '_csc_cut', None) is None:
+                    self._csc_cut = int(colptr[nl])  # once per engine
+                    self._colptr_halo = (colptr[nl:] - self._csc_cut).contiguous()
+                    self._colptr_loc = colptr[:nl + 1].contiguous()
+                cut = self._csc_cut
+                g_h, _ = self.ops.spmm(0, self._colptr_halo, row[cut:], None if tval is None else tval[cut:], grad_C)
+                back, work = self._send_halo_grads(g_h)
+                g_loc, _ = self.ops.spmm(0, self._colptr_loc, row[:cut], None if tval is None else tval[:cut], grad_C,
+                                         shared_gpu=True)
+                g_loc = self._add_halo_grads(g_loc.contiguous(), back, work)
+            else:
+                g_ext, _ = self.ops.spmm(0, colptr, row, tval, grad_C)  # [n_local + n_halo, N]
+                g_loc = self._return_halo_grads(g_ext)
         return g_loc, g_val
 
 

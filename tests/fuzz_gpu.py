@@ -58,6 +58,12 @@ def one_case(rng, it):
         else:
             sc = 1 if reduce == 'sum' else np.maximum(np.diff(rp), 1)[:, None]
             assert_sum_parity(C, Co, C64 / sc, S64 / sc, 1e-5, 2e-6, tag + ' ' + reduce, lens=np.diff(rp))
+            # round 3: the strict-order schedule is bit-exact against its sequential chain for every row length
+            for alg, fma in ((capi.ALG_STRICT_SUM, True), (capi.ALG_STRICT_NOFMA, False)):
+                if rng.integers(0, 2):
+                    Cs, _ = capi.spmm(oracle.REDUCE[reduce], drp, dcol, dval, dX, algorithm=alg)
+                    assert_bitexact(Cs.cpu().numpy(), oracle.spmm(reduce, rp, col, val, X, fma=fma)[0], tag + f' strict {reduce} fma={fma}')
+    capi.canary_check(tag + ' spmm')
     if col.shape[0] and M > 1 and rng.integers(0, 2) == 0:
         # round-2 entries: a forced locality plan must reproduce the plan-free results (max/min + E bit for bit, sum within
         # the bar), the accumulating sum adds into what C holds, the accumulating max merges a column split exactly
@@ -71,6 +77,15 @@ def one_case(rng, it):
                 else:
                     assert_bitexact(C.cpu().numpy(), Co, tag + ' plan ' + reduce)
                     assert_bitexact(E.cpu().numpy(), Eo, tag + ' plan E ' + reduce)
+            if N % 4 == 0 and 32 <= N <= 256:  # round 3: SDDMM on the fused row-block / unit schedule over the same plan
+                os.environ['DGS_SDDMM_FUSED'] = '1'
+                D1p = (rng.integers(-3, 4, (M, N)) / 8).astype(np.float32)
+                for mean in (False, True):
+                    got = capi.sddmm(drp, dcol, dev(D1p), dX, reduce_op=capi.MEAN if mean else capi.SUM, plan=plan)
+                    assert_close(got.cpu().numpy(), oracle.sddmm(rp, col, D1p, X, reduce='mean' if mean else 'sum', fma=True), 1e-5, 1e-5,
+                                 tag + f' sddmm over the plan mean={mean}')
+                os.environ.pop('DGS_SDDMM_FUSED', None)
+        capi.canary_check(tag + ' plan')
         C0 = (rng.integers(-4, 5, (M, N)) / 4).astype(np.float32)
         Cacc = dev(C0)
         capi.spmm_acc(drp, dcol, dval, dX, Cacc, None, plan=plan)
@@ -135,6 +150,7 @@ def one_case(rng, it):
         if val is not None:
             assert_close(aW.cpu().numpy(), oracle.sddmm_mask(rp, col, D1, X, Emax, fma=True), 1e-5, 1e-5,
                          tag + ' arg_backward gW')
+    capi.canary_check(tag + ' sddmm / csr2csc / backward')
     return tag
 
 
@@ -148,7 +164,7 @@ def main():
         it += 1
         if it % 50 == 0:
             print(f'{it} cases ok, {time.time() - t0:.0f} s, last: {tag}', flush=True)
-    print(f'FUZZ OK: {it} cases in {time.time() - t0:.0f} s (seed {seed})')
+    print(f'FUZZ OK: {it} cases in {time.time() - t0:.0f} s (seed {seed}, canaries {"on" if capi._CANARY else "off"})')
 
 
 if __name__ == '__main__':

@@ -148,6 +148,25 @@ def _worker(rank, world, port, cols, q):
                 res[key] = bool(np.allclose(Bl.grad.numpy(), gB[r0:r1], rtol=1e-5, atol=2e-6) and
                                 np.allclose(vl.grad.numpy(), gW[s0:s1], rtol=1e-5, atol=2e-6))
         del row_of
+        # nnz-balanced contiguous boundaries: every reduce again on that partition (rows of B and C follow the boundaries)
+        offs = dd.row_offsets(torch.from_numpy(rp), world, 'nnz')
+        shares = [int(rp[offs[i + 1]] - rp[offs[i]]) for i in range(world)]
+        res['nnz_balanced_cut'] = offs[0] == 0 and offs[-1] == M and max(shares) - min(shares) <= 2 * int(np.diff(rp).max())
+        partb = dd.partition_csr(rp, col, val, world, balance='nnz')[rank]
+        b0, b1 = partb.row_offsets[rank], partb.row_offsets[rank + 1]
+        engb = dd.DistSpMM(partb, N, ops=OracleOps(), overlap=True)
+        for red in ('sum', 'max', 'min'):
+            Cb = engb.spmm(torch.from_numpy(X[b0:b1].copy()), red)
+            Cg, Eg = oracle.spmm(red, rp, col, val, X)
+            okb = np.allclose(Cb.numpy(), Cg[b0:b1], rtol=1e-5, atol=2e-6) if red == 'sum' else \
+                (np.array_equal(Cb.numpy().view(np.int32), Cg[b0:b1].view(np.int32)) and np.array_equal(engb.last_E.numpy(), Eg[b0:b1]))
+            res['nnzbal_' + red] = bool(okb)
+        Bl = torch.from_numpy(X[b0:b1].copy()).requires_grad_()
+        dd.DistSpMMFn.apply(engb, Bl, None, 'sum').backward(torch.from_numpy(G[b0:b1].copy()))
+        gB, _ = oracle.spmm('sum', cp, rw, tv, G)
+        res['nnzbal_bwd_overlap'] = bool(np.allclose(Bl.grad.numpy(), gB[b0:b1], rtol=1e-5, atol=2e-6))
+        imb = engb.imbalance()
+        res['imbalance'] = imb['nnz']['max_over_mean'] < 1.2 and imb['rows']['max'] >= imb['rows']['mean']
         # plan sanity: halo = unique remote columns, send/recv splits are each other's transpose
         remote = np.unique(col[rp[r0]:rp[r1]][(col[rp[r0]:rp[r1]] < r0) | (col[rp[r0]:rp[r1]] >= r1)])
         res['halo'] = eng.n_halo == remote.shape[0]
