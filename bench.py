@@ -298,9 +298,10 @@ def main():
         extra['imbalance'] = eng.imbalance()  # per-rank nnz / rows / halo in / rows out: max, mean, max over mean
         # the exchange alone (pack + all-to-all-v, nothing overlapped): what the step would cost if compute were free
         ex_steps = max(5, a.steps // 5)
-        wall_x, _ = time_steps(lambda: eng.exchange(Xloc), ex_steps, 2, True)
+        wall_x, _ = time_steps(lambda: eng.exchange(Xloc), ex_steps, 2, pg)
         tx = torch.tensor([wall_x], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tx, op=torch.distributed.ReduceOp.MAX)
+        if pg:
+            torch.distributed.all_reduce(tx, op=torch.distributed.ReduceOp.MAX)
         extra['exchange_only_ms'] = round(tx.item() / ex_steps * 1e3, 4)
         workload = f'synthetic power-law CSR {K}x{K} ({Mloc} rows/GPU, ~{a.deg}/row), cols={a.cols}, ' \
                    f'locality={a.locality}, SpMM-{a.reduce} feat={N}, 1-D row partition + halo all-to-all-v'
