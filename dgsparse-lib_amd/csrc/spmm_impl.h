@@ -482,7 +482,10 @@ struct AccArg {
   const int *rowmap;  // output row of every row of A (nullptr = identity)
   int col_off;        // added to this product's arg column ids (halo slot -> extended id)
   int nl, h_lo;       // extended-id layout: local columns [0, nl), h_lo of the halo slots precede them
+  Epi epi;            // plain (non-accumulating) sum / mean only: bias / row scale / relu at the row-end store
 };
+template <int OP>
+constexpr bool epi_op() { return OP == DGS_SUM || OP == DGS_MEAN; }
 __device__ __forceinline__ int acc_key(int e, int nl, int h_lo) { return e < nl ? h_lo + e : (e - nl < h_lo ? e - nl : e); }
 
 template <int V, int OP, bool HIDDEN>
@@ -588,6 +591,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
           z[v] = 0.0f;
           m1[v] = -1;
         }
+        if constexpr (epi_op<OP>()) epi_apply<V>(z, r0 + r, f0, aa.epi);
         store_vec_stream<V>(C + (int64_t)(r0 + r) * N + f0, z);
         if constexpr (ARG) store_vec_stream<V>(E + (int64_t)(r0 + r) * N + f0, m1);
       }
@@ -721,6 +725,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
                 if constexpr (ACC) {
                   acc_commit<V, OP, true>(C, E, q.w, N, f0, acc, ei, aa);
                 } else {
+                  if constexpr (epi_op<OP>()) epi_apply<V>(acc, r0 + cur, f0, aa.epi);
                   store_vec_hidden<V>(C + (int64_t)(r0 + cur) * N + f0, acc);
                   if constexpr (ARG) store_vec_hidden<V>(E + (int64_t)(r0 + cur) * N + f0, ei);
                 }
@@ -781,6 +786,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
       if constexpr (ACC) {
         acc_commit<V, OP, false>(C, E, rows[r].w, N, f0, acc, ei, aa);
       } else {
+        if constexpr (epi_op<OP>()) epi_apply<V>(acc, r0 + r, f0, aa.epi);
         store_vec_stream<V>(C + (int64_t)(r0 + r) * N + f0, acc);
         if constexpr (ARG) store_vec_stream<V>(E + (int64_t)(r0 + r) * N + f0, ei);
       }
@@ -860,6 +866,7 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
         if constexpr (ACC) {
           acc_commit<V, OP, false>(C, E, aa.rowmap ? aa.rowmap[d.x] : d.x, N, f0, acc, ei, aa);
         } else {
+          if constexpr (epi_op<OP>()) epi_apply<V>(acc, d.x, f0, aa.epi);
           store_vec_stream<V>(C + (int64_t)d.x * N + f0, acc);
           if constexpr (ARG) store_vec_stream<V>(E + (int64_t)d.x * N + f0, ei);
         }
@@ -1055,6 +1062,7 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
       if constexpr (ACC) {
         acc_commit<V, OP, false>(C, E, aa.rowmap ? aa.rowmap[d.x] : d.x, N, f0, acc, ei, aa);
       } else {
+        if constexpr (epi_op<OP>()) epi_apply<V>(acc, d.x, f0, aa.epi);
         store_vec_stream<V>(C + (int64_t)d.x * N + f0, acc);
         if constexpr (ARG) store_vec_stream<V>(E + (int64_t)d.x * N + f0, ei);
       }
@@ -1190,7 +1198,8 @@ static int launch_impl(const SpmmArgs &a) {
         if (fb && hipMemsetAsync(&hdr->arrivals, 0, sizeof(int), a.st) != hipSuccess) return DGS_ELAUNCH;
         hipLaunchKernelGGL(kern, dim3((unsigned)P.nwg), dim3(kPanelBlock), P.lds, a.st, (int)a.M, W, (int)a.N, P.R, tl,
                            P.pcols, P.npanels, P.nsb, P.lead, a.rowptr, a.col, a.val, a.B + fb, a.C + fb,
-                           a.E ? a.E + fb : nullptr, &hdr->arrivals);
+                           a.E ? a.E + fb : nullptr, &hdr->arrivals,
+                           Epi{a.acc.epi.bias ? a.acc.epi.bias + fb : nullptr, a.acc.epi.rscale, a.acc.epi.relu});
       }
       const int nbu = 1024;
       hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC>), dim3((unsigned)nbu, (unsigned)a.tiles), dim3(kBlock), 0, a.st, (int)a.M,
@@ -1325,7 +1334,7 @@ static int launch_strict(const SpmmArgs &a) {
         if (fb && hipMemsetAsync(&hdr->arrivals, 0, sizeof(int), a.st) != hipSuccess) return DGS_ELAUNCH;
         hipLaunchKernelGGL(kern, dim3((unsigned)P.nwg), dim3(kPanelBlock), P.lds, a.st, (int)a.M, W, (int)a.N, P.R, tl,
                            P.pcols, P.npanels, P.nsb, P.lead, a.rowptr, a.col, a.val, a.B + fb, a.C + fb,
-                           (int *)nullptr, &hdr->arrivals);
+                           (int *)nullptr, &hdr->arrivals, Epi{});
       }
       hipLaunchKernelGGL((spmm_fused_strict<G, V, OP, HAS_VAL, STRICT>), dim3((unsigned)nbu, (unsigned)a.tiles), dim3(kBlock),
                          0, a.st, (int)a.M, (int)a.N, nbu, kRowsPerWave, ht, a.rowptr, a.col, a.val, a.B, a.C, hdr, units);

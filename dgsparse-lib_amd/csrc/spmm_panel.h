@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int ld, 
                                                           int nsb, int lead, const int *__restrict__ rowptr,
                                                           const int *__restrict__ col, const float *__restrict__ val,
                                                           const float *__restrict__ B, float *__restrict__ C,
-                                                          int *__restrict__ E, int *arrivals) {
+                                                          int *__restrict__ E, int *arrivals, const Epi epi) {
   constexpr int V = 4;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
   __shared__ int s_ctr;
@@ -342,6 +342,7 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int ld, 
             for (int v = 0; v < V; v++) o[v] /= d;
           }
         }
+        if constexpr (OP == DGS_SUM || OP == DGS_MEAN) epi_apply<V>(o, row, (i - r * n4) * V, epi);
         store_vec_stream<V>(C + row * ld + (int64_t)(i - r * n4) * V, o);
       }
     }

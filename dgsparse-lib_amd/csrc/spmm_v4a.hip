@@ -79,6 +79,45 @@ extern "C" int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, 
   return run(fm, a);
 }
 
+// The general entry: dgs_spmm_csr_f32 / dgs_spmm_csr_plan_f32 plus the fused epilogue (sum / mean only).
+extern "C" int dgs_spmm_csr_ex_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,
+                                   const int32_t *col, const float *val, const float *B, float *C, int32_t *E, int algorithm,
+                                   const float *bias, const float *row_scale, int relu, const void *plan,
+                                   const dgsSpmmPlanInfo *info, void *workspace, size_t workspace_bytes, dgsStream_t stream) {
+  if (reduce_op < DGS_SUM || reduce_op > DGS_MEAN || M < 0 || K < 0 || N < 0 || nnz < 0) return DGS_EINVAL;
+  if (M >= INT32_MAX || K >= INT32_MAX || N >= INT32_MAX || nnz >= INT32_MAX) return DGS_ERANGE;
+  const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
+  const bool epi = bias || row_scale || relu;
+  const bool strict = (algorithm & (DGS_ALG_STRICT_SUM | DGS_ALG_STRICT_NOFMA)) && !arg;
+  if (epi && (arg || strict)) return DGS_EINVAL;  // the epilogue exists for the default sum / mean schedules
+  if (M == 0 || N == 0) return DGS_OK;
+  if (!rowptr || !C || (nnz > 0 && (!col || !B)) || (arg && !E)) return DGS_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (E && !arg) {
+    if (hipMemsetAsync(E, 0xFF, (size_t)M * N * sizeof(int32_t), st) != hipSuccess) return DGS_ELAUNCH;
+  }
+  const bool planned = plan && info && !strict && nnz > 0 && !tiny_problem(M, nnz) &&
+                       dgs_spmm_csr_schedule(reduce_op, M, K, N, nnz) == DGS_SCHED_ROWS;
+  if (planned && !is_aligned16(plan)) return DGS_EINVAL;
+  const size_t need = planned ? dgs_spmm_csr_plan_workspace_bytes(reduce_op, M, N, nnz, info)
+                              : dgs_spmm_csr_workspace_bytes(reduce_op, M, N, nnz);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return DGS_EWORKSPACE;
+  const bool al = is_aligned16(B) && is_aligned16(C) && (!arg || is_aligned16(E)) && (need == 0 || is_aligned16(workspace)) &&
+                  (!bias || is_aligned16(bias));
+  const FeatMap fm = feat_map(N, al);
+  SpmmArgs a{M, K, N, nnz, rowptr, col, val, B, C, arg ? E : nullptr, fm.tiles, need ? workspace : nullptr, st, reduce_op};
+  a.hints = algorithm & ~0xff;
+  a.acc.epi = Epi{bias, row_scale, relu ? 1 : 0};
+  if (planned) {
+    a.plan = static_cast<const PlanHdr *>(plan);
+    a.plan_units = info->n_units;
+    a.plan_long = info->n_long;
+    a.plan_pslots = info->n_pslots;
+    a.plan_off_long = info->off_long;
+  }
+  return run(fm, a);
+}
+
 // SpMM over a cached plan (spmm_plan.hip).  Shapes that do not take the row-stream schedule ignore the plan.
 extern "C" int dgs_spmm_csr_plan_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,
                                      const int32_t *col, const float *val, const float *B, float *C, int32_t *E,

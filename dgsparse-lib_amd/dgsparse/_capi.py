@@ -65,6 +65,9 @@ _lib.dgs_spmm_plan_compact.restype = _int
 _lib.dgs_spmm_plan_compact.argtypes = [_vp, ctypes.POINTER(PlanInfo), _vp, _sz, _i64, _vp]
 _lib.dgs_spmm_csr_plan_workspace_bytes.restype = _sz
 _lib.dgs_spmm_csr_plan_workspace_bytes.argtypes = [_int, _i64, _i64, _i64, ctypes.POINTER(PlanInfo)]
+_lib.dgs_spmm_csr_ex_f32.restype = _int
+_lib.dgs_spmm_csr_ex_f32.argtypes = [_int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _int, _vp,
+                                     ctypes.POINTER(PlanInfo), _vp, _sz, _vp]
 _lib.dgs_spmm_csr_plan_f32.restype = _int
 _lib.dgs_spmm_csr_plan_f32.argtypes = [_int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        ctypes.POINTER(PlanInfo), _vp, _sz, _vp]
@@ -108,7 +111,7 @@ _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
            'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes', 'dgs_spmm_plan_build',
            'dgs_spmm_plan_compact_bytes', 'dgs_spmm_plan_compact', 'dgs_spmm_plan_info_from_header',
-           'dgs_spmm_plan_thresholds', 'dgs_spmm_plan_provisional_info', 'dgs_spmm_csr_plan_workspace_bytes',
+           'dgs_spmm_plan_thresholds', 'dgs_spmm_plan_provisional_info', 'dgs_spmm_csr_ex_f32', 'dgs_spmm_csr_plan_workspace_bytes',
            'dgs_spmm_csr_plan_f32', 'dgs_spmm_csr_acc_f32', 'dgs_spmm_csr_acc_max_f32',
            'dgs_spmm_csr_schedule', 'dgs_spmm_arg_backward_f32', 'dgs_sddmm_csr_schedule',
            'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_plan_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
@@ -306,9 +309,12 @@ def spmm_plan(rowptr, col, K, N=64, force=False):
     return SpmmPlan(small, info, M, int(K), nnz, rowptr.data_ptr(), col.data_ptr())
 
 
-def spmm(reduce_op, rowptr, col, values, dense, algorithm=0, want_E=None, plan=None):
+def spmm(reduce_op, rowptr, col, values, dense, algorithm=0, want_E=None, plan=None, bias=None, row_scale=None,
+         relu=False):
     """C = reduce(A (*) dense).  Returns (C, E) with E=None unless max/min (or want_E).  ``plan``: a SpmmPlan of
-    exactly these (rowptr, col) arrays (shapes that do not take the row-stream schedule ignore it)."""
+    exactly these (rowptr, col) arrays (shapes that do not take the row-stream schedule ignore it).
+    ``bias`` [N] / ``row_scale`` [M] / ``relu``: fused epilogue of sum / mean, C = relu(row_scale[:, None] * C + bias),
+    bit-identical to the separate elementwise ops (dgs_spmm_csr_ex_f32)."""
     dev = _need_gpu(rowptr, col, values, dense)
     rowptr = _i32(rowptr, 'rowptr')
     col = _i32(col, 'col')
@@ -316,11 +322,20 @@ def spmm(reduce_op, rowptr, col, values, dense, algorithm=0, want_E=None, plan=N
     M, nnz, (K, N) = rowptr.numel() - 1, col.numel(), dense.shape
     if M < 0:
         raise ValueError('dgsparse: rowptr must have at least one element')
+    epi = bias is not None or row_scale is not None or bool(relu)
+    if epi:
+        if reduce_op not in (SUM, MEAN):
+            raise ValueError('dgsparse: the fused epilogue exists for sum and mean')
+        if bias is not None:
+            bias = _f32vec(bias, 'bias', N)
+        if row_scale is not None:
+            row_scale = _f32vec(row_scale, 'row_scale', M)
     if N % 4 and N > 4 and _lib.dgs_spmm_csr_schedule(int(reduce_op), M, K, (N + 3) & ~3, nnz) == 2:
         # dense graph, feature width not a multiple of 4 (e.g. 41 classes): the column-panel schedule needs 16-byte
         # lane vectors, and two small copies buy it (Reddit-shaped, N = 41: 4.9 -> 2.4 ms).  Feature columns are
         # independent chains, so the visible columns are bit-identical to an unpadded run.
-        C, E = spmm(reduce_op, rowptr, col, values, _pad4(dense), algorithm, want_E)
+        bp = None if bias is None else torch.cat([bias, bias.new_zeros(((N + 3) & ~3) - N)])
+        C, E = spmm(reduce_op, rowptr, col, values, _pad4(dense), algorithm, want_E, bias=bp, row_scale=row_scale, relu=relu)
         return C[:, :N].contiguous(), (None if E is None else E[:, :N].contiguous())
     values = _f32vec(values, 'values', nnz)
     arg = reduce_op in (MAX, MIN) if want_E is None else want_E
@@ -329,6 +344,17 @@ def spmm(reduce_op, rowptr, col, values, dense, algorithm=0, want_E=None, plan=N
     if plan is not None and (plan.M != M or plan.nnz != nnz or plan.col_ptr != col.data_ptr() or
                              plan.rowptr_ptr != rowptr.data_ptr()):
         raise ValueError('dgsparse: the plan was built for other (rowptr, col) arrays')
+    if epi:
+        with _on_device(dev):
+            planned = plan is not None and _lib.dgs_spmm_csr_schedule(int(reduce_op), M, K, N, nnz) == 1
+            wsb = (_lib.dgs_spmm_csr_plan_workspace_bytes(reduce_op, M, N, nnz, ctypes.byref(plan.info)) if planned
+                   else _lib.dgs_spmm_csr_workspace_bytes(reduce_op, M, N, nnz))
+            ws = _new(wsb, dtype=torch.uint8, device=dev) if wsb else None
+            _check(_lib.dgs_spmm_csr_ex_f32(reduce_op, M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(dense), _p(out), _p(E),
+                                            int(algorithm), _p(bias), _p(row_scale), int(bool(relu)),
+                                            _p(plan.buf) if planned else None, ctypes.byref(plan.info) if planned else None,
+                                            _p(ws), wsb, _stream(dev)), 'spmm_ex')
+        return out, E
     with _on_device(dev):
         strict = (int(algorithm) & (ALG_STRICT_SUM | ALG_STRICT_NOFMA)) and reduce_op in (SUM, MEAN)
         if plan is not None and not strict and _lib.dgs_spmm_csr_schedule(int(reduce_op), M, K, N, nnz) == 1:

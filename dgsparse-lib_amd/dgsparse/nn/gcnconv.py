@@ -6,19 +6,28 @@ import torch.nn.functional as F
 
 from ..spmm import spmm_sum
 from ..tensor import SparseTensor
+from .fused import spmm_sum_fused
 from .graph import csr_from_edge_index
 
 
 class GCNConv(torch.nn.Module):
-    """``x' = A_hat @ (x W)``: dense projection first, then one SpMM-sum with the normalised adjacency."""
+    """``x' = A_hat @ (x W)``: dense projection first, then one SpMM-sum with the normalised adjacency.
+    ``activation='relu'`` (not in the reference's layer) fuses the ReLU that usually follows into the SpMM's row-end store:
+    same values bit for bit, one pass over the output less."""
 
-    def __init__(self, in_size, out_size):
+    def __init__(self, in_size, out_size, activation=None):
         super().__init__()
+        if activation not in (None, 'relu'):
+            raise ValueError(activation)
         self.W = torch.nn.Linear(in_size, out_size, bias=False)
+        self.activation = activation
 
     def forward(self, dcsr, x):
         projected = self.W(x)
-        return spmm_sum(dcsr, projected, 0)
+        if self.activation == 'relu' and projected.is_cuda:
+            return spmm_sum_fused(dcsr, projected, relu=True)
+        out = spmm_sum(dcsr, projected, 0)
+        return F.relu(out) if self.activation == 'relu' else out
 
 
 class GCN(torch.nn.Module):
@@ -26,11 +35,11 @@ class GCN(torch.nn.Module):
 
     def __init__(self, in_size, out_size, hidden_size):
         super().__init__()
-        self.conv1 = GCNConv(in_size, hidden_size)
+        self.conv1 = GCNConv(in_size, hidden_size, activation='relu')  # the ReLU rides in the SpMM's epilogue
         self.conv2 = GCNConv(hidden_size, out_size)
 
     def forward(self, dcsr, x):
-        hidden = F.relu(self.conv1(dcsr, x))
+        hidden = self.conv1(dcsr, x)
         return self.conv2(dcsr, hidden)
 
 

@@ -149,6 +149,21 @@ int dgs_spmm_csr_plan_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_
                           dgsStream_t stream);
 
 /*
+ * The general forward entry: everything dgs_spmm_csr_f32 and dgs_spmm_csr_plan_f32 do (plan / info may be NULL) plus a fused
+ * EPILOGUE for sum / mean, applied where a finished output row leaves the kernels:
+ *     C[r, f] = relu(row_scale[r] * (A.B)[r, f] + bias[f])          bias[N], row_scale[M] nullable, relu 0 / 1
+ * with the roundings of the separate elementwise ops (multiply, add, clamp; no contraction), so the result equals the
+ * unfused sequence bit for bit while the M x N result is written once instead of written, read and written again.  New (the
+ * reference's GCN layer runs spmm_sum and torch.relu as two passes, dgsparse/nn/gcnconv.py:10-35).  DGS_EINVAL for max / min
+ * and for the strict-order bits together with an epilogue.  workspace: dgs_spmm_csr_plan_workspace_bytes with a plan on the
+ * row-stream schedule, dgs_spmm_csr_workspace_bytes otherwise.
+ */
+int dgs_spmm_csr_ex_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,
+                        const int32_t *col, const float *val, const float *B, float *C, int32_t *E, int algorithm,
+                        const float *bias, const float *row_scale, int relu, const void *plan, const dgsSpmmPlanInfo *info,
+                        void *workspace, size_t workspace_bytes, dgsStream_t stream);
+
+/*
  * Accumulating SpMM (sum):  C[rowmap[r],:] += sum_{p in row r} val[p] * B[col[p],:]   (rowmap == NULL: C[r,:] += ...)
  * New (the reference has no accumulating product; its nnz-balanced algorithms atomically add into a caller-zeroed C,
  * src/ge-spmm/gespmm.cc:65-90, which is the closest thing).  Rows of A without entries leave C untouched, so a product

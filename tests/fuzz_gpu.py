@@ -2,6 +2,7 @@
 """Long-running randomized parity campaign (not collected by pytest): python tests/fuzz_gpu.py [seconds] [seed].
 Random shapes / degree laws / value kinds / feature widths, every reduce + SDDMM + masked backward + csr2csc, each
 checked against the CPU oracle with the same bars as tests/test_gpu_parity.py.  Prints one line per 50 cases."""
+import faulthandler
 import os
 import sys
 import time
@@ -155,6 +156,7 @@ def one_case(rng, it):
 
 
 def main():
+    faulthandler.enable(all_threads=True)  # a native crash prints the Python stack of every thread before the core dump
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
