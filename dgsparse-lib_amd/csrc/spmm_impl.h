@@ -130,8 +130,9 @@ static inline WsLayout ws_layout(int reduce_op, int64_t N, int64_t nnz) {
   WsLayout L;
   L.ch = unit_len(nnz);
   // sum over long rows of ceil(len/ch) <= nnz/ch + #long rows; the strict schedule (spmm_strict.h) keeps its hub-row units
-  // in per-class regions behind nnz/kT1 + 2 front entries: another nnz/64 + 128 at most
-  L.max_units = 2 * (nnz / kT2) + nnz / L.ch + 160;
+  // in per-class regions behind nnz/kT1 + 2 front entries: another 2 * nnz/64 + 128 at most (class c holds <= slices * nnz /
+  // (threshold << c) entries, slices / threshold <= 1/64)
+  L.max_units = 3 * (nnz / kT2) + nnz / L.ch + 160;
   L.max_pslots = 2 * (nnz / L.ch) + 2;               // same sum over rows longer than ch only (they need partials)
   L.max_long = nnz / L.ch + 2;                       // rows longer than ch
   L.off_units = up(sizeof(SpmmWs));
@@ -1302,7 +1303,7 @@ static int launch_strict(const SpmmArgs &a) {
   int4 *units = reinterpret_cast<int4 *>(w + L.off_units);
   // (DGS_STRICT_MID / _HUB: experiment overrides of the slicing thresholds; the table capacities assume hub >= kStrictHub)
   int tmid = env_int("DGS_STRICT_MID", kStrictMid), thub = env_int("DGS_STRICT_HUB", kStrictHub);
-  if (thub < kStrictHub) thub = kStrictHub;
+  if (thub < (strict_coop(G, V) ? kStrictMid : kStrictHub)) thub = strict_coop(G, V) ? kStrictMid : kStrictHub;
   if (tmid < kStrictMid) tmid = kStrictMid;
   if (tmid > thub) tmid = thub;
   if (hipMemsetAsync(hdr, 0, sizeof(SpmmWs), a.st) != hipSuccess) return DGS_ELAUNCH;

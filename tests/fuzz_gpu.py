@@ -61,7 +61,7 @@ def one_case(rng, it):
             assert_sum_parity(C, Co, C64 / sc, S64 / sc, 1e-5, 2e-6, tag + ' ' + reduce, lens=np.diff(rp))
             # round 3: the strict-order schedule is bit-exact against its sequential chain for every row length
             for alg, fma in ((capi.ALG_STRICT_SUM, True), (capi.ALG_STRICT_NOFMA, False)):
-                if rng.integers(0, 2):
+                if rng.integers(0, 2) and not os.environ.get('FUZZ_NO_STRICT'):
                     Cs, _ = capi.spmm(oracle.REDUCE[reduce], drp, dcol, dval, dX, algorithm=alg)
                     assert_bitexact(Cs.cpu().numpy(), oracle.spmm(reduce, rp, col, val, X, fma=fma)[0], tag + f' strict {reduce} fma={fma}')
     capi.canary_check(tag + ' spmm')
