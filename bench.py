@@ -346,7 +346,8 @@ def main():
     if os.path.exists(tf) and not use_dist:
         try:
             tj = json.load(open(tf))
-            key = f'{a.reduce}_feat{N}_{a.cols}' + ('_plan' if res.get('schedule', '').endswith('+plan') else '')
+            key = f'{a.reduce}_feat{N}_{a.cols}' + ('_plan' if res.get('schedule', '').endswith('+plan') else '') + \
+                (f'_strict_{a.strict}' if a.strict else '')
             if key in tj:
                 res['roofline']['traffic'] = tj[key]
                 res['roofline']['traffic_source'] = f"profiles/hbm_traffic.json[{key}] <- {tj.get('_source', {}).get(key, 'see profiles/README.md')}"
@@ -385,11 +386,13 @@ def main():
             t0 = time.perf_counter()
             _capi.spmm_plan(rp, col, K, N, force=(a.plan == 1))
             torch.cuda.synchronize()
+            build_ms = (time.perf_counter() - t0) * 1e3
             pfree = sorted(event_ms(lambda: _capi.spmm(op, rp, col, val, X), max(10, a.steps // 5)) for _ in range(3))[1]
-            res['plan'] = dict(build_ms_blocking=round((time.perf_counter() - t0) * 1e3, 3), planfree_ms_per_step=round(pfree, 5),
+            res['plan'] = dict(build_ms_blocking=round(build_ms, 3), planfree_ms_per_step=round(pfree, 5),
                                planned_ms_per_step=res['protocol']['median_ms'],
-                               calls_to_break_even_blocking=round((time.perf_counter() - t0) * 1e3 / max(pfree - res['protocol']['median_ms'], 1e-6), 1),
-                               note='dgsparse.Storage builds it on a side stream from the 4th use of a matrix on (DGS_PLAN_AFTER), never blocking')
+                               calls_to_break_even_blocking=round(build_ms / max(pfree - res['protocol']['median_ms'], 1e-6), 1),
+                               note='dgsparse.Storage queues the build on the caller\'s stream at the 4th use of a matrix '
+                                    '(DGS_PLAN_AFTER), with provisional counts and no host synchronisation (DESIGN.md 4.1d)')
         # the strict-order schedule on the same tensors (opt-in `algorithm` bits): time + full parity in cpu_baseline
         if a.reduce in ('sum', 'mean'):
             sd = {}

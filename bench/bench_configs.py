@@ -77,7 +77,10 @@ def main():
         if op == 'sddmm':
             D1 = torch.rand((M, N), generator=g, device='cuda')
             plan = None if a.no_plan else _capi.spmm_plan(rp, col, K, N)
-            sched = 'nnz-balanced' if plan is None or _capi._lib.dgs_sddmm_csr_schedule(M, K, N, nnz, 0) == 2 else 'fused rows+units over the plan'
+            fused = plan is not None and _capi._lib.dgs_sddmm_csr_schedule(M, K, N, nnz, 0) != 2 and \
+                plan.info.n_pslots * 256 >= nnz  # the library's own dispatch rule (csrc/sddmm.hip)
+            sched = ('panel' if _capi._lib.dgs_sddmm_csr_schedule(M, K, N, nnz, 0) == 2 else
+                     'fused rows+units over the plan' if fused else 'nnz-balanced')
             t = timeit(lambda: _capi.sddmm(rp, col, D1, X, plan=plan), iters=it)
             balg = 4 * (M + 1) + 8 * nnz + 4 * (M + K) * N
         else:

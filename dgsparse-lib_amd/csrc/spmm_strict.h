@@ -27,6 +27,9 @@
 
 namespace dgs {
 
+#ifndef DGS_STRICT_PRIO
+#define DGS_STRICT_PRIO 1
+#endif
 #ifndef DGS_STRICT_DBG
 #define DGS_STRICT_DBG 0  // experiment builds: 1 = no chain, 2 = no gathers, 3 = no LDS writes and no chain
 #endif
@@ -270,6 +273,9 @@ __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, con
     }
     __syncthreads();
     if (wave == 0 && lane < W) {
+      // the chain is the critical path of the whole call and a dependent sequence: give it the SIMD's issue slots ahead of
+      // the three other waves that share them (DGS_STRICT_PRIO=0 builds measure the difference)
+      if (DGS_STRICT_PRIO) __builtin_amdgcn_s_setprio(3);
       const float *xr = xt + lane * LD;
       constexpr int CB = 4;  // b128 pairs per batch = 16 steps
       float4 xa[CB], wa[CB], xn[CB], wn4[CB];
@@ -306,6 +312,7 @@ __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, con
         }
       }
       for (; i < cnt; i++) acc = chain_step<FMA>(HAS_VAL ? wt[i] : 1.0f, xr[i], acc);
+      if (DGS_STRICT_PRIO) __builtin_amdgcn_s_setprio(0);
     }
   }
   if (wave == 0 && lane < W && fbase + lane < N) {
