@@ -1244,7 +1244,8 @@ static int launch_impl(const SpmmArgs &a) {
                      reinterpret_cast<const int4 *>(pb + (a.plan_off_long ? (size_t)a.plan_off_long : PL.off_long))};
     int64_t ub = ((int64_t)a.plan_units + 3) / 4;
     ub = (ub + 7) & ~int64_t(7);  // a multiple of 8 so that the XCD mapping of the unit blocks applies
-    const int nbu = (int)(ub < DGS_NBU ? (ub < 8 ? 8 : ub) : DGS_NBU);
+    const int nbu_cap = (env_int("DGS_NBU", DGS_NBU) + 7) & ~7;
+    const int nbu = (int)(ub < nbu_cap ? (ub < 8 ? 8 : ub) : nbu_cap);
     hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
                        a.st, (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.acc);
     if (a.plan_long > 0) {
@@ -1269,7 +1270,8 @@ static int launch_impl(const SpmmArgs &a) {
                      longrows);
   // unit / multi counts live on the device: a bounded number of persistent unit blocks stride over the table
   const int64_t ub = (L.max_units + 3) / 4;
-  const int nbu = (int)(ub < DGS_NBU ? (ub < 1 ? 1 : ub) : DGS_NBU);
+  const int nbu_cap = env_int("DGS_NBU", DGS_NBU);
+  const int nbu = (int)(ub < nbu_cap ? (ub < 1 ? 1 : ub) : nbu_cap);
   hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
                      a.st, (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.acc);
   // combine: one wave per multi-unit row

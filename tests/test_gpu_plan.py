@@ -369,3 +369,39 @@ def test_sddmm_plan_unsorted_and_duplicate_columns(capi, monkeypatch):
     got = capi.sddmm(rpt, colt, torch.from_numpy(D1).to(d), torch.from_numpy(D2).to(d), plan=plan)
     ref = oracle.sddmm(rp, col, D1, D2, threads=oracle.max_threads())
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_provisional_plan_counts_are_upper_bounds(capi, seed, monkeypatch):
+    """The calls queued behind a non-blocking plan build size their grids and the partial-row workspace from
+    dgs_spmm_plan_provisional_info; a bound below the real count would be an out-of-bounds write into the workspace.
+    Random degree laws, sorted and unsorted rows, default and finest cut parameters: bound >= count, always."""
+    rng = np.random.default_rng(100 + seed)
+    for trial in range(6):
+        M = int(rng.choice([70000, 120000, 300000]))
+        per = float(rng.choice([3, 12, 40]))
+        alpha = float(rng.choice([1.6, 2.0, 2.6]))
+        dmax = int(rng.choice([300, 5000, 60000]))
+        rp, col, st = graphgen.powerlaw_csr(M, int(M * per), alpha=alpha, dmax=min(M, dmax), seed=seed * 10 + trial,
+                                            cols=str(rng.choice(['uniform', 'powerlaw'])))
+        if trial % 3 == 2:  # unsorted rows are chunked without cuts: fewer units, the bound must still hold
+            col = col.copy()
+            for r in rng.integers(0, M, 200):
+                rng.shuffle(col[rp[r]:rp[r + 1]])
+        if trial % 2:
+            monkeypatch.setenv('DGS_PLAN_UNIT', '16')
+            monkeypatch.setenv('DGS_PLAN_TSLICE', '128')
+        else:
+            monkeypatch.delenv('DGS_PLAN_UNIT', raising=False)
+            monkeypatch.delenv('DGS_PLAN_TSLICE', raising=False)
+        rpt, colt = torch.from_numpy(rp).cuda(), torch.from_numpy(col).cuda()
+        plan = capi.spmm_plan(rpt, colt, st['K'], 64, force=True)
+        if plan is None:
+            continue
+        t1, ts = capi.plan_thresholds()
+        deg = np.diff(rp).astype(np.int64)
+        prov = capi.plan_provisional_info(col.shape[0], int((deg > t1).sum()), int(deg[deg > t1].sum()), int((deg > ts).sum()),
+                                          int(deg[deg > ts].sum()))
+        real = plan.info
+        assert prov[0] >= real.n_units and prov[1] >= real.n_long and prov[2] >= real.n_pslots, \
+            (seed, trial, prov[:3].tolist(), real.n_units, real.n_long, real.n_pslots)

@@ -161,3 +161,58 @@ def test_schedule_queries_need_no_gpu(monkeypatch):
     monkeypatch.setenv('DGS_PANEL', '1')
     assert _capi.spmm_schedule(_capi.SUM, M1, M1, 64, nnz1) == 'panel'
 
+
+
+def test_plan_host_helpers_need_no_gpu():
+    """The host-only parts of the non-blocking plan build (include/dgsparse_hip.h): thresholds, provisional (upper-bound)
+    counts from four sums over the row lengths, and the parser of a host copy of the plan header."""
+    from dgsparse import _capi
+    t1, ts = _capi.plan_thresholds()
+    assert t1 == 64 and ts >= 128
+    info = _capi.plan_provisional_info(1 << 24, 25000, 9_000_000, 5500, 6_700_000)
+    n_units, n_long, n_pslots = int(info[0]), int(info[1]), int(info[2])
+    assert n_long == 25000 and n_units == n_pslots and n_units >= 5500 * 9  # every cut row may have 8 cells + 1
+    assert int(info[14]) == 0, 'off_long = 0: the build-time layout'
+    # more long rows / nnz never shrink the bound
+    bigger = _capi.plan_provisional_info(1 << 24, 26000, 9_500_000, 5600, 6_900_000)
+    assert int(bigger[0]) >= n_units and int(bigger[1]) >= n_long
+    for bad in ((0, 1, 1, 0, 0), (100, 1, 10, 2, 5), (100, 2, 5, 1, 10)):  # nnz <= 0; tslice rows > t1 rows; tslice nnz > t1 nnz
+        with pytest.raises(RuntimeError):
+            _capi.plan_provisional_info(*bad)
+    pi = _capi.PlanInfo()
+    junk = (ctypes.c_char * 256)()
+    assert _capi._lib.dgs_spmm_plan_info_from_header(junk, 256, ctypes.byref(pi)) == -1, 'no magic: DGS_EINVAL'
+    assert _capi._lib.dgs_spmm_plan_info_from_header(junk, 16, ctypes.byref(pi)) == -1, 'short buffer'
+    hdr = (ctypes.c_int32 * 64)()
+    hdr[0], hdr[1] = 0x64677350, 2          # magic "dgsP", version
+    hdr[5], hdr[6], hdr[7] = 1234, 56, 789  # n_units, n_long, n_pslots
+    hdr[10] = 256                           # tslice
+    for x in range(9):
+        hdr[12 + x] = 100 * x               # xcd_start
+    assert _capi._lib.dgs_spmm_plan_info_from_header(hdr, 256, ctypes.byref(pi)) == 0
+    assert (pi.n_units, pi.n_long, pi.n_pslots, pi.tslice, pi.off_long) == (1234, 56, 789, 256, 0)
+    assert list(pi.xcd_start) == [100 * x for x in range(9)]
+
+
+def test_nnz_balanced_row_offsets():
+    """dgsparse.dist.row_offsets: contiguous blocks with equal nnz (block g ends at the first row whose prefix nnz reaches
+    (g+1)*nnz/P), monotone with runs of empty rows, degenerate sizes."""
+    import numpy as np
+    from dgsparse import dist as dd
+    rng = np.random.default_rng(0)
+    deg = np.minimum(rng.zipf(1.5, 5000), 3000)
+    deg[rng.integers(0, 5000, 800)] = 0
+    deg = np.sort(deg)[::-1].copy()  # degree-correlated order: equal row blocks give rank 0 the hubs
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    for world in (1, 2, 3, 8):
+        offs = dd.row_offsets(torch.from_numpy(rp), world, 'nnz')
+        assert offs[0] == 0 and offs[-1] == 5000 and all(a <= b for a, b in zip(offs, offs[1:])) and len(offs) == world + 1
+        shares = [int(rp[offs[i + 1]] - rp[offs[i]]) for i in range(world)]
+        assert max(shares) - min(shares) <= 2 * int(deg.max()) + 1, shares
+        rows_eq = dd.row_offsets(torch.from_numpy(rp), world, 'rows')
+        eq_shares = [int(rp[rows_eq[i + 1]] - rp[rows_eq[i]]) for i in range(world)]
+        if world > 1:
+            assert max(shares) <= max(eq_shares)
+    assert dd.row_offsets(torch.tensor([0, 0, 0]), 2, 'nnz') == [0, 0, 2]
+    with pytest.raises(ValueError):
+        dd.row_offsets(torch.from_numpy(rp), 2, 'cols')
