@@ -11,6 +11,18 @@ pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-5, 2e-6
 
 
+def assert_scatter_close(got, want, g, what):
+    """dX of max/min from the single-pass backward: sums of SIGNED terms accumulated with fp32 atomics in whatever order
+    the hardware delivers them, so the error is bounded by the condition scale of a column - sum_i |A[i, j]| * max |G| is an
+    upper bound of sum |terms| for row j of dX - not by the (possibly cancelled) result.  5 eps of that scale on top of the
+    usual bars; the deterministic masked kernels are held to the plain bars."""
+    col, val = g['col'], np.abs(g['val']) if 'val' in g else np.ones(g['col'].shape[0], np.float32)
+    scale = np.bincount(col, weights=val, minlength=want.shape[0])[:want.shape[0]] * float(np.abs(g['G']).max())
+    err = np.abs(np.asarray(got, np.float64) - want)
+    bad = err > RTOL * np.abs(want) + ATOL + 3e-7 * scale[:, None]
+    assert not bad.any(), f'{what}: {bad.sum()} / {bad.size} outside the scatter bar; worst {err.max()}'
+
+
 def make(g, requires_grad=True, has_value=True):
     import dgsparse
     M, K = g['rowptr'].shape[0] - 1, int(g['K'])
@@ -41,7 +53,10 @@ def test_forward_backward_like_reference_tests(name, reduce):
     else:
         assert_close(out.detach().cpu().numpy(), g[f'{reduce}_out'], RTOL, ATOL)
     out.backward(torch.from_numpy(g['G']).cuda())
-    assert_close(X.grad.cpu().numpy(), g[f'{reduce}_dX'], RTOL, ATOL, 'dX')
+    if reduce == 'max':
+        assert_scatter_close(X.grad.cpu().numpy(), g['max_dX'], g, 'dX (fp32 atomics)')
+    else:
+        assert_close(X.grad.cpu().numpy(), g[f'{reduce}_dX'], RTOL, ATOL, 'dX')
     assert_close(dcsr.storage._values.grad.cpu().numpy(), g[f'{reduce}_dA'], RTOL, ATOL, 'dA')
 
 
@@ -64,10 +79,14 @@ def test_max_backward_single_pass_and_deterministic_mode():
         finally:
             torch.use_deterministic_algorithms(False)
         grads[det] = runs
-        assert_close(runs[0][0].cpu().numpy(), g['max_dX'], RTOL, ATOL, f'dX deterministic={det}')
+        if det:
+            assert_close(runs[0][0].cpu().numpy(), g['max_dX'], RTOL, ATOL, 'dX deterministic')
+        else:
+            assert_scatter_close(runs[0][0].cpu().numpy(), g['max_dX'], g, 'dX single pass (fp32 atomics)')
         assert_close(runs[0][1].cpu().numpy(), g['max_dA'], RTOL, ATOL, f'dA deterministic={det}')
     assert torch.equal(grads[True][0][0], grads[True][1][0]) and torch.equal(grads[True][0][1], grads[True][1][1])
-    assert torch.allclose(grads[True][0][0], grads[False][0][0], rtol=1e-5, atol=2e-6)
+    assert_scatter_close(grads[False][0][0].cpu().numpy(), grads[True][0][0].cpu().numpy().astype(np.float64), g,
+                         'single pass vs deterministic')
 
 
 def test_permuted_values_cache_tracks_in_place_updates():
