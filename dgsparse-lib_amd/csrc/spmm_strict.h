@@ -9,16 +9,18 @@
 // and (b) everything that is not the chain: the gathers.  Schedule (included by spmm_impl.h, shares its row blocks):
 //
 //   spmm_classify_strict   rows > T1 become units {row, first nnz, nnz, slice}: rows up to 256 nnz one unit (the whole
-//                          feature tile), up to 2048 nnz 4 units, longer ("hub") rows 16 units - a unit owns a SLICE of
-//                          the row's features, so its wave gathers narrow pieces of MANY dense rows at once: a 50 k-nnz
-//                          row has 16 waves x 8 KB of gathers in flight instead of one wave's 8 KB.  Hub units are
-//                          written from the back of the table and taken first.
-//   unit waves             (the persistent unit blocks of spmm_fused) one wave per unit, no block-level sync: rounds of
-//                          kUS gathers per lane in the usual lane mapping (GP lanes x V floats per nnz, 64/GP nnz per
-//                          load instruction) -> transposed through the wave's LDS region in two halves -> the CHAIN
-//                          lanes (one per feature of the slice) walk the half in nnz order: one ds_read (x, and w beside
-//                          it for narrow slices) + one fma per nnz.  The gathers of the next round are issued as soon as
-//                          a half has left the registers, so they fly under the chain.
+//                          feature tile), longer rows 4 units - a unit owns a SLICE of the row's features, so the waves that
+//                          work a long row gather narrow pieces of MANY dense rows at once.  Hub rows (> 2048 nnz) are kept in
+//                          six length classes, each in its own region of the table, and are taken longest first.
+//   unit waves             (the persistent unit blocks of spmm_fused_strict) rows up to 2048 nnz: one WAVE per unit, no
+//                          block-level sync: rounds of kUS gathers per lane in the usual lane mapping (GP lanes x V floats per
+//                          nnz, 64/GP nnz per load instruction) -> transposed through the wave's LDS region in two halves ->
+//                          the CHAIN lanes (one per feature of the slice) walk the half in nnz order: one ds_read (x, and w
+//                          beside it for narrow slices) + one fma per nnz; the next round's gathers are issued as soon as a
+//                          half has left the registers.  Hub rows: one WORKGROUP per unit (strict_hub_coop): four waves
+//                          gather (128 KB in flight per row), the tile sits feature-major in LDS, wave 0 chains with one
+//                          ds_read_b128 of x and one of w per four steps.  (Tiles narrower than 64 floats or scalar lanes: up
+//                          to 16 wave-level slices per hub row instead.)  All slices of a row run on one XCD.
 //   row blocks             unchanged: rows <= T1 are sequential chains already.
 //
 // Nothing is combined afterwards: no partial rows, no combine launch, bit-identical results from run to run and for any
