@@ -309,6 +309,15 @@ extern "C" size_t dgs_spmm_plan_workspace_bytes(int64_t M, int64_t K, int64_t nn
 extern "C" int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int32_t *rowptr, const int32_t *col,
                                    void *plan, size_t plan_bytes, void *workspace, size_t workspace_bytes,
                                    dgsSpmmPlanInfo *info, dgsStream_t stream) {
+  return dgs_spmm_plan_build2(M, K, nnz, rowptr, col, nullptr, plan, plan_bytes, workspace, workspace_bytes, info, stream);
+}
+
+// col_prefix (nullable): col_prefix[c] = number of entries with column < c, c = 0 .. K - i.e. the colptr of the matrix's CSC
+// view, which a caller that keeps one (dgsparse.Storage) already has.  It replaces the column histogram (nnz atomicAdds) and
+// its scan: 0.87 + 0.03 of the build's 1.5 ms on the headline graph.
+extern "C" int dgs_spmm_plan_build2(int64_t M, int64_t K, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                                    const int32_t *col_prefix, void *plan, size_t plan_bytes, void *workspace,
+                                    size_t workspace_bytes, dgsSpmmPlanInfo *info, dgsStream_t stream) {
   if (M <= 0 || K <= 0 || nnz <= 0 || !rowptr || !col || !plan || !workspace) return DGS_EINVAL;
   if (M >= INT32_MAX || K >= INT32_MAX || nnz >= INT32_MAX) return DGS_ERANGE;
   const PlanLayout PL = plan_layout(nnz);
@@ -343,11 +352,15 @@ extern "C" int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int3
   if (hipMemsetAsync(keys_in, 0xFF, (size_t)PL.max_units * 8, st) != hipSuccess) return DGS_ELAUNCH;  // unused = last
   if (hipMemsetAsync(units_in, 0, (size_t)PL.max_units * 16, st) != hipSuccess) return DGS_ELAUNCH;
 
-  hipLaunchKernelGGL(plan_hist, dim3(2048), dim3(kBlock), 0, st, (int)nnz, (int)K, col, cnt);
   size_t tb = WL.tmp_bytes;
-  if (rocprim::exclusive_scan(tmp, tb, cnt, cum, 0, (size_t)(K + 1), rocprim::plus<int>(), st, false) != hipSuccess)
-    return DGS_ELAUNCH;
-  hipLaunchKernelGGL(plan_bounds, dim3(1), dim3(192), 0, st, (int)K, (int)nnz, cum, hdr, bounds, (int)M, ch, kT1, tslice,
+  const int *prefix = col_prefix;
+  if (!prefix) {
+    hipLaunchKernelGGL(plan_hist, dim3(2048), dim3(kBlock), 0, st, (int)nnz, (int)K, col, cnt);
+    if (rocprim::exclusive_scan(tmp, tb, cnt, cum, 0, (size_t)(K + 1), rocprim::plus<int>(), st, false) != hipSuccess)
+      return DGS_ELAUNCH;
+    prefix = cum;
+  }
+  hipLaunchKernelGGL(plan_bounds, dim3(1), dim3(192), 0, st, (int)K, (int)nnz, prefix, hdr, bounds, (int)M, ch, kT1, tslice,
                      unit);
   hipLaunchKernelGGL(plan_longlist, dim3((unsigned)((M + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int)M, kT1, rowptr,
                      pw, list);

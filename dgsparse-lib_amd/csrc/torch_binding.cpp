@@ -327,17 +327,24 @@ std::vector<Tensor> spmm_plan_op(Tensor rowptr_, Tensor col_, int64_t n_cols) {
 
 // Non-blocking build, first half: (rowptr, col, n_cols) -> [build buffer (uint8, GPU), header copy (256 uint8, pinned CPU)].
 // Everything is queued on the CURRENT stream (the caller makes that a side stream); no host synchronisation.
-std::vector<Tensor> spmm_plan_start_op(Tensor rowptr_, Tensor col_, int64_t n_cols) {
+std::vector<Tensor> spmm_plan_start_op(Tensor rowptr_, Tensor col_, int64_t n_cols, OptTensor col_prefix) {
   const Tensor rowptr = i32vec(rowptr_, "rowptr"), col = i32vec(col_, "col");
   same_device(rowptr, col, "rowptr and col");
+  Tensor prefix;  // the CSC view's colptr, when the caller keeps one: replaces the column histogram of the build
+  if (has(col_prefix)) {
+    prefix = i32vec(*col_prefix, "col_prefix");
+    same_device(prefix, col, "col_prefix and col");
+    TORCH_CHECK(prefix.numel() == n_cols + 1, "dgsparse: col_prefix must have n_cols + 1 entries");
+  }
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(rowptr.device());
   const int64_t M = rowptr.numel() - 1, nnz = col.numel();
   TORCH_CHECK(M > 0 && nnz > 0 && n_cols > 0, "dgsparse: cannot plan an empty matrix");
   const size_t pb = dgs_spmm_plan_bytes(M, n_cols, nnz), wb = dgs_spmm_plan_workspace_bytes(M, n_cols, nnz);
   Tensor plan = workspace(pb, rowptr), ws = workspace(wb, rowptr);
   Tensor hdr = at::zeros({DGS_PLAN_HEADER_BYTES}, at::TensorOptions().dtype(at::kByte).device(at::kCPU).pinned_memory(true));
-  check_rc(dgs_spmm_plan_build(M, n_cols, nnz, rowptr.data_ptr<int>(), col.data_ptr<int>(), plan.data_ptr(), pb,
-                               ws.data_ptr(), wb, nullptr, cur_stream()),
+  check_rc(dgs_spmm_plan_build2(M, n_cols, nnz, rowptr.data_ptr<int>(), col.data_ptr<int>(),
+                                prefix.defined() ? prefix.data_ptr<int>() : nullptr, plan.data_ptr(), pb, ws.data_ptr(), wb,
+                                nullptr, cur_stream()),
            "spmm_plan_build");
   TORCH_CHECK(hipMemcpyAsync(hdr.data_ptr(), plan.data_ptr(), DGS_PLAN_HEADER_BYTES, hipMemcpyDeviceToHost,
                              static_cast<hipStream_t>(cur_stream())) == hipSuccess, "dgsparse: header copy failed");

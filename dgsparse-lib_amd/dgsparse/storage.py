@@ -47,10 +47,11 @@ class _SharedPlan:
     hands out the build buffer with PROVISIONAL counts (upper bounds from those sums: the kernels read the real counts
     from the device header, the host only sizes grids and the workspace with them); once the build's event has
     completed, a later use swaps in the compacted plan with the real counts and drops the worst-case build buffer."""
-    __slots__ = ('ptr', 'idx', 'K', 'calls', 'ready', 'prov', '__weakref__')
+    __slots__ = ('ptr', 'idx', 'K', 'prefix', 'calls', 'ready', 'prov', '__weakref__')
 
-    def __init__(self, ptr, idx, K):
+    def __init__(self, ptr, idx, K, prefix=None):
         self.ptr, self.idx, self.K = ptr, idx, K
+        self.prefix = prefix  # pointer array of the OTHER view (colptr for the CSR plan): the column histogram, for free
         self.calls = 0
         self.ready = None   # (compact plan buffer, plan info) once the build has been seen complete
         self.prov = None    # (build buffer, provisional info, pinned header copy, event, stream) in between
@@ -65,7 +66,7 @@ class _SharedPlan:
                 ev.synchronize()
             elif not ev.query():
                 return (None, None)  # the sums have not arrived yet (only right after construction): next time
-            buf, hdr = torch.ops.dgsparse_spmm.spmm_plan_start(self.ptr, self.idx, self.K)  # queued on `cur`
+            buf, hdr = torch.ops.dgsparse_spmm.spmm_plan_start(self.ptr, self.idx, self.K, self.prefix)  # queued on `cur`
             done = torch.cuda.Event()
             done.record(cur)
             info = _capi.plan_provisional_info(self.idx.numel(), *host.tolist())
@@ -221,9 +222,9 @@ class Storage(object):
         if not (self.nnz and self._col.is_cuda) or os.environ.get('DGS_PLAN', '1') == '0':
             return (None, None)
         if which == 'csr':
-            ptr, idx, M, K = self._rowptr, self._col, self.sparse_sizes[0], self.sparse_sizes[1]
+            ptr, idx, M, K, other = self._rowptr, self._col, self.sparse_sizes[0], self.sparse_sizes[1], self._colptr
         else:
-            ptr, idx, M, K = self._colptr, self._csc_row, self.sparse_sizes[1], self.sparse_sizes[0]
+            ptr, idx, M, K, other = self._colptr, self._csc_row, self.sparse_sizes[1], self.sparse_sizes[0], self._rowptr
         rows = self._sched.get((which, n_feat))
         if rows is None:  # the schedule depends on the feature width: decided per width, not once per Storage
             rows = self._sched[(which, n_feat)] = M > 0 and _capi.spmm_schedule(_capi.SUM, M, K, n_feat, self.nnz) == 'rows'
@@ -234,7 +235,7 @@ class Storage(object):
             key = (ptr.data_ptr(), idx.data_ptr(), ptr.numel(), idx.numel(), ptr._version, idx._version, K)
             sp = _SHARED_PLANS.get(key)
             if sp is None:
-                sp = _SHARED_PLANS[key] = _SharedPlan(ptr, idx, K)
+                sp = _SHARED_PLANS[key] = _SharedPlan(ptr, idx, K, other if other.numel() == K + 1 else None)
             self._plans[which] = sp
         if sp.ready is not None:
             return sp.ready

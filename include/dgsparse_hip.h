@@ -121,6 +121,11 @@ size_t dgs_spmm_plan_workspace_bytes(int64_t M, int64_t K, int64_t nnz);
 int dgs_spmm_plan_build(int64_t M, int64_t K, int64_t nnz, const int32_t *rowptr, const int32_t *col, void *plan,
                         size_t plan_bytes, void *workspace, size_t workspace_bytes, dgsSpmmPlanInfo *info,
                         dgsStream_t stream);
+/* The same build with the column histogram supplied: col_prefix[c] = number of entries with column < c for c = 0 .. K (the
+ * colptr of the CSC view; NULL = count it here).  Saves the nnz atomicAdds of the histogram, ~60 % of the build time. */
+int dgs_spmm_plan_build2(int64_t M, int64_t K, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                         const int32_t *col_prefix, void *plan, size_t plan_bytes, void *workspace, size_t workspace_bytes,
+                         dgsSpmmPlanInfo *info, dgsStream_t stream);
 /* Build without blocking: call dgs_spmm_plan_build with info == NULL (no host synchronisation at all), copy the first
  * DGS_PLAN_HEADER_BYTES of the plan buffer to (pinned) host memory behind it on the same stream, and hand that copy to
  * dgs_spmm_plan_info_from_header once the copy has completed (event query): it fills *info exactly as the blocking build

