@@ -481,7 +481,12 @@ def main():
                 schedule=_capi.spmm_schedule(_capi.SUM, st3['M'], st3['K'], 128, st3['nnz']),
                 ms_per_step=round(w3 / 10 * 1e3, 4), gflops=round(2.0 * st3['nnz'] * 128 / (w3 / 10) / 1e9, 1),
                 alg_gbs=round(b3 / (e3 / 10) / 1e9, 1), frac=round(b3 / (e3 / 10) / 1e9 / HBM_PEAK_GBS, 4),
-                alg_bytes_per_launch=int(b3))
+                alg_bytes_per_launch=int(b3),
+                # this configuration's compulsory intensity (~25 flop/B, B fits the Infinity Cache) puts it
+                # under the L2 gather rate, not under HBM: one 512-byte row of B per nnz through the CUs' vector-memory
+                # pipelines, measured at 20.6 TB/s chip-wide for L2 hits (experiments/gather_policy.cpp)
+                gather=dict(bytes_per_launch=int(st3['nnz']) * 128 * 4, achieved_tbs=round(st3['nnz'] * 512 / (e3 / 10) / 1e12, 2),
+                            l2_gather_rate_tbs=20.6, frac=round(st3['nnz'] * 512 / (e3 / 10) / 1e12 / 20.6, 3)))
             try:
                 tj3 = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
                 if 'C3_sum_feat128_panel' in tj3:
