@@ -142,9 +142,33 @@ def synthetic_partition(rank: int, world: int, n_local: int, deg: int, cols: str
     return RowPartition(rank, world, [i * n_local for i in range(world + 1)], rowptr.to(torch.int32), col, val)
 
 
+class _Done:
+    """Work handle of a collective that has already completed (the staged gloo path below)."""
+
+    def wait(self):
+        return True
+
+
+def _staged(t: torch.Tensor, group) -> bool:
+    """GPU tensors on a gloo group: gloo has no all-to-all for device memory, so the collective is staged through the host.
+    Never the production path (backend nccl = RCCL moves device memory directly); it lets SEVERAL ranks share ONE GPU, which
+    is how tests/test_gpu_dist.py runs the N > 1 code paths with the real HIP kernels on a single-GPU box."""
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits: List[int], in_splits: List[int], group=None, async_op=False):
+    """all_to_all_single with per-peer splits (first-dim rows); returns a work handle when async_op."""
+    if _staged(out, group):
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(host, inp.cpu().contiguous(), out_splits, in_splits, group=group)
+        out.copy_(host)
+        return _Done() if async_op else None
+    return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
+
+
 def _all_to_all_v(out: torch.Tensor, inp: torch.Tensor, out_splits: List[int], in_splits: List[int], group=None):
     """all_to_all_single with per-peer splits (first-dim rows); nccl(RCCL) and gloo both implement it."""
-    dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+    _a2a(out, inp, out_splits, in_splits, group)
 
 
 class HaloPlan:
@@ -285,7 +309,12 @@ class DistSpMM:
         self.B_ext = torch.empty((part.n_local + self.n_halo, n_feat), dtype=torch.float32, device=dev)
         t = torch.tensor([part.nnz], dtype=torch.int64, device=dev)
         if part.world > 1 and not standalone:
-            dist.all_reduce(t, group=group)
+            if _staged(t, group):
+                h = t.cpu()
+                dist.all_reduce(h, group=group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, group=group)
         self.global_nnz = int(t.item())
         self.last_E = None       # global column ids of the last max/min
         self.last_E_ext = None   # the same in the extended index space (what the backward needs)
@@ -297,8 +326,9 @@ class DistSpMM:
         mine = torch.tensor([p.nnz, p.n_local, self.n_halo, int(plan.send_ids.numel())], dtype=torch.int64,
                             device=p.col.device)
         if p.world > 1 and not self.standalone:
-            allv = [torch.empty_like(mine) for _ in range(p.world)]
-            dist.all_gather(allv, mine, group=self.group)
+            src = mine.cpu() if _staged(mine, self.group) else mine
+            allv = [torch.empty_like(src) for _ in range(p.world)]
+            dist.all_gather(allv, src, group=self.group)
             t = torch.stack(allv).double()
         else:
             t = mine.double()[None]
@@ -318,8 +348,7 @@ class DistSpMM:
         work = None
         if p.world > 1 and not self.standalone:
             self._packed = self.ops.gather_rows(self.B_ext[:p.n_local], plan.send_ids)  # kept alive until waited
-            work = dist.all_to_all_single(self.B_ext[p.n_local:], self._packed, plan.recv_splits, plan.send_splits,
-                                          group=self.group, async_op=async_op)
+            work = _a2a(self.B_ext[p.n_local:], self._packed, plan.recv_splits, plan.send_splits, self.group, async_op)
         return self.B_ext, work
 
     def compute(self, reduce: str = 'sum', val: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -388,8 +417,7 @@ class DistSpMM:
         g_loc = g_ext[:p.n_local].contiguous()
         if p.world > 1 and not self.standalone:
             back = torch.empty((int(plan.send_ids.numel()), g_ext.shape[1]), dtype=torch.float32, device=g_ext.device)
-            dist.all_to_all_single(back, g_ext[p.n_local:].contiguous(), plan.send_splits, plan.recv_splits,
-                                   group=self.group)
+            _a2a(back, g_ext[p.n_local:].contiguous(), plan.send_splits, plan.recv_splits, self.group)
             off = 0
             for n in plan.send_splits:  # one peer at a time: ids are unique inside a peer's block
                 if n:
@@ -402,7 +430,7 @@ class DistSpMM:
         plan = self.plan
         back = torch.empty((int(plan.send_ids.numel()), g_halo.shape[1]), dtype=torch.float32, device=g_halo.device)
         self._g_halo = g_halo.contiguous()  # kept alive until waited
-        work = dist.all_to_all_single(back, self._g_halo, plan.send_splits, plan.recv_splits, group=self.group, async_op=True)
+        work = _a2a(back, self._g_halo, plan.send_splits, plan.recv_splits, self.group, async_op=True)
         return back, work
 
     def _add_halo_grads(self, g_loc: torch.Tensor, back: torch.Tensor, work) -> torch.Tensor:

@@ -41,6 +41,16 @@ def test_dist_hip_single_rank_under_launcher():
     _run_workers(1, dict(DGS_TEST_ROWS_PER_RANK='70000'))  # > 2^16 rows: the planned row-stream schedule
 
 
+@pytest.mark.parametrize('world,rows', [(2, '40000'), (3, '25000'), (4, '20000')])
+def test_dist_hip_several_ranks_on_one_gpu(world, rows):
+    """N > 1 with the REAL HIP kernels on a single-GPU box: every rank runs on cuda:0 under a gloo group and the
+    collectives are staged through the host (dgsparse.dist._a2a).  Everything except the RCCL transport is the production
+    code: halo plan, pack kernel, overlapped local / accumulating halo products (sum, mean, sorted max), E relabel to global
+    ids, forward of every reduce and both gradients through the (overlapped) reversed exchange, each rank's rows checked
+    against the single-process oracle on the whole graph."""
+    _run_workers(world, dict(DGS_TEST_BACKEND='gloo', DGS_TEST_ROWS_PER_RANK=rows))
+
+
 def test_dist_hip_multi_rank():
     n = min(torch.cuda.device_count(), 8)
     if n < 2:
