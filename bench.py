@@ -199,13 +199,30 @@ def main():
     pg = dist_on or ('RANK' in os.environ and a.force_dist)  # process group (also for a 1-rank launcher run: tests)
     if a.gpus != world and dist_on:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
+    # DGS_BENCH_BACKEND=gloo: functional dry run of the N > 1 branch on a box with ONE GPU - every rank on cuda:0, collectives
+    # staged through the host by dgsparse.dist (tests/test_gpu_dist.py); the numbers of such a run mean nothing
+    one_gpu = os.environ.get('DGS_BENCH_BACKEND') == 'gloo'
+    if one_gpu:
+        local_rank = 0
     if not torch.cuda.is_available() or local_rank >= torch.cuda.device_count():
         raise SystemExit(f'bench.py needs {max(a.gpus, 1)} GPU(s); visible: {torch.cuda.device_count()}')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if pg:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.distributed.init_process_group('nccl', device_id=dev)
+        if one_gpu:
+            torch.distributed.init_process_group('gloo')
+        else:
+            torch.distributed.init_process_group('nccl', device_id=dev)
+
+    def allreduce_max(x):  # gloo (dry run) reduces on the host
+        if one_gpu:
+            h = x.cpu()
+            torch.distributed.all_reduce(h, op=torch.distributed.ReduceOp.MAX)
+            x.copy_(h)
+        else:
+            torch.distributed.all_reduce(x, op=torch.distributed.ReduceOp.MAX)
+
 
     import dgsparse  # noqa: F401
     from dgsparse import _capi
@@ -301,7 +318,7 @@ def main():
         wall_x, _ = time_steps(lambda: eng.exchange(Xloc), ex_steps, 2, pg)
         tx = torch.tensor([wall_x], device=dev, dtype=torch.float64)
         if pg:
-            torch.distributed.all_reduce(tx, op=torch.distributed.ReduceOp.MAX)
+            allreduce_max(tx)
         extra['exchange_only_ms'] = round(tx.item() / ex_steps * 1e3, 4)
         workload = f'synthetic power-law CSR {K}x{K} ({Mloc} rows/GPU, ~{a.deg}/row), cols={a.cols}, ' \
                    f'locality={a.locality}, SpMM-{a.reduce} feat={N}, 1-D row partition + halo all-to-all-v'
@@ -312,7 +329,7 @@ def main():
     wall, ev = time_steps(step, a.steps, a.warmup, pg)
     t = torch.tensor([wall, ev], device=dev, dtype=torch.float64)
     if pg:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        allreduce_max(t)
     wall, ev = t.tolist()
     flops = 2.0 * nnz_total * N
     ms = wall / a.steps * 1e3
@@ -444,7 +461,7 @@ def main():
             ws, ww = max(5, a.steps // 5), 3
             wall_w, _ = time_steps(lambda: eng_w.spmm(Xw, a.reduce), ws, ww, True)
             tw = torch.tensor([wall_w, float(eng_w.n_halo)], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
+            allreduce_max(tw)
             res['worst_case'] = dict(cols='uniform', locality=round(1.0 / world, 4), steps=ws,
                                      ms_per_step=round(tw[0].item() / ws * 1e3, 4),
                                      value=round(2.0 * eng_w.global_nnz * N / (tw[0].item() / ws) / 1e9, 2),

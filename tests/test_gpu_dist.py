@@ -51,6 +51,27 @@ def test_dist_hip_several_ranks_on_one_gpu(world, rows):
     _run_workers(world, dict(DGS_TEST_BACKEND='gloo', DGS_TEST_ROWS_PER_RANK=rows))
 
 
+def test_bench_multi_rank_branch_dry_run_on_one_gpu():
+    """bench.py --gpus 2 as the driver launches it, but with both ranks on cuda:0 over gloo (DGS_BENCH_BACKEND=gloo): the
+    N > 1 branch - partition generator, halo plan across ranks, overlapped step, max-over-ranks timing, imbalance figures,
+    exchange-only time, worst-case second run - executes end to end.  A functional check only: its numbers mean nothing."""
+    import json
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', DGS_BENCH_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rows-log2', '17', '--steps', '3',
+           '--warmup', '1', '--settle', '2']
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert j['n_gpus'] == 2 and j['value'] > 0 and j['config']['parallelism'].startswith('rowpart2')
+    assert j['halo']['rows_per_gpu'] > 0 and j['imbalance']['nnz']['max_over_mean'] >= 1.0 and j['exchange_only_ms'] > 0
+    assert 'error' not in j.get('worst_case', {'error': 1}), j.get('worst_case')
+
+
 def test_dist_hip_multi_rank():
     n = min(torch.cuda.device_count(), 8)
     if n < 2:
