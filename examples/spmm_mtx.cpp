@@ -199,6 +199,39 @@ int main(int argc, char **argv) {
              pbad ? "FAILED" : "ok", pbad, ms / 100, 2.0 * nnz * N / (ms / 100) * 1e-6);
     }
   }
+  {  // strict-order sum (DGS_ALG_STRICT_NOFMA): the reference's own host loop (example/util/sp_util.hpp:73-83: C += val * B, a
+     // sequential fp32 chain per (row, feature), product rounded before the add) reproduced BIT FOR BIT for every row length
+    for (int r = 0; r < M; r++)
+      for (int f = 0; f < N; f++) {
+        volatile float acc = 0.f;  // volatile: no host-side contraction or reassociation of the chain
+        for (int p = indptr[r]; p < indptr[r + 1]; p++) {
+          volatile float t = val[p] * B[(size_t)indices[p] * N + f];
+          acc = acc + t;
+        }
+        Cref[(size_t)r * N + f] = acc;
+      }
+    int rc = dgs_spmm_csr_f32(DGS_SUM, M, K, N, nnz, d_ptr, d_idx, d_val, d_B, d_C, nullptr, DGS_ALG_STRICT_NOFMA, d_ws, wsb, st);
+    if (rc) {
+      fprintf(stderr, "dgs_spmm_csr_f32 (strict): %s\n", dgs_strerror(rc));
+      return 3;
+    }
+    HIP_OK(hipMemcpyAsync(C.data(), d_C, C.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    long bad = 0;
+    for (size_t i = 0; i < C.size(); i++) bad += memcmp(&C[i], &Cref[i], sizeof(float)) != 0;
+    bad_total += bad != 0;
+    for (int i = 0; i < 10; i++)
+      dgs_spmm_csr_f32(DGS_SUM, M, K, N, nnz, d_ptr, d_idx, d_val, d_B, d_C, nullptr, DGS_ALG_STRICT_NOFMA, d_ws, wsb, st);
+    HIP_OK(hipEventRecord(e0, st));
+    for (int i = 0; i < 100; i++)
+      dgs_spmm_csr_f32(DGS_SUM, M, K, N, nnz, d_ptr, d_idx, d_val, d_B, d_C, nullptr, DGS_ALG_STRICT_NOFMA, d_ws, wsb, st);
+    HIP_OK(hipEventRecord(e1, st));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    printf("[SpMM-sum, strict order] bit-exact vs the sequential host loop: %s (%ld of %zu elements differ)  time %.6f ms\n",
+           bad ? "FAILED" : "yes", bad, C.size(), ms / 100);
+  }
   {  // SDDMM
     std::vector<float> out(nnz), ref(nnz);
     for (int r = 0; r < M; r++)

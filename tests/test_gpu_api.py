@@ -216,6 +216,7 @@ def test_standalone_cabi_driver_on_mtx(tmp_path):
     out = subprocess.run([os.path.join(root, 'examples', 'spmm_mtx'), p, '48'], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count('passed') == 5 and 'FAILED' not in out.stdout
+    assert 'strict order] bit-exact vs the sequential host loop: yes' in out.stdout, out.stdout
     # a larger graph takes the row-stream schedule: the driver then also builds the cached plan through the C ABI
     # (build -> compact -> dgs_spmm_csr_plan_f32) and verifies the four reduces over it
     n = 70000
@@ -230,6 +231,7 @@ def test_standalone_cabi_driver_on_mtx(tmp_path):
     out = subprocess.run([os.path.join(root, 'examples', 'spmm_mtx'), p2, '32'], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count('passed') == 5 and out.stdout.count('verification ok') == 4 and 'FAILED' not in out.stdout
+    assert 'strict order] bit-exact vs the sequential host loop: yes' in out.stdout, out.stdout  # hub rows of 6000 nnz included
 
 
 def test_hip_graph_capture_and_replay():
