@@ -64,6 +64,21 @@ def one_case(rng, it):
                 if rng.integers(0, 2) and not os.environ.get('FUZZ_NO_STRICT'):
                     Cs, _ = capi.spmm(oracle.REDUCE[reduce], drp, dcol, dval, dX, algorithm=alg)
                     assert_bitexact(Cs.cpu().numpy(), oracle.spmm(reduce, rp, col, val, X, fma=fma)[0], tag + f' strict {reduce} fma={fma}')
+    if rng.integers(0, 2):  # round 3: fused epilogue == the unfused elementwise ops, bit for bit, on whatever schedule this shape takes
+        red = ('sum', 'mean')[int(rng.integers(0, 2))]
+        base, _ = capi.spmm(oracle.REDUCE[red], drp, dcol, dval, dX)
+        bias = dev((rng.integers(-4, 5, N) / 8).astype(np.float32)) if rng.integers(0, 2) else None
+        rs = dev((rng.integers(1, 5, M) / 4).astype(np.float32)) if rng.integers(0, 2) else None
+        relu = bool(rng.integers(0, 2))
+        got, _ = capi.spmm(oracle.REDUCE[red], drp, dcol, dval, dX, bias=bias, row_scale=rs, relu=relu)
+        want = base
+        if rs is not None:
+            want = want * rs[:, None]
+        if bias is not None:
+            want = want + bias
+        if relu:
+            want = torch.relu(want)
+        assert torch.equal(got, want), tag + f' epilogue {red} bias={bias is not None} rs={rs is not None} relu={relu}'
     capi.canary_check(tag + ' spmm')
     if col.shape[0] and M > 1 and rng.integers(0, 2) == 0:
         # round-2 entries: a forced locality plan must reproduce the plan-free results (max/min + E bit for bit, sum within
