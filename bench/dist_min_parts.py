@@ -1,0 +1,63 @@
+"""Compute-side cost of the overlapped min of dgsparse.dist on ONE rank's shard (no exchange: standalone plan, halo rows
+filled with random features): the one-pass product that has to wait for the exchange, against the pieces of the overlapped
+schedule - local product (runs under the exchange), detector scans, halo product over the rows cut in two, merge.
+    python bench/dist_min_parts.py [rows_log2=20] [deg=16] [feat=64] [world=8] [locality=0.8]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'dgsparse-lib_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def ms(fn, n=20):
+    for _ in range(3):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def main():
+    from dgsparse import dist as dd
+    av = [float(x) for x in sys.argv[1:]]
+    rows_log2, deg, N, world = (int(av[i]) if len(av) > i else d for i, d in enumerate((20, 16, 64, 8)))
+    locality = av[4] if len(av) > 4 else 0.8
+    dev = torch.device('cuda:0')
+    part = dd.synthetic_partition(3 % world, world, 1 << rows_log2, deg, locality=locality, seed=0, device=dev)
+    eng = dd.DistSpMM(part, N, standalone=True)
+    p, plan, ops = eng.part, eng.plan, eng.ops
+    eng.B_ext.copy_(torch.rand(eng.B_ext.shape, device=dev))
+    nl = p.n_local
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    R = int(plan.rem_rows.numel())
+    print(f'shard: {nl} rows, {p.nnz} nnz, {eng.n_halo} halo rows, {R} rows with remote entries, '
+          f'{int(plan.rem[1].numel())} remote nnz, feat {N}')
+    one = ms(lambda: eng.compute('min'))
+    loc = ms(lambda: ops.spmm(2, plan.loc[0], plan.loc[1], plan.loc[2], eng.B_ext[:nl], shared_gpu=True))
+    scan_loc = ms(lambda: (ops.nonfinite_flag(eng.B_ext[:nl], flag), ops.nonfinite_flag(p.val, flag)))
+    scan_halo = ms(lambda: ops.nonfinite_flag(eng.B_ext[nl:], flag))
+    halo = ms(lambda: ops.spmm(2, plan.rem2_rowptr, plan.rem[1], plan.rem[2], eng.B_ext[nl:]))
+    C, E = ops.spmm(2, plan.loc[0], plan.loc[1], plan.loc[2], eng.B_ext[:nl])
+    Ch, Eh = ops.spmm(2, plan.rem2_rowptr, plan.rem[1], plan.rem[2], eng.B_ext[nl:])
+    flag.zero_()
+    merge = ms(lambda: ops.spmm_min_merge(plan.rem_rows, plan.rem2_rowptr, Ch, Eh, nl, plan.loc[0], C, E, flag, p.rowptr,
+                                          plan.col_ext, p.val, eng.B_ext))
+    relabel = ms(lambda: ops.relabel(E, plan.ext2glob32))
+    print(f'one pass after the exchange (min + relabel)      {one:8.4f} ms')
+    print(f'under the exchange: local min {loc:.4f} + scans of local features / values {scan_loc:.4f}')
+    print(f'after the exchange: scan of the halo {scan_halo:.4f} + halo min over 2R rows {halo:.4f} + merge {merge:.4f} '
+          f'+ relabel {relabel:.4f} = {scan_halo + halo + merge + relabel:8.4f} ms')
+    print(f'exposed after the exchange: {one:.4f} -> {scan_halo + halo + merge + relabel:.4f} ms; '
+          f'total GPU work {one:.4f} -> {loc + scan_loc + scan_halo + halo + merge + relabel:.4f} ms')
+
+
+if __name__ == '__main__':
+    main()

@@ -105,6 +105,10 @@ _lib.dgs_gather_rows_f32.restype = _int
 _lib.dgs_gather_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 _lib.dgs_relabel_i32.restype = _int
 _lib.dgs_relabel_i32.argtypes = [_i64, _vp, _vp, _vp]
+_lib.dgs_nonfinite_flag_f32.restype = _int
+_lib.dgs_nonfinite_flag_f32.argtypes = [_i64, _vp, _vp, _vp]
+_lib.dgs_spmm_min_merge_f32.restype = _int
+_lib.dgs_spmm_min_merge_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
 _lib.dgs_scatter_add_rows_f32.restype = _int
 _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
@@ -115,7 +119,7 @@ EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_by
            'dgs_spmm_csr_plan_f32', 'dgs_spmm_csr_acc_f32', 'dgs_spmm_csr_acc_max_f32',
            'dgs_spmm_csr_schedule', 'dgs_spmm_arg_backward_f32', 'dgs_sddmm_csr_schedule',
            'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_plan_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
-           'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'dgs_relabel_i32', 'dgs_sddmm_coo_f32', 'dgs_gspmm_csr_workspace_bytes', 'dgs_gspmm_csr_f32', 'gespmmCsrSpMM',
+           'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'dgs_relabel_i32', 'dgs_nonfinite_flag_f32', 'dgs_spmm_min_merge_f32', 'dgs_sddmm_coo_f32', 'dgs_gspmm_csr_workspace_bytes', 'dgs_gspmm_csr_f32', 'gespmmCsrSpMM',
            'spmm_cuda', 'spmm_cuda_no_edge_value', 'sddmm_cuda_csr', 'sddmm_cuda_coo', 'gespmmAlgSel',
            'csrspmm_parreduce_rowbalance', 'csrspmm_parreduce_nnzbalance', 'csrspmm_seqreduce_rowbalance',
            'csrspmm_seqreduce_nnzbalance', 'csrspmm_rowcaching_rowbalance', 'csrspmm_rowcaching_nnzbalance']
@@ -602,6 +606,42 @@ def scatter_add_rows(dst, ids, src):
         _check(_lib.dgs_scatter_add_rows_f32(ids.numel(), src.shape[1], _p(ids), _p(src), _p(dst), _stream(dev)),
                'scatter_add')
     return dst
+
+
+def nonfinite_flag(x, flag):
+    """flag[0] |= 1 when x holds a NaN or an infinity (flag: int32 device tensor the caller zeroed); no host sync."""
+    dev = _need_gpu(x, flag)
+    if x.dtype != torch.float32 or not x.is_contiguous() or flag.dtype != torch.int32 or flag.numel() < 1:
+        raise TypeError('dgsparse: nonfinite_flag wants a contiguous float32 tensor and an int32 flag')
+    with _on_device(dev):
+        _check(_lib.dgs_nonfinite_flag_f32(x.numel(), _p(x), _p(flag), _stream(dev)), 'nonfinite_flag')
+    return flag
+
+
+def spmm_min_merge(rowmap, rowptr2, Ch, Eh, col_off, loc_rowptr, C, E, flag, rowptr, col, values, dense):
+    """In place (C, E)[rowmap[r]] <- MIN fold of  Ch[2r] | (C, E)[rowmap[r]] | Ch[2r + 1]  in CSR order, or the sequential
+    chain over the whole shard row when flag[0] != 0 (include/dgsparse_hip.h: dgs_spmm_min_merge_f32)."""
+    dev = _need_gpu(rowmap, rowptr2, Ch, Eh, loc_rowptr, C, E, flag, rowptr, col, values, dense)
+    rowmap, rowptr2, loc_rowptr = _i32(rowmap, 'rowmap'), _i32(rowptr2, 'rowptr2'), _i32(loc_rowptr, 'loc_rowptr')
+    rowptr, col = _i32(rowptr, 'rowptr'), _i32(col, 'col')
+    dense = _f32mat(dense, 'dense')
+    R, N = rowmap.numel(), dense.shape[1]
+    if rowptr2.numel() != 2 * R + 1:
+        raise ValueError('dgsparse: rowptr2 needs 2 * len(rowmap) + 1 entries')
+    for name, t, dt, rows in (('Ch', Ch, torch.float32, 2 * R), ('Eh', Eh, torch.int32, 2 * R),
+                              ('C', C, torch.float32, None), ('E', E, torch.int32, None)):
+        if t.dtype != dt or t.dim() != 2 or t.shape[1] != N or not t.is_contiguous() or (rows is not None and t.shape[0] != rows):
+            raise TypeError(f'dgsparse: {name} must be a contiguous {dt} [rows, {N}] tensor')
+    if E.shape != C.shape or loc_rowptr.numel() != C.shape[0] + 1 or rowptr.numel() != C.shape[0] + 1:
+        raise ValueError('dgsparse: C, E, loc_rowptr and rowptr describe different row counts')
+    if flag.dtype != torch.int32 or flag.numel() < 1:
+        raise TypeError('dgsparse: flag must be an int32 device tensor')
+    values = _f32vec(values, 'values', col.numel())
+    with _on_device(dev):
+        _check(_lib.dgs_spmm_min_merge_f32(R, N, _p(rowmap), _p(rowptr2), _p(Ch), _p(Eh), int(col_off), _p(loc_rowptr),
+                                           _p(C), _p(E), _p(flag), _p(rowptr), _p(col), _p(values), _p(dense),
+                                           _stream(dev)), 'spmm_min_merge')
+    return C, E
 
 
 def relabel_(ids, mapping):

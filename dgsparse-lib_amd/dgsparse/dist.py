@@ -14,7 +14,11 @@ with ONE all-to-all-v:
              compute : sum/mean: C = spmm(A_loc, B_loc) WHILE the exchange is in flight (RCCL runs on its own
                                  stream), then C[rem_rows] += spmm(A_rem, B_halo)   [A = A_loc + A_rem by column owner;
                                  A_rem holds only the rows that have a remote entry]
-                       max/min : C, E = spmm(A_ext, B_ext) after the exchange (one pass keeps first-wins ties exact)
+                       max/min : shards with sorted rows overlap too - (C, E) of the local columns while the halo
+                                 travels, then the halo part is merged in CSR order (max: accumulating kernel, ties to the
+                                 smaller global column; min: halo rows cut in two at the local columns + one fold
+                                 lower | local | higher, with a sequential redo when a NaN / inf is about) - bit-exact;
+                                 unsorted rows: C, E = spmm(A_ext, B_ext) after the exchange (one pass)
     backward (DistSpMMFn): the same plan reversed - gradients of halo rows travel home by all-to-all-v and are
              scatter-added; sum / mean / max / min, w.r.t. the feature rows and the edge values.
 
@@ -227,6 +231,18 @@ class HaloPlan:
             inc[starts[starts < col.numel()]] = True  # a REAL row start never breaks the order (trailing empty rows have
             # rowptr == nnz: clamping those to nnz-1 used to mask a descent inside the last non-empty row)
         self.rows_sorted = bool(inc.all())
+        # for the overlapped min (csrc/dist_merge.hip): the halo matrix with every row cut in two at the local columns -
+        # row 2r = the lower-rank halo entries of rem_rows[r], row 2r + 1 = the higher-rank ones; same (col, val) arrays
+        self.rem2_rowptr = None
+        if self.rows_sorted:
+            R = int(self.rem_rows.numel())
+            rp = self.rem[0].long()
+            rrow = torch.repeat_interleave(torch.arange(R, device=dev), rp[1:] - rp[:-1])
+            lo_cnt = torch.bincount(rrow[self.rem[1].long() < self.h_lo], minlength=R)
+            rp2 = torch.empty(2 * R + 1, dtype=torch.int64, device=dev)
+            rp2[0::2] = rp
+            rp2[1::2] = rp[:-1] + lo_cnt
+            self.rem2_rowptr = rp2.to(torch.int32).contiguous()
         if world == 1 or standalone:  # nothing to exchange; no process group needed
             self.send_splits = [0] * world
             self.send_ids = torch.zeros(0, dtype=torch.int32, device=dev)
@@ -268,6 +284,14 @@ class _HipOps:
         """(C, E)[rowmap[r]] <- better of the old pair and the max over row r (dgs_spmm_csr_acc_max_f32), in place."""
         return self._c.spmm_acc_max(rowptr, col, val, B, C, E, rowmap, col_off, n_local, h_lo,
                                     plan=self._plan(rowptr, col, B.shape[0], B.shape[1]))
+
+    def nonfinite_flag(self, x, flag):
+        """flag |= 1 if x holds a NaN or an infinity (stream-ordered, no host sync)."""
+        return self._c.nonfinite_flag(x, flag)
+
+    def spmm_min_merge(self, rowmap, rowptr2, Ch, Eh, col_off, loc_rowptr, C, E, flag, rowptr, col, val, B):
+        """(C, E)[rowmap[r]] <- lower halo | local | higher halo folded with MIN in CSR order (dgs_spmm_min_merge_f32)."""
+        return self._c.spmm_min_merge(rowmap, rowptr2, Ch, Eh, col_off, loc_rowptr, C, E, flag, rowptr, col, val, B)
 
     def sddmm(self, rowptr, col, D1, D2, op=0, E=None):
         return self._c.sddmm(rowptr, col, D1, D2, op, E=E)
@@ -391,6 +415,30 @@ class DistSpMM:
             if plan.rem_rows.numel() > 0:
                 self.ops.spmm_acc_max(plan.rem[0], plan.rem[1], vr, B_ext[p.n_local:], C, E, plan.rem_rows, p.n_local,
                                       p.n_local, plan.h_lo)
+            self.last_E_ext = E
+            self.last_E = self.ops.relabel(E, plan.ext2glob32)
+            return C
+        if self.overlap and p.world > 1 and not self.standalone and reduce == 'min' and plan.rows_sorted:
+            # min: the local (value, arg) while the halo travels, the halo product over the rows cut in two at the local
+            # columns, then ONE fold  lower halo -> local -> higher halo  per row that has remote entries.  MIN cannot be
+            # merged across a NaN product, so features and edge values are scanned for NaN / inf on the way (stream-
+            # ordered flag, no host sync) and the merge kernel recomputes its rows sequentially when the flag is up
+            B_ext, work = self.exchange(B_loc, async_op=True)
+            vl = plan.loc[2] if val is None else val[plan.nnz_pos_loc]
+            vr = plan.rem[2] if val is None else val[plan.nnz_pos_rem]
+            v_all = p.val if val is None else val
+            flag = torch.zeros(1, dtype=torch.int32, device=B_ext.device)
+            C, E = self.ops.spmm(2, plan.loc[0], plan.loc[1], vl, B_ext[:p.n_local], shared_gpu=True)
+            self.ops.nonfinite_flag(B_ext[:p.n_local], flag)
+            if v_all is not None:
+                self.ops.nonfinite_flag(v_all, flag)
+            if work is not None:
+                work.wait()
+            if plan.rem_rows.numel() > 0:
+                self.ops.nonfinite_flag(B_ext[p.n_local:], flag)
+                Ch, Eh = self.ops.spmm(2, plan.rem2_rowptr, plan.rem[1], vr, B_ext[p.n_local:])
+                self.ops.spmm_min_merge(plan.rem_rows, plan.rem2_rowptr, Ch, Eh, p.n_local, plan.loc[0], C, E, flag,
+                                        p.rowptr, plan.col_ext, v_all, B_ext)
             self.last_E_ext = E
             self.last_E = self.ops.relabel(E, plan.ext2glob32)
             return C

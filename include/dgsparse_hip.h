@@ -302,6 +302,21 @@ int dgs_scatter_add_rows_f32(int64_t n_ids, int64_t N, const int32_t *ids, const
 /* In-place relabel of arg ids: ids[i] = map[ids[i]] where ids[i] >= 0 (-1 = "no arg" stays).  The multi-GPU path
  * computes max/min in the extended [local | halo] column space and hands back GLOBAL column ids (new). */
 int dgs_relabel_i32(int64_t n, int32_t *ids, const int32_t *map, dgsStream_t stream);
+/* Overlapped MIN of the multi-GPU path for shards whose rows have sorted columns (new; csrc/dist_merge.hip has the
+ * argument for exactness).  (C, E) hold the min over the columns this rank owns (the product that ran while the halo was
+ * travelling); (Ch, Eh) [2R, N] hold the min over the halo entries of the R rows that have any, row 2r = those that come
+ * BEFORE the local columns of shard row rowmap[r] (lower ranks), row 2r + 1 = those AFTER (rowptr2 [2R + 1] is that
+ * matrix's row pointer; arg ids are halo slots, col_off is added).  loc_rowptr [rows + 1] is the row pointer of the local
+ * product (a row without local entries holds the empty-row 0 / -1, which must not take part).  The three pairs are folded
+ * in CSR order with algorithm 0's own MIN step, in place.  nonfinite (device int, may be NULL): when *nonfinite != 0 a
+ * product may be NaN and MIN stops being mergeable, so the R rows are recomputed sequentially over the whole shard
+ * (rowptr, col in extended ids, val or NULL, B = the [local | halo] buffer) instead.
+ * dgs_nonfinite_flag_f32 ORs 1 into *flag when x[0, n) holds a NaN or an infinity (the caller zeroes the flag). */
+int dgs_nonfinite_flag_f32(int64_t n, const float *x, int32_t *flag, dgsStream_t stream);
+int dgs_spmm_min_merge_f32(int64_t R, int64_t N, const int32_t *rowmap, const int32_t *rowptr2, const float *Ch,
+                           const int32_t *Eh, int32_t col_off, const int32_t *loc_rowptr, float *C, int32_t *E,
+                           const int32_t *nonfinite, const int32_t *rowptr, const int32_t *col, const float *val,
+                           const float *B, dgsStream_t stream);
 
 /* ---- GE-SpMM / SDDMM compatibility entry points (same names and argument order as the reference's
  *      standalone C libraries; default stream, void return) ------------------------------------- */

@@ -83,6 +83,26 @@ def main():
             else:
                 assert_close(Bl.grad.cpu().numpy(), gB[r0:r1], 2e-5, 1e-5, tag + ' dB')
             assert_close(vl.grad.cpu().numpy(), gW[s0:s1], 2e-5, 1e-5, tag + ' dW')
+        if overlap:
+            # overlapped min in its corners (csrc/dist_merge.hip): signed zeros - MIN keeps the LATER operand's bits on a tie,
+            # E the first arg - and NaN / inf features, where the merge has to give way to the sequential redo
+            rng = np.random.default_rng(11)
+            Xz = rng.choice(np.array([-0.0, 0.0, 0.0, 1.0, -1.0], np.float32), size=(M, N))
+            Xn = X.copy()
+            for bad in (np.nan, np.inf, -np.inf):
+                Xn[rng.integers(0, M, 60), rng.integers(0, N, 60)] = bad
+            for name, Xc, has_val in (('signed zeros', Xz, True), ('signed zeros, no values', Xz, False),
+                                      ('NaN / inf features', Xn, True)):
+                vc = val if has_val else None
+                pc = dd.partition_csr(rp, col, vc, world)[rank]
+                pc.rowptr, pc.col = pc.rowptr.to(dev), pc.col.to(dev)
+                pc.val = None if pc.val is None else pc.val.to(dev)
+                ec = dd.DistSpMM(pc, N, overlap=True)
+                assert ec.plan.rows_sorted and ec.plan.rem2_rowptr is not None
+                Cc = ec.spmm(torch.from_numpy(Xc[r0:r1].copy()).to(dev), 'min')
+                Cg, Eg = oracle.spmm('min', rp, col, vc, Xc, fma=True)
+                assert_bitexact(Cc.cpu().numpy(), Cg[r0:r1], f'rank {rank}/{world} overlapped min, {name}: values')
+                assert_bitexact(ec.last_E.cpu().numpy(), Eg[r0:r1], f'rank {rank}/{world} overlapped min, {name}: E')
         remote = np.unique(col[s0:s1][(col[s0:s1] < r0) | (col[s0:s1] >= r1)])
         assert eng.n_halo == remote.shape[0] and eng.global_nnz == col.shape[0]
     torch.cuda.synchronize()

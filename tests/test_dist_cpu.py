@@ -42,6 +42,40 @@ class OracleOps:
         E[rowmap.long()] = torch.from_numpy(np.where(take, en, Eo).astype(np.int32))
         return C, E
 
+    def nonfinite_flag(self, x, flag):
+        if not bool(torch.isfinite(x).all()):
+            flag |= 1
+        return flag
+
+    def spmm_min_merge(self, rowmap, rowptr2, Ch, Eh, col_off, loc_rowptr, C, E, flag, rowptr, col, val, B):
+        """numpy restatement of dgs_spmm_min_merge_f32 (include/dgsparse_hip.h): lower halo | local | higher halo folded
+        with algorithm 0's MIN step, or the whole-row chain (the oracle) when the flag is up."""
+        import oracle
+        rm = rowmap.long().numpy()
+        if int(flag[0]):
+            Cf, Ef = oracle.spmm(2, rowptr.numpy(), col.numpy(), None if val is None else val.numpy(), B.numpy())
+            C[rowmap.long()] = torch.from_numpy(Cf[rm])
+            E[rowmap.long()] = torch.from_numpy(Ef[rm])
+            return C, E
+        rp2, lrp = rowptr2.numpy(), loc_rowptr.numpy()
+        R, N = rm.shape[0], C.shape[1]
+        acc = np.full((R, N), np.float32(2147483647), np.float32)
+        e = np.full((R, N), -1, np.int32)
+
+        def step(b, eb, live):
+            nonlocal acc, e
+            with np.errstate(invalid='ignore'):
+                gt, lt = acc > b, acc < b
+            e = np.where(live[:, None] & gt, eb, e).astype(np.int32)
+            acc = np.where(live[:, None] & ~lt, b, acc)
+        Chn, Ehn = Ch.numpy(), Eh.numpy()
+        step(Chn[0::2], Ehn[0::2] + col_off, rp2[0:-1:2] < rp2[1::2])
+        step(C.numpy()[rm], E.numpy()[rm], lrp[rm] < lrp[rm + 1])
+        step(Chn[1::2], Ehn[1::2] + col_off, rp2[1::2] < rp2[2::2])
+        C[rowmap.long()] = torch.from_numpy(acc)
+        E[rowmap.long()] = torch.from_numpy(e)
+        return C, E
+
     def gather_rows(self, src, ids):
         return src[ids.long()].contiguous()
 
@@ -112,11 +146,26 @@ def _worker(rank, world, port, cols, q):
             if red in ('sum', 'mean'):  # overlapped path: local part + halo part, summation order differs
                 Co = eng_ov.spmm(torch.from_numpy(X[r0:r1].copy()), red)
                 res[red + '_overlap'] = bool(np.allclose(Co.numpy(), Cg[r0:r1], rtol=1e-5, atol=2e-6))
-            if red == 'max':  # overlapped max: two products merged by global column order: values AND E bit-exact
+            if red in ('max', 'min'):  # overlapped max / min: products merged in CSR order: values AND E bit-exact
                 assert eng_ov.plan.rows_sorted
                 Co = eng_ov.spmm(torch.from_numpy(X[r0:r1].copy()), red)
-                res['max_overlap'] = bool(np.array_equal(Co.numpy().view(np.int32), Cg[r0:r1].view(np.int32)) and
-                                          np.array_equal(eng_ov.last_E.numpy(), Eg[r0:r1]))
+                res[red + '_overlap'] = bool(np.array_equal(Co.numpy().view(np.int32), Cg[r0:r1].view(np.int32)) and
+                                             np.array_equal(eng_ov.last_E.numpy(), Eg[r0:r1]))
+        # overlapped min in its corners: signed zeros (MIN keeps the LATER operand's bits on a tie, E the first arg) and
+        # NaN / inf features (MIN forgets what came before a NaN product: the merge must give way to the sequential redo)
+        rng = np.random.default_rng(11)
+        Xz = rng.choice(np.array([-0.0, 0.0, 0.0, 1.0, -1.0], np.float32), size=(M, N))
+        Xn = X.copy()
+        Xn[rng.integers(0, M, 40), rng.integers(0, N, 40)] = np.nan
+        Xn[rng.integers(0, M, 40), rng.integers(0, N, 40)] = np.inf
+        Xn[rng.integers(0, M, 40), rng.integers(0, N, 40)] = -np.inf
+        for name, Xc, vc in (('zeros', Xz, val), ('zeros_noval', Xz, None), ('nonfinite', Xn, val)):
+            pc = dd.partition_csr(rp, col, vc, world)[rank]
+            ec = dd.DistSpMM(pc, N, ops=OracleOps(), overlap=True)
+            Co = ec.spmm(torch.from_numpy(Xc[r0:r1].copy()), 'min')
+            Cg, Eg = oracle.spmm('min', rp, col, vc, Xc)
+            res['min_overlap_' + name] = bool(np.array_equal(Co.numpy().view(np.int32), Cg[r0:r1].view(np.int32)) and
+                                              np.array_equal(ec.last_E.numpy(), Eg[r0:r1]))
         # backward of sum w.r.t. B through the reversed exchange == rows [r0,r1) of A^T G on the whole graph
         G = (np.random.default_rng(2).integers(-2, 3, (M, N)) / 4).astype(np.float32)
         Bl = torch.from_numpy(X[r0:r1].copy()).requires_grad_()

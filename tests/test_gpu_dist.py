@@ -161,3 +161,69 @@ def test_bench_partitioned_path_under_the_launcher():
     assert j['n_gpus'] == 1 and j['value'] > 0 and j['config']['parallelism'].startswith('rowpart1')
     assert 'halo' in j and 'error' not in j.get('worst_case', {'error': 1}), j.get('worst_case')
     assert j['roofline']['frac'] > 0 and j['scaling'] == 'weak'
+
+
+@pytest.mark.parametrize('N', [32, 7])
+def test_min_merge_and_nonfinite_flag_through_the_c_abi(N):
+    """dgs_spmm_min_merge_f32 / dgs_nonfinite_flag_f32 on their own: a matrix whose columns are cut in three ranges
+    [lower | local | higher] the way a shard of dgsparse.dist is, every row's min put together from the three products and
+    compared bit for bit with the one-pass kernel AND the oracle - with signed zeros (the tie corner), with the flag forced
+    up (the sequential redo), and with a NaN the detector has to find at any alignment."""
+    from dgsparse import _capi
+    from bench import graphgen
+    dev = torch.device('cuda:0')
+    M, K = 3000, 3000
+    rp, col, st = graphgen.powerlaw_csr(M, 40 * M, K=K, alpha=2.0, dmax=900, cols='powerlaw', seed=9)
+    rng = np.random.default_rng(3)
+    val = rng.choice(np.array([-1.0, 0.5, 1.0, 2.0], np.float32), size=col.shape[0])
+    X = rng.choice(np.array([-0.0, 0.0, 0.0, 1.0, -1.0, 0.25], np.float32), size=(K, N))
+    lo, hi = 900, 2100  # local columns [lo, hi); ext ids: local -> c - lo, lower -> nl + c, higher -> nl + lo + (c - hi)
+    nl = hi - lo
+    ext = np.where((col >= lo) & (col < hi), col - lo, np.where(col < lo, nl + col, nl + lo + col - hi)).astype(np.int32)
+    Bext = np.concatenate([X[lo:hi], X[:lo], X[hi:]])
+    rows = np.repeat(np.arange(M), np.diff(rp))
+    is_loc = ext < nl
+
+    def sub(mask, shift):
+        cnt = np.bincount(rows[mask], minlength=M)
+        r = np.zeros(M + 1, np.int32)
+        r[1:] = np.cumsum(cnt)
+        return r, (ext[mask] - shift).astype(np.int32), val[mask]
+    lrp, lcol, lval = sub(is_loc, 0)
+    cnt_rem = np.bincount(rows[~is_loc], minlength=M)
+    rem_rows = np.nonzero(cnt_rem)[0].astype(np.int32)
+    cnt_lo = np.bincount(rows[~is_loc & (ext - nl < lo)], minlength=M)
+    R = rem_rows.shape[0]
+    rp2 = np.zeros(2 * R + 1, np.int64)
+    rp2[1::2] = cnt_lo[rem_rows]
+    rp2[2::2] = cnt_rem[rem_rows] - cnt_lo[rem_rows]
+    rp2 = np.cumsum(rp2).astype(np.int32)
+    hcol, hval = (ext[~is_loc] - nl).astype(np.int32), val[~is_loc]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    Bd = t(Bext)
+    full_rp, full_col, full_val = t(rp), t(ext), t(val)
+    Cref, Eref = oracle.spmm('min', rp, ext, val, Bext, fma=True)
+    C1, E1 = _capi.spmm(_capi.MIN, full_rp, full_col, full_val, Bd)
+    assert_bitexact(C1.cpu().numpy(), Cref, 'one-pass min')
+    for force in (0, 1):
+        flag = torch.full((1,), force, dtype=torch.int32, device=dev)
+        C, E = _capi.spmm(_capi.MIN, t(lrp), t(lcol), t(lval), Bd[:nl])
+        Ch, Eh = _capi.spmm(_capi.MIN, t(rp2), t(hcol), t(hval), Bd[nl:])
+        _capi.spmm_min_merge(t(rem_rows), t(rp2), Ch, Eh, nl, t(lrp), C, E, flag, full_rp, full_col, full_val, Bd)
+        assert_bitexact(C.cpu().numpy(), Cref, f'merged min values (flag {force})')
+        assert_bitexact(E.cpu().numpy(), Eref, f'merged min E (flag {force})')
+    # the detector: clean data leaves the flag alone; one NaN / inf anywhere (any alignment, head, tail) raises it
+    for off in (0, 1, 3):
+        x = torch.rand(100003, device=dev)[off:].contiguous() if off == 0 else torch.rand(100003 + off, device=dev)[off:]
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        _capi.nonfinite_flag(x.contiguous() if off == 0 else x, flag)
+        assert int(flag) == 0
+        for pos, bad in ((0, float('nan')), (x.numel() - 1, float('inf')), (x.numel() // 2 + 1, float('-inf'))):
+            y = x.clone()
+            if off:
+                y = torch.empty(x.numel() + off, device=dev)[off:]
+                y.copy_(x)
+            y[pos] = bad
+            flag.zero_()
+            _capi.nonfinite_flag(y, flag)
+            assert int(flag) == 1, (off, pos, bad)
