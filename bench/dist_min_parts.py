@@ -51,12 +51,13 @@ def main():
     merge = ms(lambda: ops.spmm_min_merge(plan.rem_rows, plan.rem2_rowptr, Ch, Eh, nl, plan.loc[0], C, E, flag, p.rowptr,
                                           plan.col_ext, p.val, eng.B_ext))
     relabel = ms(lambda: ops.relabel(E, plan.ext2glob32))
-    print(f'one pass after the exchange (min + relabel)      {one:8.4f} ms')
+    print(f'one pass after the exchange                      {one:8.4f} ms')
     print(f'under the exchange: local min {loc:.4f} + scans of local features / values {scan_loc:.4f}')
     print(f'after the exchange: scan of the halo {scan_halo:.4f} + halo min over 2R rows {halo:.4f} + merge {merge:.4f} '
-          f'+ relabel {relabel:.4f} = {scan_halo + halo + merge + relabel:8.4f} ms')
-    print(f'exposed after the exchange: {one:.4f} -> {scan_halo + halo + merge + relabel:.4f} ms; '
-          f'total GPU work {one:.4f} -> {loc + scan_loc + scan_halo + halo + merge + relabel:.4f} ms')
+          f'= {scan_halo + halo + merge:8.4f} ms')
+    print(f'exposed after the exchange: {one:.4f} -> {scan_halo + halo + merge:.4f} ms; '
+          f'total GPU work {one:.4f} -> {loc + scan_loc + scan_halo + halo + merge:.4f} ms')
+    print(f'global column ids of E on demand (DistSpMM.last_E): {relabel:.4f} ms')
 
 
 if __name__ == '__main__':
