@@ -179,6 +179,28 @@ __device__ __forceinline__ void load_vec_gather(const float *p, float (&o)[V]) {
 #endif
 }
 typedef float dgs_f2 __attribute__((ext_vector_type(2)));
+// SDDMM's row operand D1: every row is used by its own nnz within one short window and never again, so reading it
+// non-temporally (DGS_SD_D1_NT = 1) should keep it from pushing rows of the GATHERED operand out of L2.  Measured and left
+// off: the per-nnz re-loads of the row then stop hitting L1 - 1M graph 455 -> 514 us, products-shaped 2227 -> 2306 us.
+#ifndef DGS_SD_D1_NT
+#define DGS_SD_D1_NT 0
+#endif
+template <int V>
+__device__ __forceinline__ void load_vec_rowop(const float *p, float (&o)[V]) {
+#if DGS_SD_D1_NT
+  if constexpr (V == 4) {
+    const dgs_f4 t = __builtin_nontemporal_load(reinterpret_cast<const dgs_f4 *>(p));
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3];
+  } else if constexpr (V == 2) {
+    const dgs_f2 t = __builtin_nontemporal_load(reinterpret_cast<const dgs_f2 *>(p));
+    o[0] = t[0]; o[1] = t[1];
+  } else {
+    o[0] = __builtin_nontemporal_load(p);
+  }
+#else
+  load_vec<V>(p, o);
+#endif
+}
 template <int V>
 __device__ __forceinline__ void store_vec_stream(float *p, const float (&o)[V]) {
 #if DGS_NT

@@ -66,7 +66,7 @@ __device__ __forceinline__ void sd_tile_dots(const int2 *tile, int *cnt, int cnt
         int m[kSdU][V];
 #pragma unroll
         for (int q = 0; q < kSdU; q++) {
-          load_vec<V>(D1 + (int64_t)cr[q].y * F + f, a[q]);
+          load_vec_rowop<V>(D1 + (int64_t)cr[q].y * F + f, a[q]);
           load_vec<V>(D2 + (int64_t)cr[q].x * F + f, b[q]);
           if constexpr (MASK) load_vec<V>(E + (int64_t)cr[q].y * F + f, m[q]);
         }
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kBlock) void sddmm_coo(int F, int tiles, int nnz, c
           float a[kSdU][V], b[kSdU][V];
 #pragma unroll
           for (int q = 0; q < kSdU; q++) {
-            load_vec<V>(D1 + (int64_t)cr[q].y * F + f, a[q]);
+            load_vec_rowop<V>(D1 + (int64_t)cr[q].y * F + f, a[q]);
             load_vec<V>(D2 + (int64_t)cr[q].x * F + f, b[q]);
           }
 #pragma unroll

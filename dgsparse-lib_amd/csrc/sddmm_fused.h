@@ -92,7 +92,7 @@ __device__ __forceinline__ void sddmm_units_body(int bid, int nblocks, SfLds &ld
     const int4 d = ut.units[u];  // {row, first nnz, nnz in the unit, -}
     float a[V];
     int m[V];
-    load_vec<V>(D1 + (int64_t)d.x * F + fo, a);
+    load_vec_rowop<V>(D1 + (int64_t)d.x * F + fo, a);
     if constexpr (MASK) load_vec<V>(E + (int64_t)d.x * F + fo, m);
     float scale = 1.0f;
     if constexpr (MEAN) scale = (float)(rowptr[d.x + 1] - rowptr[d.x]);
@@ -219,7 +219,7 @@ __device__ __forceinline__ void sddmm_rows_body(int bid, int rpw, SfLds &lds, in
       // measured no faster (1M graph 462 vs 468 us, products-shaped 2347 vs 2279) and hipcc 7.2 miscompiled the copies for G = 64
 #pragma unroll
       for (int q = 0; q < kSfU; q++) {
-        load_vec<V>(D1 + (int64_t)(r0 + cr[q].y) * F + fo, av[q]);
+        load_vec_rowop<V>(D1 + (int64_t)(r0 + cr[q].y) * F + fo, av[q]);
         if constexpr (MASK) load_vec<V>(E + (int64_t)(r0 + cr[q].y) * F + fo, mv[q]);
       }
 #pragma unroll
