@@ -163,8 +163,9 @@ def test_bench_partitioned_path_under_the_launcher():
     assert j['roofline']['frac'] > 0 and j['scaling'] == 'weak'
 
 
-@pytest.mark.parametrize('N', [32, 7])
-def test_min_merge_and_nonfinite_flag_through_the_c_abi(N):
+@pytest.mark.parametrize('N,lo,hi,has_val', [(32, 900, 2100, True), (7, 900, 2100, True), (16, 0, 1500, True),
+                                             (16, 1500, 3000, False), (8, 1200, 1200, True), (64, 0, 3000, True)])
+def test_min_merge_and_nonfinite_flag_through_the_c_abi(N, lo, hi, has_val):
     """dgs_spmm_min_merge_f32 / dgs_nonfinite_flag_f32 on their own: a matrix whose columns are cut in three ranges
     [lower | local | higher] the way a shard of dgsparse.dist is, every row's min put together from the three products and
     compared bit for bit with the one-pass kernel AND the oracle - with signed zeros (the tie corner), with the flag forced
@@ -177,7 +178,10 @@ def test_min_merge_and_nonfinite_flag_through_the_c_abi(N):
     rng = np.random.default_rng(3)
     val = rng.choice(np.array([-1.0, 0.5, 1.0, 2.0], np.float32), size=col.shape[0])
     X = rng.choice(np.array([-0.0, 0.0, 0.0, 1.0, -1.0, 0.25], np.float32), size=(K, N))
-    lo, hi = 900, 2100  # local columns [lo, hi); ext ids: local -> c - lo, lower -> nl + c, higher -> nl + lo + (c - hi)
+    # local columns [lo, hi); ext ids: local -> c - lo, lower -> nl + c, higher -> nl + lo + (c - hi).  The parameters also
+    # cover: no lower ranks, no higher ranks, no local columns at all, nothing remote (R = 0), no edge values
+    if not has_val:
+        val = None
     nl = hi - lo
     ext = np.where((col >= lo) & (col < hi), col - lo, np.where(col < lo, nl + col, nl + lo + col - hi)).astype(np.int32)
     Bext = np.concatenate([X[lo:hi], X[:lo], X[hi:]])
@@ -188,7 +192,7 @@ def test_min_merge_and_nonfinite_flag_through_the_c_abi(N):
         cnt = np.bincount(rows[mask], minlength=M)
         r = np.zeros(M + 1, np.int32)
         r[1:] = np.cumsum(cnt)
-        return r, (ext[mask] - shift).astype(np.int32), val[mask]
+        return r, (ext[mask] - shift).astype(np.int32), (None if val is None else val[mask])
     lrp, lcol, lval = sub(is_loc, 0)
     cnt_rem = np.bincount(rows[~is_loc], minlength=M)
     rem_rows = np.nonzero(cnt_rem)[0].astype(np.int32)
@@ -198,8 +202,8 @@ def test_min_merge_and_nonfinite_flag_through_the_c_abi(N):
     rp2[1::2] = cnt_lo[rem_rows]
     rp2[2::2] = cnt_rem[rem_rows] - cnt_lo[rem_rows]
     rp2 = np.cumsum(rp2).astype(np.int32)
-    hcol, hval = (ext[~is_loc] - nl).astype(np.int32), val[~is_loc]
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    hcol, hval = (ext[~is_loc] - nl).astype(np.int32), (None if val is None else val[~is_loc])
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     Bd = t(Bext)
     full_rp, full_col, full_val = t(rp), t(ext), t(val)
     Cref, Eref = oracle.spmm('min', rp, ext, val, Bext, fma=True)
@@ -207,7 +211,13 @@ def test_min_merge_and_nonfinite_flag_through_the_c_abi(N):
     assert_bitexact(C1.cpu().numpy(), Cref, 'one-pass min')
     for force in (0, 1):
         flag = torch.full((1,), force, dtype=torch.int32, device=dev)
-        C, E = _capi.spmm(_capi.MIN, t(lrp), t(lcol), t(lval), Bd[:nl])
+        if nl > 0:
+            C, E = _capi.spmm(_capi.MIN, t(lrp), t(lcol), t(lval), Bd[:nl])
+        else:  # a shard that owns no column: what an empty product leaves behind
+            C, E = torch.zeros((M, N), device=dev), torch.full((M, N), -1, dtype=torch.int32, device=dev)
+        if R == 0:
+            assert_bitexact(C.cpu().numpy(), Cref, 'nothing remote: the local product is the result')
+            continue
         Ch, Eh = _capi.spmm(_capi.MIN, t(rp2), t(hcol), t(hval), Bd[nl:])
         _capi.spmm_min_merge(t(rem_rows), t(rp2), Ch, Eh, nl, t(lrp), C, E, flag, full_rp, full_col, full_val, Bd)
         assert_bitexact(C.cpu().numpy(), Cref, f'merged min values (flag {force})')
