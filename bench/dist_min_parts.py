@@ -1,6 +1,6 @@
 """Compute-side cost of the overlapped min of dgsparse.dist on ONE rank's shard (no exchange: standalone plan, halo rows
 filled with random features): the one-pass product that has to wait for the exchange, against the pieces of the overlapped
-schedule - local product (runs under the exchange), detector scans, halo product over the rows cut in two, merge.
+schedule - local product (runs under the exchange), detector scans, the two accumulating halo products, the redo-only call.
     python bench/dist_min_parts.py [rows_log2=20] [deg=16] [feat=64] [world=8] [locality=0.8]"""
 import os
 import sys
@@ -44,19 +44,20 @@ def main():
     loc = ms(lambda: ops.spmm(2, plan.loc[0], plan.loc[1], plan.loc[2], eng.B_ext[:nl], shared_gpu=True))
     scan_loc = ms(lambda: (ops.nonfinite_flag(eng.B_ext[:nl], flag), ops.nonfinite_flag(p.val, flag)))
     scan_halo = ms(lambda: ops.nonfinite_flag(eng.B_ext[nl:], flag))
-    halo = ms(lambda: ops.spmm(2, plan.rem2_rowptr, plan.rem[1], plan.rem[2], eng.B_ext[nl:]))
     C, E = ops.spmm(2, plan.loc[0], plan.loc[1], plan.loc[2], eng.B_ext[:nl])
-    Ch, Eh = ops.spmm(2, plan.rem2_rowptr, plan.rem[1], plan.rem[2], eng.B_ext[nl:])
+    halo = eng.B_ext[nl:]
+    acc_lo = ms(lambda: ops.spmm_acc_min(plan.rem_lo[0], plan.rem_lo[1], plan.rem_lo[2], halo, C, E, plan.rem_lo_rows, nl, True))
+    acc_hi = ms(lambda: ops.spmm_acc_min(plan.rem_hi[0], plan.rem_hi[1], plan.rem_hi[2], halo, C, E, plan.rem_hi_rows, nl, False))
     flag.zero_()
-    merge = ms(lambda: ops.spmm_min_merge(plan.rem_rows, plan.rem2_rowptr, Ch, Eh, nl, plan.loc[0], C, E, flag, p.rowptr,
-                                          plan.col_ext, p.val, eng.B_ext))
+    redo = ms(lambda: ops.min_redo(plan.rem_rows, C, E, flag, p.rowptr, plan.col_ext, p.val, eng.B_ext))
     relabel = ms(lambda: ops.relabel(E, plan.ext2glob32))
+    after = scan_halo + acc_lo + acc_hi + redo
     print(f'one pass after the exchange                      {one:8.4f} ms')
     print(f'under the exchange: local min {loc:.4f} + scans of local features / values {scan_loc:.4f}')
-    print(f'after the exchange: scan of the halo {scan_halo:.4f} + halo min over 2R rows {halo:.4f} + merge {merge:.4f} '
-          f'= {scan_halo + halo + merge:8.4f} ms')
-    print(f'exposed after the exchange: {one:.4f} -> {scan_halo + halo + merge:.4f} ms; '
-          f'total GPU work {one:.4f} -> {loc + scan_loc + scan_halo + halo + merge:.4f} ms')
+    print(f'after the exchange: scan of the halo {scan_halo:.4f} + lower halo folded in front {acc_lo:.4f} '
+          f'({int(plan.rem_lo[1].numel())} nnz, {int(plan.rem_lo_rows.numel())} rows) + higher halo behind {acc_hi:.4f} '
+          f'({int(plan.rem_hi[1].numel())} nnz, {int(plan.rem_hi_rows.numel())} rows) + redo-if-flagged {redo:.4f} = {after:8.4f} ms')
+    print(f'exposed after the exchange: {one:.4f} -> {after:.4f} ms; total GPU work {one:.4f} -> {loc + scan_loc + after:.4f} ms')
     print(f'global column ids of E on demand (DistSpMM.last_E): {relabel:.4f} ms')
 
 

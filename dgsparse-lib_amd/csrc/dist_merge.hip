@@ -12,6 +12,9 @@
 // NaN inside a segment makes the chain forget everything before it, which no (value, arg) pair can express.  A product
 // can only be NaN if a feature or an edge value is NaN or infinite; dgs_nonfinite_flag_f32 looks for those, and when the
 // flag is up the kernel recomputes its rows sequentially over the whole [local | halo] shard instead of merging.
+// The schedule dgsparse.dist actually uses folds the two halo halves into (C, E) with the accumulating min kernels instead
+// (dgs_spmm_csr_acc_min_f32, lower half then higher half: no (Ch, Eh) round trip through memory) and calls this kernel
+// with rowptr2 == NULL: nothing to merge, only the redo when the flag is up.
 #include "dgs_common.h"
 
 namespace dgs {
@@ -57,7 +60,9 @@ __global__ __launch_bounds__(kBlock) void min_merge_kernel(int64_t R, int N, con
     acc[v] = reduce_init<DGS_MIN>();
     e[v] = -1;
   }
-  if (nonfinite && *nonfinite) {  // uniform: the chain itself, over the whole shard row
+  const bool redo = nonfinite && *nonfinite;  // uniform
+  if (!rowptr2 && !redo) return;              // redo-only call (the accumulating min kernels did the merge) and nothing to redo
+  if (redo) {  // the chain itself, over the whole shard row
     for (int p = rowptr[row], pe = rowptr[row + 1]; p < pe; p++) {
       const int c = col[p];
       const float w = HAS_VAL ? val[p] : 1.0f;
@@ -116,10 +121,11 @@ extern "C" int dgs_spmm_min_merge_f32(int64_t R, int64_t N, const int32_t *rowma
                                       const float *val, const float *B, dgsStream_t stream) {
   if (R < 0 || N < 0 || N >= INT32_MAX || 2 * R >= INT32_MAX) return DGS_EINVAL;
   if (R == 0 || N == 0) return DGS_OK;
-  if (!rowptr2 || !Ch || !Eh || !loc_rowptr || !C || !E) return DGS_EINVAL;
+  if (!C || !E) return DGS_EINVAL;
+  if (rowptr2 ? (!Ch || !Eh || !loc_rowptr) : !nonfinite) return DGS_EINVAL;  // rowptr2 == NULL: redo-only call
   if (nonfinite && (!rowptr || !col || !B)) return DGS_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool v4 = (N % 4 == 0) && is_aligned16(Ch) && is_aligned16(Eh) && is_aligned16(C) && is_aligned16(E) &&
+  const bool v4 = (N % 4 == 0) && (!rowptr2 || (is_aligned16(Ch) && is_aligned16(Eh))) && is_aligned16(C) && is_aligned16(E) &&
                   (!nonfinite || is_aligned16(B));
   const int64_t lanes = v4 ? N / 4 : N;
   const dim3 grid((unsigned)((R * lanes + kBlock - 1) / kBlock));

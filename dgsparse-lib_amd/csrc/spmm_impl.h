@@ -477,12 +477,20 @@ struct RowsLds {
 //        columns), whose ids live in one extended space [0, nl) = local, [nl, ...) = halo slots in global order; h_lo
 //        halo slots belong to lower ranks, i.e. come BEFORE the local columns in a row.  key() restores that order, so
 //        for rows with sorted columns "smaller key" = "earlier in CSR order" and MAX's rule (the earlier operand keeps
-//        value and arg on a tie) is reproduced exactly.  (MIN keeps the LATER operand's value bits on a tie while E
-//        names the first one; the position of the last minimum is not recoverable from (C, E), so min is not offered.)
+//        value and arg on a tie) is reproduced exactly.
+//   min  MIN keeps the LATER operand's value bits on a tie while E names the FIRST minimum, so a pair can be appended to
+//        what precedes it in the row or the other way round, but two pairs of interleaved column sets cannot be merged.
+//        The caller therefore says where this product's columns lie: h_lo != 0 = they all PRECEDE the columns (C, E)
+//        already cover, h_lo == 0 = they all FOLLOW them (dgsparse.dist: the lower-rank halo entries, then the higher-rank
+//        ones, in two launches), and the commit is algorithm 0's own step applied to the two pairs in that order.  An
+//        output row the earlier products had no entry for holds the empty-row (0, -1); a non-empty MIN result with arg -1
+//        can only be the identity, so (arg < 0 and value != identity) marks it and the new pair simply replaces it.
+//        Exact unless a product is NaN (a NaN makes the chain forget what came before): dist_merge.hip has the detector
+//        and the sequential redo that go with it.
 struct AccArg {
   const int *rowmap;  // output row of every row of A (nullptr = identity)
   int col_off;        // added to this product's arg column ids (halo slot -> extended id)
-  int nl, h_lo;       // extended-id layout: local columns [0, nl), h_lo of the halo slots precede them
+  int nl, h_lo;       // max: extended-id layout: local columns [0, nl), h_lo of the halo slots precede them; min: see above
   Epi epi;            // plain (non-accumulating) sum / mean only: bias / row scale / relu at the row-end store
 };
 template <int OP>
@@ -519,6 +527,32 @@ __device__ __forceinline__ void acc_commit(float *__restrict__ C, int *__restric
       store_vec_stream<V>(ep, ev);
       store_vec_stream<V>(cp, cv);
     }
+  } else if constexpr (OP == DGS_MIN) {
+    int *ep = E + orow * N + f0;
+    int eo[V];
+    load_vec<V>(ep, eo);
+    const bool first = aa.h_lo != 0;  // this product's columns precede the ones (old, eo) cover
+    float cv[V];
+    int ev[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+      const int en = ei[v] >= 0 ? ei[v] + aa.col_off : -1;
+      const float a = first ? acc[v] : old[v], b = first ? old[v] : acc[v];  // a comes first in the row
+      const int ea = first ? en : eo[v], eb = first ? eo[v] : en;
+      const bool old_empty = (eo[v] < 0) & (old[v] != reduce_init<DGS_MIN>());
+      // algorithm 0's step with res = a, t = b (branch-free, fresh arrays: see the max case)
+      const float mv = (a < b) ? a : b;
+      const int me = (a > b) ? eb : ea;
+      cv[v] = old_empty ? acc[v] : mv;
+      ev[v] = old_empty ? en : me;
+    }
+    if constexpr (HIDDEN) {
+      store_vec_hidden<V>(ep, ev);
+      store_vec_hidden<V>(cp, cv);
+    } else {
+      store_vec_stream<V>(ep, ev);
+      store_vec_stream<V>(cp, cv);
+    }
   } else {
     float cv[V];
 #pragma unroll
@@ -540,7 +574,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
                                                const float *__restrict__ B, float *__restrict__ C,
                                                int *__restrict__ E, const AccArg aa = AccArg{},
                                                float *strict_xb = nullptr) {
-  static_assert(!ACC || OP == DGS_SUM || OP == DGS_MAX, "accumulation exists for sum and max");
+  static_assert(!ACC || OP == DGS_SUM || OP == DGS_MAX || OP == DGS_MIN, "accumulation exists for sum, max and min");
   static_assert(STRICT == 0 || ((OP == DGS_SUM || OP == DGS_MEAN) && !ACC), "strict order exists for plain sum and mean");
   const int *rowmap = aa.rowmap;
   constexpr int NG = kWave / G;
@@ -1090,7 +1124,7 @@ struct SpmmArgs {
   const struct PlanHdr *plan = nullptr;
   int plan_units = 0, plan_long = 0, plan_pslots = 0, plan_off_long = 0;
   int hints = 0;  // DGS_ALG_* bits of the `algorithm` argument
-  bool accumulate = false;      // merge into C (and E) instead of overwriting (sum, max): see AccArg
+  bool accumulate = false;      // merge into C (and E) instead of overwriting (sum, max, min): see AccArg
   AccArg acc{};
 };
 
@@ -1378,8 +1412,8 @@ static int dispatch_strict(int G, const SpmmArgs &a) {
 
 template <int G, int V, int OP, bool HAS_VAL>
 static int launch_all(const SpmmArgs &a) {
-  if (a.accumulate) {  // merge into C / (C, E) (sum, max; never the column-panel sweep)
-    if constexpr (OP == DGS_SUM || OP == DGS_MAX) return launch_impl<G, V, OP, HAS_VAL, true>(a);
+  if (a.accumulate) {  // merge into C / (C, E) (sum, max, min; never the column-panel sweep)
+    if constexpr (OP == DGS_SUM || OP == DGS_MAX || OP == DGS_MIN) return launch_impl<G, V, OP, HAS_VAL, true>(a);
     else return DGS_EINVAL;
   }
   return launch_impl<G, V, OP, HAS_VAL, false>(a);

@@ -210,6 +210,38 @@ extern "C" int dgs_spmm_csr_acc_max_f32(int64_t M, int64_t K, int64_t N, int64_t
   return run(fm, a);
 }
 
+// (C, E)[rowmap[r], :] = algorithm 0's MIN step applied to what they hold and the min over row r of A, in row order:
+// precedes != 0 = this product's columns all come BEFORE the ones (C, E) cover, 0 = all AFTER (spmm_impl.h AccArg).
+extern "C" int dgs_spmm_csr_acc_min_f32(int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,
+                                        const int32_t *col, const float *val, const float *B, float *C, int32_t *E,
+                                        const int32_t *rowmap, int32_t col_off, int32_t precedes, const void *plan,
+                                        const dgsSpmmPlanInfo *info, void *workspace, size_t workspace_bytes,
+                                        dgsStream_t stream) {
+  if (M < 0 || K < 0 || N < 0 || nnz < 0) return DGS_EINVAL;
+  if (M >= INT32_MAX || K >= INT32_MAX || N >= INT32_MAX || nnz >= INT32_MAX) return DGS_ERANGE;
+  if (M == 0 || N == 0 || nnz == 0) return DGS_OK;
+  if (!rowptr || !C || !E || !col || !B) return DGS_EINVAL;
+  const bool planned = plan && info && !tiny_problem(M, nnz);
+  if (planned && !is_aligned16(plan)) return DGS_EINVAL;
+  const size_t need = planned ? dgs_spmm_csr_plan_workspace_bytes(DGS_MIN, M, N, nnz, info)
+                              : dgs_spmm_csr_workspace_bytes(DGS_MIN, M, N, nnz);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return DGS_EWORKSPACE;
+  const bool al = is_aligned16(B) && is_aligned16(C) && is_aligned16(E) && (need == 0 || is_aligned16(workspace));
+  const FeatMap fm = feat_map(N, al);
+  SpmmArgs a{M, K, N, nnz, rowptr, col, val, B, C, E, fm.tiles, need ? workspace : nullptr,
+             static_cast<hipStream_t>(stream), DGS_MIN};
+  a.accumulate = true;
+  a.acc = AccArg{rowmap, col_off, 0, precedes ? 1 : 0};
+  if (planned) {
+    a.plan = static_cast<const PlanHdr *>(plan);
+    a.plan_units = info->n_units;
+    a.plan_long = info->n_long;
+    a.plan_pslots = info->n_pslots;
+    a.plan_off_long = info->off_long;
+  }
+  return run(fm, a);
+}
+
 // Masked SpMM (max/min backward w.r.t. the dense operand) on the CSC arrays: same launcher, internal op kOpMaskSum.
 extern "C" size_t dgs_spmm_csr_mask_workspace_bytes(int64_t Mout, int64_t N, int64_t nnz) {
   return dgs_spmm_csr_workspace_bytes(DGS_SUM, Mout, N, nnz);

@@ -77,6 +77,9 @@ _lib.dgs_spmm_csr_acc_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp
 _lib.dgs_spmm_csr_acc_max_f32.restype = _int
 _lib.dgs_spmm_csr_acc_max_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp,
                                           ctypes.POINTER(PlanInfo), _vp, _sz, _vp]
+_lib.dgs_spmm_csr_acc_min_f32.restype = _int
+_lib.dgs_spmm_csr_acc_min_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp,
+                                          ctypes.POINTER(PlanInfo), _vp, _sz, _vp]
 _lib.dgs_spmm_csr_mask_f32.restype = _int
 _lib.dgs_spmm_csr_mask_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
 _lib.dgs_spmm_csr_mask_workspace_bytes.restype = _sz
@@ -116,7 +119,7 @@ EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_spmm_csr_workspace_by
            'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes', 'dgs_spmm_plan_build', 'dgs_spmm_plan_build2',
            'dgs_spmm_plan_compact_bytes', 'dgs_spmm_plan_compact', 'dgs_spmm_plan_info_from_header',
            'dgs_spmm_plan_thresholds', 'dgs_spmm_plan_provisional_info', 'dgs_spmm_csr_ex_f32', 'dgs_spmm_csr_plan_workspace_bytes',
-           'dgs_spmm_csr_plan_f32', 'dgs_spmm_csr_acc_f32', 'dgs_spmm_csr_acc_max_f32',
+           'dgs_spmm_csr_plan_f32', 'dgs_spmm_csr_acc_f32', 'dgs_spmm_csr_acc_max_f32', 'dgs_spmm_csr_acc_min_f32',
            'dgs_spmm_csr_schedule', 'dgs_spmm_arg_backward_f32', 'dgs_sddmm_csr_schedule',
            'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_plan_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
            'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'dgs_relabel_i32', 'dgs_nonfinite_flag_f32', 'dgs_spmm_min_merge_f32', 'dgs_sddmm_coo_f32', 'dgs_gspmm_csr_workspace_bytes', 'dgs_gspmm_csr_f32', 'gespmmCsrSpMM',
@@ -445,6 +448,43 @@ def spmm_acc_max(rowptr, col, values, dense, C, E, rowmap=None, col_off=0, n_loc
     return C, E
 
 
+def spmm_acc_min(rowptr, col, values, dense, C, E, rowmap=None, col_off=0, precedes=False, plan=None):
+    """(C, E)[rowmap[r], :] <- algorithm 0's MIN step on what they hold and the min over row r of A (args written as
+    col + col_off), in place; ``precedes``: this product's columns all come BEFORE the ones (C, E) cover in the row, else all
+    AFTER (include/dgsparse_hip.h: dgs_spmm_csr_acc_min_f32)."""
+    dev = _need_gpu(rowptr, col, values, dense, C, E, rowmap)
+    rowptr = _i32(rowptr, 'rowptr')
+    col = _i32(col, 'col')
+    dense = _f32mat(dense, 'dense')
+    M, nnz, (K, N) = rowptr.numel() - 1, col.numel(), dense.shape
+    if C.dtype != torch.float32 or C.dim() != 2 or C.shape[1] != N or not C.is_contiguous():
+        raise TypeError('dgsparse: C must be a contiguous float32 [rows, N] tensor')
+    if E.dtype != torch.int32 or E.shape != C.shape or not E.is_contiguous():
+        raise TypeError('dgsparse: E must be a contiguous int32 tensor with the shape of C')
+    if rowmap is not None:
+        rowmap = _i32(rowmap, 'rowmap')
+        if rowmap.numel() != M:
+            raise ValueError('dgsparse: rowmap needs one entry per row of A')
+    elif C.shape[0] < M:
+        raise ValueError('dgsparse: C has fewer rows than A')
+    values = _f32vec(values, 'values', nnz)
+    if plan is not None and (plan.M != M or plan.nnz != nnz or plan.col_ptr != col.data_ptr() or
+                             plan.rowptr_ptr != rowptr.data_ptr()):
+        raise ValueError('dgsparse: the plan was built for other (rowptr, col) arrays')
+    with _on_device(dev):
+        if plan is not None:
+            wsb = _lib.dgs_spmm_csr_plan_workspace_bytes(MIN, M, N, nnz, ctypes.byref(plan.info))
+        else:
+            wsb = _lib.dgs_spmm_csr_workspace_bytes(MIN, M, N, nnz)
+        ws = _new(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        _check(_lib.dgs_spmm_csr_acc_min_f32(M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(dense), _p(C), _p(E),
+                                             _p(rowmap), int(col_off), int(bool(precedes)),
+                                             _p(plan.buf) if plan is not None else None,
+                                             ctypes.byref(plan.info) if plan is not None else None, _p(ws), wsb,
+                                             _stream(dev)), 'spmm_acc_min')
+    return C, E
+
+
 SCHEDULES = ('small', 'rows', 'panel')
 
 
@@ -620,21 +660,29 @@ def nonfinite_flag(x, flag):
 
 def spmm_min_merge(rowmap, rowptr2, Ch, Eh, col_off, loc_rowptr, C, E, flag, rowptr, col, values, dense):
     """In place (C, E)[rowmap[r]] <- MIN fold of  Ch[2r] | (C, E)[rowmap[r]] | Ch[2r + 1]  in CSR order, or the sequential
-    chain over the whole shard row when flag[0] != 0 (include/dgsparse_hip.h: dgs_spmm_min_merge_f32)."""
+    chain over the whole shard row when flag[0] != 0 (include/dgsparse_hip.h: dgs_spmm_min_merge_f32).  rowptr2 = None:
+    redo-only call (Ch, Eh, loc_rowptr ignored) after the accumulating min kernels did the merge."""
     dev = _need_gpu(rowmap, rowptr2, Ch, Eh, loc_rowptr, C, E, flag, rowptr, col, values, dense)
-    rowmap, rowptr2, loc_rowptr = _i32(rowmap, 'rowmap'), _i32(rowptr2, 'rowptr2'), _i32(loc_rowptr, 'loc_rowptr')
+    rowmap = _i32(rowmap, 'rowmap')
     rowptr, col = _i32(rowptr, 'rowptr'), _i32(col, 'col')
     dense = _f32mat(dense, 'dense')
     R, N = rowmap.numel(), dense.shape[1]
-    if rowptr2.numel() != 2 * R + 1:
-        raise ValueError('dgsparse: rowptr2 needs 2 * len(rowmap) + 1 entries')
-    for name, t, dt, rows in (('Ch', Ch, torch.float32, 2 * R), ('Eh', Eh, torch.int32, 2 * R),
-                              ('C', C, torch.float32, None), ('E', E, torch.int32, None)):
+    checks = [('C', C, torch.float32, None), ('E', E, torch.int32, None)]
+    if rowptr2 is not None:
+        rowptr2, loc_rowptr = _i32(rowptr2, 'rowptr2'), _i32(loc_rowptr, 'loc_rowptr')
+        if rowptr2.numel() != 2 * R + 1:
+            raise ValueError('dgsparse: rowptr2 needs 2 * len(rowmap) + 1 entries')
+        if loc_rowptr.numel() != C.shape[0] + 1:
+            raise ValueError('dgsparse: loc_rowptr and C describe different row counts')
+        checks += [('Ch', Ch, torch.float32, 2 * R), ('Eh', Eh, torch.int32, 2 * R)]
+    else:
+        Ch = Eh = loc_rowptr = None
+    for name, t, dt, rows in checks:
         if t.dtype != dt or t.dim() != 2 or t.shape[1] != N or not t.is_contiguous() or (rows is not None and t.shape[0] != rows):
             raise TypeError(f'dgsparse: {name} must be a contiguous {dt} [rows, {N}] tensor')
-    if E.shape != C.shape or loc_rowptr.numel() != C.shape[0] + 1 or rowptr.numel() != C.shape[0] + 1:
-        raise ValueError('dgsparse: C, E, loc_rowptr and rowptr describe different row counts')
-    if flag.dtype != torch.int32 or flag.numel() < 1:
+    if E.shape != C.shape or rowptr.numel() != C.shape[0] + 1:
+        raise ValueError('dgsparse: C, E and rowptr describe different row counts')
+    if flag is None or flag.dtype != torch.int32 or flag.numel() < 1:
         raise TypeError('dgsparse: flag must be an int32 device tensor')
     values = _f32vec(values, 'values', col.numel())
     with _on_device(dev):

@@ -16,8 +16,9 @@ with ONE all-to-all-v:
                                  A_rem holds only the rows that have a remote entry]
                        max/min : shards with sorted rows overlap too - (C, E) of the local columns while the halo
                                  travels, then the halo part is merged in CSR order (max: accumulating kernel, ties to the
-                                 smaller global column; min: halo rows cut in two at the local columns + one fold
-                                 lower | local | higher, with a sequential redo when a NaN / inf is about) - bit-exact;
+                                 smaller global column; min: the lower-rank halo entries folded in front of the local
+                                 result and the higher-rank ones behind it, two accumulating launches, with a
+                                 sequential redo when a NaN / inf is about) - bit-exact;
                                  unsorted rows: C, E = spmm(A_ext, B_ext) after the exchange (one pass)
     backward (DistSpMMFn): the same plan reversed - gradients of halo rows travel home by all-to-all-v and are
              scatter-added; sum / mean / max / min, w.r.t. the feature rows and the edge values.
@@ -231,18 +232,18 @@ class HaloPlan:
             inc[starts[starts < col.numel()]] = True  # a REAL row start never breaks the order (trailing empty rows have
             # rowptr == nnz: clamping those to nnz-1 used to mask a descent inside the last non-empty row)
         self.rows_sorted = bool(inc.all())
-        # for the overlapped min (csrc/dist_merge.hip): the halo matrix with every row cut in two at the local columns -
-        # row 2r = the lower-rank halo entries of rem_rows[r], row 2r + 1 = the higher-rank ones; same (col, val) arrays
-        self.rem2_rowptr = None
+        # for the overlapped min: MIN can only be folded in row order (csrc/spmm_impl.h AccArg), so the halo entries are
+        # kept a second time as two compact matrices - the slots of lower ranks (they precede the local columns of a sorted
+        # row) and those of higher ranks (they follow them) - each with the shard rows it touches
+        self.rem_lo = self.rem_hi = None
         if self.rows_sorted:
-            R = int(self.rem_rows.numel())
-            rp = self.rem[0].long()
-            rrow = torch.repeat_interleave(torch.arange(R, device=dev), rp[1:] - rp[:-1])
-            lo_cnt = torch.bincount(rrow[self.rem[1].long() < self.h_lo], minlength=R)
-            rp2 = torch.empty(2 * R + 1, dtype=torch.int64, device=dev)
-            rp2[0::2] = rp
-            rp2[1::2] = rp[:-1] + lo_cnt
-            self.rem2_rowptr = rp2.to(torch.int32).contiguous()
+            lower = is_remote & (ext - nl < self.h_lo)
+            self.rem_lo, keep = _sub(lower, nl, True)
+            self.rem_lo_rows = keep.to(torch.int32).contiguous()
+            self.rem_hi, keep = _sub(is_remote & ~lower, nl, True)
+            self.rem_hi_rows = keep.to(torch.int32).contiguous()
+            self.nnz_pos_lo = torch.nonzero(lower).view(-1)
+            self.nnz_pos_hi = torch.nonzero(is_remote & ~lower).view(-1)
         if world == 1 or standalone:  # nothing to exchange; no process group needed
             self.send_splits = [0] * world
             self.send_ids = torch.zeros(0, dtype=torch.int32, device=dev)
@@ -289,9 +290,16 @@ class _HipOps:
         """flag |= 1 if x holds a NaN or an infinity (stream-ordered, no host sync)."""
         return self._c.nonfinite_flag(x, flag)
 
-    def spmm_min_merge(self, rowmap, rowptr2, Ch, Eh, col_off, loc_rowptr, C, E, flag, rowptr, col, val, B):
-        """(C, E)[rowmap[r]] <- lower halo | local | higher halo folded with MIN in CSR order (dgs_spmm_min_merge_f32)."""
-        return self._c.spmm_min_merge(rowmap, rowptr2, Ch, Eh, col_off, loc_rowptr, C, E, flag, rowptr, col, val, B)
+    def spmm_acc_min(self, rowptr, col, val, B, C, E, rowmap, col_off, precedes):
+        """(C, E)[rowmap[r]] <- MIN step on the old pair and the min over row r, this product's columns first if
+        ``precedes`` else last (dgs_spmm_csr_acc_min_f32), in place."""
+        return self._c.spmm_acc_min(rowptr, col, val, B, C, E, rowmap, col_off, precedes,
+                                    plan=self._plan(rowptr, col, B.shape[0], B.shape[1]))
+
+    def min_redo(self, rowmap, C, E, flag, rowptr, col, val, B):
+        """Rows rowmap of (C, E) recomputed sequentially over the whole shard IF flag != 0 (stream-ordered; the redo-only
+        form of dgs_spmm_min_merge_f32)."""
+        return self._c.spmm_min_merge(rowmap, None, None, None, 0, None, C, E, flag, rowptr, col, val, B)
 
     def sddmm(self, rowptr, col, D1, D2, op=0, E=None):
         return self._c.sddmm(rowptr, col, D1, D2, op, E=E)
@@ -428,14 +436,14 @@ class DistSpMM:
             self._last_E = None
             return C
         if self.overlap and p.world > 1 and not self.standalone and reduce == 'min' and plan.rows_sorted:
-            # min: the local (value, arg) while the halo travels, the halo product over the rows cut in two at the local
-            # columns, then ONE fold  lower halo -> local -> higher halo  per row that has remote entries.  MIN cannot be
-            # merged across a NaN product, so features and edge values are scanned for NaN / inf on the way (stream-
-            # ordered flag, no host sync) and the merge kernel recomputes its rows sequentially when the flag is up
+            # min: the local (value, arg) while the halo travels; then the lower-rank halo entries are folded in FRONT of
+            # it and the higher-rank ones BEHIND it (MIN keeps the later operand's bits on a tie, so only in-order folds
+            # are exact; two accumulating launches).  MIN cannot be folded across a NaN product at all, so features and
+            # edge values are scanned for NaN / inf on the way (stream-ordered flag, no host sync) and the rows that have
+            # remote entries are recomputed sequentially when the flag is up
             B_ext, work = self.exchange(B_loc, async_op=True)
-            vl = plan.loc[2] if val is None else val[plan.nnz_pos_loc]
-            vr = plan.rem[2] if val is None else val[plan.nnz_pos_rem]
             v_all = p.val if val is None else val
+            vl = plan.loc[2] if val is None else val[plan.nnz_pos_loc]
             flag = torch.zeros(1, dtype=torch.int32, device=B_ext.device)
             C, E = self.ops.spmm(2, plan.loc[0], plan.loc[1], vl, B_ext[:p.n_local], shared_gpu=True)
             self.ops.nonfinite_flag(B_ext[:p.n_local], flag)
@@ -444,10 +452,14 @@ class DistSpMM:
             if work is not None:
                 work.wait()
             if plan.rem_rows.numel() > 0:
-                self.ops.nonfinite_flag(B_ext[p.n_local:], flag)
-                Ch, Eh = self.ops.spmm(2, plan.rem2_rowptr, plan.rem[1], vr, B_ext[p.n_local:])
-                self.ops.spmm_min_merge(plan.rem_rows, plan.rem2_rowptr, Ch, Eh, p.n_local, plan.loc[0], C, E, flag,
-                                        p.rowptr, plan.col_ext, v_all, B_ext)
+                halo = B_ext[p.n_local:]
+                self.ops.nonfinite_flag(halo, flag)
+                for sub, rows, pos, first in ((plan.rem_lo, plan.rem_lo_rows, plan.nnz_pos_lo, True),
+                                              (plan.rem_hi, plan.rem_hi_rows, plan.nnz_pos_hi, False)):
+                    if rows.numel() > 0:
+                        self.ops.spmm_acc_min(sub[0], sub[1], sub[2] if val is None else val[pos], halo, C, E, rows,
+                                              p.n_local, first)
+                self.ops.min_redo(plan.rem_rows, C, E, flag, p.rowptr, plan.col_ext, v_all, B_ext)
             self.last_E_ext = E
             self._last_E = None
             return C

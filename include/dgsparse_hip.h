@@ -191,14 +191,22 @@ int dgs_spmm_csr_acc_f32(int64_t M, int64_t K, int64_t N, int64_t nnz, const int
  * columns / halo slots in global order, h_lo of them owned by lower ranks).  Ties go to the entry that comes first in
  * that original column order, value and arg together - exactly algorithm 0's rule on the undivided row provided the row's
  * columns are sorted (include/cuda/spmm_cuda.cuh:38-41).  E == -1 means "no arg yet" (empty so far).  New; lets the
- * multi-GPU max overlap its local product with the halo exchange.  MIN is not offered: its macro keeps the LATER
- * operand's bits on a tie (+0.0 / -0.0) while E names the first, and the position of the last minimum cannot be
- * recovered from (C, E).
+ * multi-GPU max overlap its local product with the halo exchange.  MIN cannot be merged by column key (its macro keeps
+ * the LATER operand's bits on a tie (+0.0 / -0.0) while E names the first): see dgs_spmm_csr_acc_min_f32 below.
  */
 int dgs_spmm_csr_acc_max_f32(int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr, const int32_t *col,
                              const float *val, const float *B, float *C, int32_t *E, const int32_t *rowmap,
                              int32_t col_off, int32_t n_local, int32_t h_lo, const void *plan,
                              const dgsSpmmPlanInfo *info, void *workspace, size_t workspace_bytes, dgsStream_t stream);
+/* The same for MIN, which keeps the LATER operand's bits on a tie while E names the FIRST minimum: a pair can be put in
+ * front of or behind what (C, E) hold, nothing else.  precedes != 0: the columns of this product all come BEFORE the ones
+ * (C, E) already cover in the row, 0: all AFTER; the commit is algorithm 0's MIN step on the two pairs in that order (an
+ * output row no earlier product had entries for must hold the empty-row 0 / -1).  Exact unless a product is NaN - see
+ * dgs_spmm_min_merge_f32 for the detector and the redo that go with it (new; multi-GPU path). */
+int dgs_spmm_csr_acc_min_f32(int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                             const float *val, const float *B, float *C, int32_t *E, const int32_t *rowmap,
+                             int32_t col_off, int32_t precedes, const void *plan, const dgsSpmmPlanInfo *info,
+                             void *workspace, size_t workspace_bytes, dgsStream_t stream);
 
 /*
  * Masked SpMM = backward of max/min w.r.t. the dense operand, run on the CSC arrays of A:
@@ -310,7 +318,8 @@ int dgs_relabel_i32(int64_t n, int32_t *ids, const int32_t *map, dgsStream_t str
  * product (a row without local entries holds the empty-row 0 / -1, which must not take part).  The three pairs are folded
  * in CSR order with algorithm 0's own MIN step, in place.  nonfinite (device int, may be NULL): when *nonfinite != 0 a
  * product may be NaN and MIN stops being mergeable, so the R rows are recomputed sequentially over the whole shard
- * (rowptr, col in extended ids, val or NULL, B = the [local | halo] buffer) instead.
+ * (rowptr, col in extended ids, val or NULL, B = the [local | halo] buffer) instead.  rowptr2 == NULL (then Ch, Eh,
+ * loc_rowptr are ignored and nonfinite is required): redo-only call - the merge was done by dgs_spmm_csr_acc_min_f32.
  * dgs_nonfinite_flag_f32 ORs 1 into *flag when x[0, n) holds a NaN or an infinity (the caller zeroes the flag). */
 int dgs_nonfinite_flag_f32(int64_t n, const float *x, int32_t *flag, dgsStream_t stream);
 int dgs_spmm_min_merge_f32(int64_t R, int64_t N, const int32_t *rowmap, const int32_t *rowptr2, const float *Ch,

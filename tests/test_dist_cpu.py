@@ -47,33 +47,30 @@ class OracleOps:
             flag |= 1
         return flag
 
-    def spmm_min_merge(self, rowmap, rowptr2, Ch, Eh, col_off, loc_rowptr, C, E, flag, rowptr, col, val, B):
-        """numpy restatement of dgs_spmm_min_merge_f32 (include/dgsparse_hip.h): lower halo | local | higher halo folded
-        with algorithm 0's MIN step, or the whole-row chain (the oracle) when the flag is up."""
+    def spmm_acc_min(self, rowptr, col, val, B, C, E, rowmap, col_off, precedes):
+        """numpy restatement of dgs_spmm_csr_acc_min_f32's commit (include/dgsparse_hip.h): algorithm 0's MIN step on the
+        old pair and this product's pair, this product first if ``precedes``; (arg < 0, value != identity) = empty so far."""
         import oracle
+        Cr, Er = oracle.spmm(2, rowptr.numpy(), col.numpy(), None if val is None else val.numpy(), B.numpy())
         rm = rowmap.long().numpy()
+        Co, Eo = C.numpy()[rm], E.numpy()[rm]
+        en = np.where(Er >= 0, Er + col_off, -1).astype(np.int32)
+        a, ea, b, eb = (Cr, en, Co, Eo) if precedes else (Co, Eo, Cr, en)
+        with np.errstate(invalid='ignore'):
+            mv = np.where(a < b, a, b)
+            me = np.where(a > b, eb, ea)
+        empty = (Eo < 0) & (Co != np.float32(2147483647))
+        C[rowmap.long()] = torch.from_numpy(np.where(empty, Cr, mv))
+        E[rowmap.long()] = torch.from_numpy(np.where(empty, en, me).astype(np.int32))
+        return C, E
+
+    def min_redo(self, rowmap, C, E, flag, rowptr, col, val, B):
+        import oracle
         if int(flag[0]):
+            rm = rowmap.long().numpy()
             Cf, Ef = oracle.spmm(2, rowptr.numpy(), col.numpy(), None if val is None else val.numpy(), B.numpy())
             C[rowmap.long()] = torch.from_numpy(Cf[rm])
             E[rowmap.long()] = torch.from_numpy(Ef[rm])
-            return C, E
-        rp2, lrp = rowptr2.numpy(), loc_rowptr.numpy()
-        R, N = rm.shape[0], C.shape[1]
-        acc = np.full((R, N), np.float32(2147483647), np.float32)
-        e = np.full((R, N), -1, np.int32)
-
-        def step(b, eb, live):
-            nonlocal acc, e
-            with np.errstate(invalid='ignore'):
-                gt, lt = acc > b, acc < b
-            e = np.where(live[:, None] & gt, eb, e).astype(np.int32)
-            acc = np.where(live[:, None] & ~lt, b, acc)
-        Chn, Ehn = Ch.numpy(), Eh.numpy()
-        step(Chn[0::2], Ehn[0::2] + col_off, rp2[0:-1:2] < rp2[1::2])
-        step(C.numpy()[rm], E.numpy()[rm], lrp[rm] < lrp[rm + 1])
-        step(Chn[1::2], Ehn[1::2] + col_off, rp2[1::2] < rp2[2::2])
-        C[rowmap.long()] = torch.from_numpy(acc)
-        E[rowmap.long()] = torch.from_numpy(e)
         return C, E
 
     def gather_rows(self, src, ids):

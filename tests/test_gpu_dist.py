@@ -163,18 +163,23 @@ def test_bench_partitioned_path_under_the_launcher():
     assert j['roofline']['frac'] > 0 and j['scaling'] == 'weak'
 
 
-@pytest.mark.parametrize('N,lo,hi,has_val', [(32, 900, 2100, True), (7, 900, 2100, True), (16, 0, 1500, True),
-                                             (16, 1500, 3000, False), (8, 1200, 1200, True), (64, 0, 3000, True)])
-def test_min_merge_and_nonfinite_flag_through_the_c_abi(N, lo, hi, has_val):
-    """dgs_spmm_min_merge_f32 / dgs_nonfinite_flag_f32 on their own: a matrix whose columns are cut in three ranges
-    [lower | local | higher] the way a shard of dgsparse.dist is, every row's min put together from the three products and
-    compared bit for bit with the one-pass kernel AND the oracle - with signed zeros (the tie corner), with the flag forced
-    up (the sequential redo), and with a NaN the detector has to find at any alignment."""
+@pytest.mark.parametrize('M,N,lo,hi,has_val', [(3000, 32, 900, 2100, True), (3000, 7, 900, 2100, True),
+                                               (3000, 16, 0, 1500, True), (3000, 16, 1500, 3000, False),
+                                               (3000, 8, 1200, 1200, True), (3000, 64, 0, 3000, True),
+                                               (70000, 32, 20000, 50000, True), (70000, 12, 30000, 45000, False)])
+def test_min_merge_and_nonfinite_flag_through_the_c_abi(M, N, lo, hi, has_val):
+    """dgs_spmm_csr_acc_min_f32 / dgs_spmm_min_merge_f32 / dgs_nonfinite_flag_f32 on their own: a matrix whose columns are
+    cut in three ranges [lower | local | higher] the way a shard of dgsparse.dist is, every row's min put together from
+    the three products - (a) lower folded in front of and higher behind the local result by the accumulating kernels, (b)
+    the two halo halves computed apart and folded by the merge kernel - and compared bit for bit with the one-pass kernel
+    AND the oracle: with signed zeros (the tie corner), with the flag forced up (the sequential redo), and with a NaN the
+    detector has to find at any alignment.  The 70 000-row cases are past the single-launch size, so the accumulating
+    commit runs in the row blocks, the unit blocks and the combine kernel."""
     from dgsparse import _capi
     from bench import graphgen
     dev = torch.device('cuda:0')
-    M, K = 3000, 3000
-    rp, col, st = graphgen.powerlaw_csr(M, 40 * M, K=K, alpha=2.0, dmax=900, cols='powerlaw', seed=9)
+    K = M
+    rp, col, st = graphgen.powerlaw_csr(M, 40 * M, K=K, alpha=2.0, dmax=max(900, M // 8), cols='powerlaw', seed=9)
     rng = np.random.default_rng(3)
     val = rng.choice(np.array([-1.0, 0.5, 1.0, 2.0], np.float32), size=col.shape[0])
     X = rng.choice(np.array([-0.0, 0.0, 0.0, 1.0, -1.0, 0.25], np.float32), size=(K, N))
@@ -222,6 +227,32 @@ def test_min_merge_and_nonfinite_flag_through_the_c_abi(N, lo, hi, has_val):
         _capi.spmm_min_merge(t(rem_rows), t(rp2), Ch, Eh, nl, t(lrp), C, E, flag, full_rp, full_col, full_val, Bd)
         assert_bitexact(C.cpu().numpy(), Cref, f'merged min values (flag {force})')
         assert_bitexact(E.cpu().numpy(), Eref, f'merged min E (flag {force})')
+    # (a) the schedule dgsparse.dist uses: two accumulating launches + the redo-only call
+    is_lo = ~is_loc & (ext - nl < lo)
+
+    def compact(mask):
+        cnt = np.bincount(rows[mask], minlength=M)
+        keep = np.nonzero(cnt)[0].astype(np.int32)
+        r = np.zeros(keep.shape[0] + 1, np.int32)
+        r[1:] = np.cumsum(cnt[keep])
+        return r, (ext[mask] - nl).astype(np.int32), (None if val is None else val[mask]), keep
+    for force in (0, 1):
+        flag = torch.full((1,), force, dtype=torch.int32, device=dev)
+        if nl > 0:
+            C, E = _capi.spmm(_capi.MIN, t(lrp), t(lcol), t(lval), Bd[:nl])
+        else:
+            C, E = torch.zeros((M, N), device=dev), torch.full((M, N), -1, dtype=torch.int32, device=dev)
+        for mask, first in ((is_lo, True), (~is_loc & ~is_lo, False)):
+            srp, scol, sval, keep = compact(mask)
+            if keep.shape[0]:
+                srp_d, scol_d = t(srp), t(scol)
+                # second round of the big cases: through the cached locality plan (None where the library offers none)
+                plan = _capi.spmm_plan(srp_d, scol_d, K - nl, N) if (M > 3000 and force) else None
+                _capi.spmm_acc_min(srp_d, scol_d, t(sval), Bd[nl:], C, E, t(keep), nl, first, plan=plan)
+        if R:
+            _capi.spmm_min_merge(t(rem_rows), None, None, None, 0, None, C, E, flag, full_rp, full_col, full_val, Bd)
+        assert_bitexact(C.cpu().numpy(), Cref, f'accumulated min values (flag {force})')
+        assert_bitexact(E.cpu().numpy(), Eref, f'accumulated min E (flag {force})')
     # the detector: clean data leaves the flag alone; one NaN / inf anywhere (any alignment, head, tail) raises it
     for off in (0, 1, 3):
         x = torch.rand(100003, device=dev)[off:].contiguous() if off == 0 else torch.rand(100003 + off, device=dev)[off:]
