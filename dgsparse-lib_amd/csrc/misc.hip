@@ -80,7 +80,7 @@ extern "C" int dgs_relabel_i32(int64_t n, int32_t *ids, const int32_t *map, dgsS
   return check_launch();
 }
 
-extern "C" int dgs_version(void) { return 1002; }  // 1.1: cached plans, accumulating SpMM, scheduling hints, relabel; 1.2: strict-order bits, dgs_spmm_csr_ex_f32 (epilogue), dgs_sddmm_csr_plan_f32, non-blocking plan helpers
+extern "C" int dgs_version(void) { return 1003; }  // 1.1: cached plans, accumulating SpMM, scheduling hints, relabel; 1.2: strict-order bits, dgs_spmm_csr_ex_f32 (epilogue), dgs_sddmm_csr_plan_f32, non-blocking plan helpers; 1.3: accumulating min, min merge / redo, non-finite detector
 extern "C" const char *dgs_arch(void) { return "gfx950"; }
 extern "C" const char *dgs_strerror(int code) {
   switch (code) {

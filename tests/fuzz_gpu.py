@@ -140,6 +140,35 @@ def one_case(rng, it):
                                   n_local=nl, h_lo=h_lo)
             assert_bitexact(Cm.cpu().numpy(), Cu, tag + ' acc max values')
             assert_bitexact(Em.cpu().numpy(), Eu, tag + ' acc max E')
+            # late round 3: the same cut for MIN - the lower columns folded in FRONT of the local result, the higher ones
+            # BEHIND it (dgs_spmm_csr_acc_min_f32), features with signed zeros and, one case in three, NaN / inf entries that
+            # the detector must find and the redo-only call must then repair (dgs_nonfinite_flag_f32, dgs_spmm_min_merge_f32)
+            Xz = Xe.copy()
+            Xz[Xz == 0] = rng.choice(np.array([0.0, -0.0], np.float32), size=int((Xz == 0).sum()))
+            poisoned = rng.integers(0, 3) == 0
+            if poisoned:
+                for bad in (np.nan, np.inf, -np.inf):
+                    Xz[rng.integers(0, K, 4), rng.integers(0, N, 4)] = bad
+            Cn, En = oracle.spmm('min', rp, ext, val, Xz, fma=True)
+            Xzd = dev(Xz)
+            if lcol.shape[0]:
+                Cq, Eq = capi.spmm(oracle.MIN, dev(lrp), dev(lcol), dev(lval), Xzd[:nl].contiguous())
+            else:
+                Cq = torch.zeros((M, N), device='cuda')
+                Eq = torch.full((M, N), -1, dtype=torch.int32, device='cuda')
+            halo = Xzd[nl:].contiguous()
+            for mask, first in ((col < a, True), (col >= b, False)):
+                srp, scol, sval, keep = sub(mask, nl, True)
+                if scol.shape[0]:
+                    capi.spmm_acc_min(dev(srp), dev(scol), dev(sval), halo, Cq, Eq, dev(keep), col_off=nl, precedes=first)
+            flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+            capi.nonfinite_flag(Xzd, flag)
+            capi.nonfinite_flag(dev(vv), flag)
+            assert bool(int(flag)) == (not np.isfinite(Xz).all()), tag + ' nonfinite detector'
+            if rrows.shape[0]:
+                capi.spmm_min_merge(dev(rrows), None, None, None, 0, None, Cq, Eq, flag, drp, dev(ext), dev(vv), Xzd)
+            assert_bitexact(Cq.cpu().numpy(), Cn, tag + f' acc min values (poisoned={poisoned})')
+            assert_bitexact(Eq.cpu().numpy(), En, tag + f' acc min E (poisoned={poisoned})')
     if col.shape[0]:
         D1 = (rng.integers(-3, 4, (M, N)) / 8).astype(np.float32)
         dD1 = dev(D1)
