@@ -47,11 +47,13 @@ __global__ __launch_bounds__(kBlock) void min_merge_kernel(int64_t R, int N, con
                                                            int *__restrict__ E, const int *__restrict__ nonfinite,
                                                            const int *__restrict__ rowptr, const int *__restrict__ col,
                                                            const float *__restrict__ val, const float *__restrict__ B) {
+  const bool redo = nonfinite && *nonfinite;  // uniform
+  if (!rowptr2 && !redo) return;              // redo-only call (the accumulating min kernels did the merge) and nothing to redo
   const int lanes = N / V;
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  // grid-stride: the launch is capped so that the redo-only call with the flag down costs a few microseconds
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < R * lanes; t += (int64_t)gridDim.x * kBlock) {
   const int64_t r = t / lanes;
   const int f = (int)(t % lanes) * V;
-  if (r >= R) return;
   const int64_t row = rowmap ? rowmap[r] : r;
   float acc[V];
   int e[V];
@@ -60,8 +62,6 @@ __global__ __launch_bounds__(kBlock) void min_merge_kernel(int64_t R, int N, con
     acc[v] = reduce_init<DGS_MIN>();
     e[v] = -1;
   }
-  const bool redo = nonfinite && *nonfinite;  // uniform
-  if (!rowptr2 && !redo) return;              // redo-only call (the accumulating min kernels did the merge) and nothing to redo
   if (redo) {  // the chain itself, over the whole shard row
     for (int p = rowptr[row], pe = rowptr[row + 1]; p < pe; p++) {
       const int c = col[p];
@@ -95,6 +95,7 @@ __global__ __launch_bounds__(kBlock) void min_merge_kernel(int64_t R, int N, con
   }
   store_vec<V>(C + row * N + f, acc);
   store_vec<V>(E + row * N + f, e);
+  }
 }
 
 }  // namespace dgs
@@ -128,7 +129,9 @@ extern "C" int dgs_spmm_min_merge_f32(int64_t R, int64_t N, const int32_t *rowma
   const bool v4 = (N % 4 == 0) && (!rowptr2 || (is_aligned16(Ch) && is_aligned16(Eh))) && is_aligned16(C) && is_aligned16(E) &&
                   (!nonfinite || is_aligned16(B));
   const int64_t lanes = v4 ? N / 4 : N;
-  const dim3 grid((unsigned)((R * lanes + kBlock - 1) / kBlock));
+  int64_t blocks = (R * lanes + kBlock - 1) / kBlock;
+  if (blocks > 4096) blocks = 4096;  // 16 workgroups per CU of a 256-CU part; grid-stride beyond that
+  const dim3 grid((unsigned)blocks);
 #define DGS_MERGE(V, HV)                                                                                                \
   hipLaunchKernelGGL((min_merge_kernel<V, HV>), grid, dim3(kBlock), 0, st, R, (int)N, rowmap, rowptr2, Ch, Eh, col_off, \
                      loc_rowptr, C, E, nonfinite, rowptr, col, val, B)
