@@ -424,20 +424,21 @@ __device__ __forceinline__ void coop_accumulate(int p0, int p1, int lane, int g,
       float w[kU];
       float x[kU][V];
       int m[kU][V];
+      // tile reads and gathers are issued unconditionally, the entry index clamped into the tile: as conditional blocks each
+      // ds_read got an lgkmcnt(0) of its own (8 serial LDS latencies per batch; ISA read, late round 3).  A clamped entry is
+      // the batch's last valid one, so the extra gather is a repeat of an address already in flight.
+      const int fo = fl ? f0 : 0;
 #pragma unroll
       for (int q = 0; q < kU; q++) {
-        if (j + q * NG < cnt) {
-          const int2 cv = tile[j + q * NG];
-          c[q] = cv.x;
-          w[q] = __int_as_float(cv.y);
-        }
+        const int2 cv = tile[min(j + q * NG, cnt - 1)];
+        c[q] = cv.x;
+        w[q] = __int_as_float(cv.y);
       }
 #pragma unroll
-      for (int q = 0; q < kU; q++)
-        if (j + q * NG < cnt && fl) {
-          load_vec_gather<V>(B + (int64_t)c[q] * N + f0, x[q]);
-          if constexpr (OP == kOpMaskSum) load_vec<V>(Em + (int64_t)c[q] * N + f0, m[q]);
-        }
+      for (int q = 0; q < kU; q++) {
+        load_vec_gather<V>(B + (int64_t)c[q] * N + fo, x[q]);
+        if constexpr (OP == kOpMaskSum) load_vec<V>(Em + (int64_t)c[q] * N + fo, m[q]);
+      }
 #pragma unroll
       for (int q = 0; q < kU; q++)
         if (j + q * NG < cnt && fl) {
@@ -1016,7 +1017,10 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
 #ifndef DGS_COMBINE_UP
 #define DGS_COMBINE_UP 8  // partial rows in flight per lane: 4 -> 8 takes the fold of a 400-unit hub row from 25 to 13 dependent rounds (combine 13.6 -> ~8 us on the headline graph, 8.7 -> 6.5 us arxiv-shaped); 16 adds little
 #endif
-  constexpr int UP = DGS_COMBINE_UP;
+#ifndef DGS_COMBINE_UP_ARG
+#define DGS_COMBINE_UP_ARG 4  // max / min carry (value, arg) per partial row: 8 in flight cost 134 VGPRs = 3 waves per SIMD
+#endif
+  constexpr int UP = ARG ? DGS_COMBINE_UP_ARG : DGS_COMBINE_UP;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane / G, l = lane % G;
   const int f0 = (blockIdx.y * G + l) * V;
