@@ -174,9 +174,12 @@ __global__ __launch_bounds__(kPanelBlock) void sddmm_panel(int M, int F, int ld,
             float pt[kSdPU];
             float x[kSdPU][V];
             int cj[kSdPU];
+            // all the column shuffles first, then the gathers: in one loop every gather waited for its own ds_bpermute
+            // (an lgkmcnt(0) per entry: 8 serial LDS-crossbar latencies per batch; ISA read, late round 3)
+#pragma unroll
+            for (int u = 0; u < kSdPU; u++) cj[u] = __shfl(c, gbase + ((j + u) & (G - 1)));
 #pragma unroll
             for (int u = 0; u < kSdPU; u++) {
-              cj[u] = __shfl(c, gbase + ((j + u) & (G - 1)));
               if (j + u < cnt && active) {
                 load_vec<V>(D2 + (int64_t)cj[u] * ld + f0, x[u]);
               } else {

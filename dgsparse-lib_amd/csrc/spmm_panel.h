@@ -119,12 +119,17 @@ __device__ __forceinline__ void panel_visit(int r, int c, float w, int pend, int
       float wj[PU];
       int cj[PU];
       int mk[PU][V];
+      // all the (column, value) shuffles first, then the gathers: in one loop every gather waited for its own ds_bpermute
+      // (an lgkmcnt(0) per entry: 8 serial LDS-crossbar latencies per batch; ISA read, late round 3)
 #pragma unroll
       for (int u = 0; u < PU; u++) {
         const int src = gbase + ((j + u) & (G - 1));
         cj[u] = __shfl(c, src);
         if constexpr (HAS_VAL) wj[u] = __shfl(w, src);
         else wj[u] = 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < PU; u++) {
         if (j + u < cnt && active) {
           load_vec<V>(B + (int64_t)cj[u] * ld + f0, x[u]);
           if constexpr (OP == kOpMaskSum) load_vec<V>(Em + (int64_t)cj[u] * ld + f0, mk[u]);
