@@ -775,6 +775,8 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
             }
           }
           // refill the slot just consumed (same registers: no copies, so the waits stay counted)
+          // (reading the tile entry one step ahead, so that its LDS latency runs under the wait for the oldest gather, was
+          // built and measured late in round 3: no change anywhere - arxiv-shaped 48.0 us, headline 0.390 ms - and dropped)
           cv[u] = tile[min(p + u + kU1, last)];
           load_vec_gather<V>(Bl + (int64_t)(cv[u].x & 0x7fffffff) * N, x[u]);
           if constexpr (OP == kOpMaskSum) load_vec<V>(El + (int64_t)(cv[u].x & 0x7fffffff) * N, mk[u]);
