@@ -46,8 +46,9 @@ def main():
     scan_halo = ms(lambda: ops.nonfinite_flag(eng.B_ext[nl:], flag))
     C, E = ops.spmm(2, plan.loc[0], plan.loc[1], plan.loc[2], eng.B_ext[:nl])
     halo = eng.B_ext[nl:]
-    acc_lo = ms(lambda: ops.spmm_acc_min(plan.rem_lo[0], plan.rem_lo[1], plan.rem_lo[2], halo, C, E, plan.rem_lo_rows, nl, True))
-    acc_hi = ms(lambda: ops.spmm_acc_min(plan.rem_hi[0], plan.rem_hi[1], plan.rem_hi[2], halo, C, E, plan.rem_hi_rows, nl, False))
+    (lo, lo_rows, _), (hi, hi_rows, _) = plan.min_parts()
+    acc_lo = ms(lambda: ops.spmm_acc_min(lo[0], lo[1], lo[2], halo, C, E, lo_rows, nl, True))
+    acc_hi = ms(lambda: ops.spmm_acc_min(hi[0], hi[1], hi[2], halo, C, E, hi_rows, nl, False))
     flag.zero_()
     redo = ms(lambda: ops.min_redo(plan.rem_rows, C, E, flag, p.rowptr, plan.col_ext, p.val, eng.B_ext))
     relabel = ms(lambda: ops.relabel(E, plan.ext2glob32))
@@ -55,8 +56,8 @@ def main():
     print(f'one pass after the exchange                      {one:8.4f} ms')
     print(f'under the exchange: local min {loc:.4f} + scans of local features / values {scan_loc:.4f}')
     print(f'after the exchange: scan of the halo {scan_halo:.4f} + lower halo folded in front {acc_lo:.4f} '
-          f'({int(plan.rem_lo[1].numel())} nnz, {int(plan.rem_lo_rows.numel())} rows) + higher halo behind {acc_hi:.4f} '
-          f'({int(plan.rem_hi[1].numel())} nnz, {int(plan.rem_hi_rows.numel())} rows) + redo-if-flagged {redo:.4f} = {after:8.4f} ms')
+          f'({int(lo[1].numel())} nnz, {int(lo_rows.numel())} rows) + higher halo behind {acc_hi:.4f} '
+          f'({int(hi[1].numel())} nnz, {int(hi_rows.numel())} rows) + redo-if-flagged {redo:.4f} = {after:8.4f} ms')
     print(f'exposed after the exchange: {one:.4f} -> {after:.4f} ms; total GPU work {one:.4f} -> {loc + scan_loc + after:.4f} ms')
     print(f'global column ids of E on demand (DistSpMM.last_E): {relabel:.4f} ms')
 

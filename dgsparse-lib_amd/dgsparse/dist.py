@@ -232,18 +232,7 @@ class HaloPlan:
             inc[starts[starts < col.numel()]] = True  # a REAL row start never breaks the order (trailing empty rows have
             # rowptr == nnz: clamping those to nnz-1 used to mask a descent inside the last non-empty row)
         self.rows_sorted = bool(inc.all())
-        # for the overlapped min: MIN can only be folded in row order (csrc/spmm_impl.h AccArg), so the halo entries are
-        # kept a second time as two compact matrices - the slots of lower ranks (they precede the local columns of a sorted
-        # row) and those of higher ranks (they follow them) - each with the shard rows it touches
-        self.rem_lo = self.rem_hi = None
-        if self.rows_sorted:
-            lower = is_remote & (ext - nl < self.h_lo)
-            self.rem_lo, keep = _sub(lower, nl, True)
-            self.rem_lo_rows = keep.to(torch.int32).contiguous()
-            self.rem_hi, keep = _sub(is_remote & ~lower, nl, True)
-            self.rem_hi_rows = keep.to(torch.int32).contiguous()
-            self.nnz_pos_lo = torch.nonzero(lower).view(-1)
-            self.nnz_pos_hi = torch.nonzero(is_remote & ~lower).view(-1)
+        self._min_parts = None  # see min_parts()
         if world == 1 or standalone:  # nothing to exchange; no process group needed
             self.send_splits = [0] * world
             self.send_ids = torch.zeros(0, dtype=torch.int32, device=dev)
@@ -256,6 +245,33 @@ class HaloPlan:
         _all_to_all_v(send_ids, rem.contiguous(), self.send_splits, self.recv_splits, group)
         self.send_ids = (send_ids - part.r0).to(torch.int32).contiguous()  # local row indices peers asked for
         assert self.send_ids.numel() == 0 or (int(self.send_ids.min()) >= 0 and int(self.send_ids.max()) < part.n_local)
+
+
+    def min_parts(self):
+        """For the overlapped min: MIN can only be folded in row order (csrc/spmm_impl.h AccArg), so the halo matrix is kept a
+        second time as two compact matrices - the slots of lower ranks (they precede the local columns of a sorted row) and
+        those of higher ranks (they follow them).  Built on the first min call, from the halo matrix alone.
+        Returns [(matrix (rowptr, slots, values | None), shard rows it touches, positions of its entries in the halo
+        matrix's arrays), ...] for (lower, higher)."""
+        if self._min_parts is None:
+            assert self.rows_sorted
+            rp, slot, v = self.rem
+            dev = slot.device
+            R = int(self.rem_rows.numel())
+            rpl = rp.long()
+            rrow = torch.repeat_interleave(torch.arange(R, device=dev), rpl[1:] - rpl[:-1])
+            lower = slot.long() < self.h_lo
+            parts = []
+            for mask in (lower, ~lower):
+                cnt = torch.bincount(rrow[mask], minlength=R)
+                keep = torch.nonzero(cnt).view(-1)
+                rp2 = torch.zeros(keep.numel() + 1, dtype=torch.int64, device=dev)
+                rp2[1:] = torch.cumsum(cnt[keep], 0)
+                pos = torch.nonzero(mask).view(-1)
+                parts.append(((rp2.to(torch.int32), slot[pos].contiguous(), None if v is None else v[pos].contiguous()),
+                              self.rem_rows[keep].contiguous(), pos))
+            self._min_parts = parts
+        return self._min_parts
 
 
 class _HipOps:
@@ -454,10 +470,10 @@ class DistSpMM:
             if plan.rem_rows.numel() > 0:
                 halo = B_ext[p.n_local:]
                 self.ops.nonfinite_flag(halo, flag)
-                for sub, rows, pos, first in ((plan.rem_lo, plan.rem_lo_rows, plan.nnz_pos_lo, True),
-                                              (plan.rem_hi, plan.rem_hi_rows, plan.nnz_pos_hi, False)):
+                vr = None if val is None else val[plan.nnz_pos_rem]
+                for (sub, rows, pos), first in zip(plan.min_parts(), (True, False)):
                     if rows.numel() > 0:
-                        self.ops.spmm_acc_min(sub[0], sub[1], sub[2] if val is None else val[pos], halo, C, E, rows,
+                        self.ops.spmm_acc_min(sub[0], sub[1], sub[2] if vr is None else vr[pos], halo, C, E, rows,
                                               p.n_local, first)
                 self.ops.min_redo(plan.rem_rows, C, E, flag, p.rowptr, plan.col_ext, v_all, B_ext)
             self.last_E_ext = E

@@ -98,7 +98,7 @@ def main():
                 pc.rowptr, pc.col = pc.rowptr.to(dev), pc.col.to(dev)
                 pc.val = None if pc.val is None else pc.val.to(dev)
                 ec = dd.DistSpMM(pc, N, overlap=True)
-                assert ec.plan.rows_sorted and ec.plan.rem_lo is not None
+                assert ec.plan.rows_sorted
                 Cc = ec.spmm(torch.from_numpy(Xc[r0:r1].copy()).to(dev), 'min')
                 Cg, Eg = oracle.spmm('min', rp, col, vc, Xc, fma=True)
                 assert_bitexact(Cc.cpu().numpy(), Cg[r0:r1], f'rank {rank}/{world} overlapped min, {name}: values')
