@@ -43,7 +43,9 @@ __device__ __forceinline__ int wave_incl_scan(int x, int lane) {
 
 // Dot products of one staged tile: tile[j] = {col, row} of nnz t0 + j (j < cntn); group g takes nnz g, g+NG, ...,
 // kSdU of them in flight; the results go through `cnt` (LDS) and leave with one coalesced store.
-template <int G, int V, bool MEAN, bool MASK>
+// ONE_ROW: every entry of the tile belongs to the same row (sddmm_longrows): its D1 slice (and arg ids) are loaded once per
+// feature tile instead of once per nnz - half the vector-memory instructions of the batch.
+template <int G, int V, bool MEAN, bool MASK, bool ONE_ROW = false>
 __device__ __forceinline__ void sd_tile_dots(const int2 *tile, int *cnt, int cntn, int t0, int lane, int F, int tiles,
                                              const int *__restrict__ rowptr, const float *__restrict__ D1,
                                              const float *__restrict__ D2, const int *__restrict__ E,
@@ -62,22 +64,27 @@ __device__ __forceinline__ void sd_tile_dots(const int2 *tile, int *cnt, int cnt
     for (int t = 0; t < tiles; t++) {
       const int f = (t * G + l) * V;
       if (f < F) {
-        float a[kSdU][V], b[kSdU][V];
-        int m[kSdU][V];
+        float a[ONE_ROW ? 1 : kSdU][V], b[kSdU][V];
+        int m[ONE_ROW ? 1 : kSdU][V];
+        if constexpr (ONE_ROW) {
+          load_vec_rowop<V>(D1 + (int64_t)cr[0].y * F + f, a[0]);
+          if constexpr (MASK) load_vec<V>(E + (int64_t)cr[0].y * F + f, m[0]);
+        }
 #pragma unroll
         for (int q = 0; q < kSdU; q++) {
-          load_vec_rowop<V>(D1 + (int64_t)cr[q].y * F + f, a[q]);
+          if constexpr (!ONE_ROW) load_vec_rowop<V>(D1 + (int64_t)cr[q].y * F + f, a[q]);
           load_vec<V>(D2 + (int64_t)cr[q].x * F + f, b[q]);
-          if constexpr (MASK) load_vec<V>(E + (int64_t)cr[q].y * F + f, m[q]);
+          if constexpr (MASK && !ONE_ROW) load_vec<V>(E + (int64_t)cr[q].y * F + f, m[q]);
         }
 #pragma unroll
         for (int q = 0; q < kSdU; q++)
 #pragma unroll
           for (int v = 0; v < V; v++) {
+            constexpr int qa = ONE_ROW ? 0 : 1;
             if constexpr (MASK) {
-              if (m[q][v] == cr[q].x) part[q] = __builtin_fmaf(a[q][v], b[q][v], part[q]);
+              if (m[q * qa][v] == cr[q].x) part[q] = __builtin_fmaf(a[q * qa][v], b[q][v], part[q]);
             } else {
-              part[q] = __builtin_fmaf(a[q][v], b[q][v], part[q]);
+              part[q] = __builtin_fmaf(a[q * qa][v], b[q][v], part[q]);
             }
           }
       }
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(kLongBlock) void sddmm_longrows(int M, int F, int t
       __builtin_amdgcn_wave_barrier();
       tile[lane] = make_int2(lane < cntn ? ld_stream(col + t0 + lane) : 0, r0 + rl);
       __builtin_amdgcn_wave_barrier();
-      sd_tile_dots<G, V, MEAN, MASK>(tile, cnt, cntn, t0, lane, F, tiles, rowptr, D1, D2, E, out);
+      sd_tile_dots<G, V, MEAN, MASK, true>(tile, cnt, cntn, t0, lane, F, tiles, rowptr, D1, D2, E, out);
     }
   }
 }
