@@ -1022,7 +1022,10 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
 #ifndef DGS_COMBINE_UP_ARG
 #define DGS_COMBINE_UP_ARG 4  // max / min carry (value, arg) per partial row: 8 in flight cost 134 VGPRs = 3 waves per SIMD
 #endif
-  constexpr int UP = ARG ? DGS_COMBINE_UP_ARG : DGS_COMBINE_UP;
+  // max: a partial row that never improved on the identity carries the identity as its value, so the fold needs values and
+  // positions only; the arg id of each element's winner is fetched once at the end (half the loads, 8 rows in flight again)
+  constexpr bool LATE_ARG = (OP == DGS_MAX);
+  constexpr int UP = (ARG && !LATE_ARG) ? DGS_COMBINE_UP_ARG : DGS_COMBINE_UP;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane / G, l = lane % G;
   const int f0 = (blockIdx.y * G + l) * V;
@@ -1052,7 +1055,7 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
       for (int q = 0; q < UP; q++) {
         const int64_t slot = (int64_t)(d.y + min(k + q * NG, d.z - 1)) * N + (fl ? f0 : 0);
         load_vec<V>(part + slot, x[q]);
-        if constexpr (ARG) load_vec<V>(parte + slot, xe[q]);
+        if constexpr (ARG && !LATE_ARG) load_vec<V>(parte + slot, xe[q]);
       }
       // branch-free folds (selects on fresh values): the merges of one round are 32 short data-dependent branches otherwise
 #pragma unroll
@@ -1074,10 +1077,10 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
             ep[v] = lt ? pos : ep[v];
             el[v] = le ? pos : el[v];
           } else if constexpr (ARG) {
-            // a partial that never improved on the identity carries E=-1 and must not win
-            const bool take = valid & (xe[q][v] != -1) & arg_better<OP>(acc[v], ep[v], x[q][v], pos);
+            // a partial that never improved on the identity (E = -1) holds the identity itself: it can take the position of
+            // another such partial, never that of a real one, and the arg id fetched for it at the end is its -1
+            const bool take = valid & arg_better<OP>(acc[v], ep[v], x[q][v], pos);
             acc[v] = take ? x[q][v] : acc[v];
-            ei[v] = take ? xe[q][v] : ei[v];
             ep[v] = take ? pos : ep[v];
           } else {
             if (valid) acc[v] += x[q][v];
@@ -1086,6 +1089,12 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
       }
     }
     cross_group_reduce<G, V, OP>(acc, ei, ep, el);
+    if constexpr (LATE_ARG) {
+      if (g == 0 && fl) {
+#pragma unroll
+        for (int v = 0; v < V; v++) ei[v] = (ep[v] != INT_MAX) ? parte[(int64_t)(d.y + ep[v]) * N + f0 + v] : -1;
+      }
+    }
     if constexpr (OP == DGS_MIN) {
 #pragma unroll
       for (int dd = G; dd < 64; dd <<= 1) nm |= (unsigned)__shfl_xor((int)nm, dd, 64);
