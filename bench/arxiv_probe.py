@@ -43,8 +43,10 @@ for k, (rp, col, st) in graphs.items():
 rp, col, st = graphs['arxiv-shaped']
 for mw in (1024, 2048, 4096, 8192, 16384, 32768):
     os.environ['DGS_MIN_WAVES'] = str(mw)
+    _capi.reload_tuning()
     run(f'arxiv-shaped DGS_MIN_WAVES={mw}', rp, col, st, True)
 os.environ.pop('DGS_MIN_WAVES')
+_capi.reload_tuning()
 # a copy with the same algorithmic bytes (97 MB: 48 read + 48 written), and an empty-ish launch
 a = torch.rand(12 * 1024 * 1024, device='cuda')
 b = torch.empty_like(a)

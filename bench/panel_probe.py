@@ -66,14 +66,18 @@ def main():
         def call():
             return _capi.spmm(op, rowptr, col, val, B)
     os.environ['DGS_PANEL'] = '0'
+    _capi.reload_tuning()
     ref, _ = call()
     t0 = timeit(lambda: call())
     print(f'row-stream schedule : {t0:8.3f} ms  {2e-6 * nnz * a.feat / t0:8.1f} GFLOP/s', flush=True)
     os.environ['DGS_PANEL'] = '1'
+    _capi.reload_tuning()
     for kb in a.kb:
         for lead in a.lead:
             os.environ['DGS_PANEL_KB'] = str(kb)
+            _capi.reload_tuning()
             os.environ['DGS_PANEL_LEAD'] = str(lead)
+            _capi.reload_tuning()
             out, _ = call()
             err = ((out - ref).abs() / (ref.abs() + 1e-3)).max().item()
             t = timeit(lambda: call())

@@ -269,4 +269,16 @@ inline bool is_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p)
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ELAUNCH; }
 
+// Tuning overrides (tests and experiments; every one has a compiled-in default at its point of use).  The environment is read
+// ONCE per process into an immutable snapshot (misc.hip: std::call_once), so a launch costs no getenv() and host threads can
+// launch concurrently; dgs_reload_tuning() publishes a fresh snapshot (tests that flip DGS_PANEL* between calls).
+constexpr int kTuneUnset = INT_MIN;
+struct Tuning {
+  int panel, panel_kb, panel_lead, panel_tlong, min_waves, nbu, strict_mid, strict_hub, strict_nbu, sddmm_fused;
+  int plan_tslice, plan_unit, plan_ch, plan_nocut, hub_chain;
+};
+const Tuning &tuning();
+inline int tune(int v, int dflt) { return v == kTuneUnset ? dflt : v; }
+int cu_count();  // compute units of the CURRENT device (cached per device)
+
 }  // namespace dgs

@@ -1,9 +1,64 @@
 // misc.hip -- row gather / scatter-add (halo pack / unpack for the multi-GPU path), version/info entry
 // points, and the GE-SpMM / SDDMM compatibility shims (reference src/ge-spmm/gespmm.h:32-41,
 // src/sddmm/sddmm.h:10) over the dgs_* entry points.
+#include <stdlib.h>
+
+#include <atomic>
+#include <mutex>
+
 #include "dgs_common.h"
 
 namespace dgs {
+
+// ---- process-wide tuning snapshot + per-device facts (the only global state of the library; see dgs_common.h) -------------
+static Tuning g_tuning[2];
+static std::atomic<const Tuning *> g_tuning_cur{nullptr};
+static std::mutex g_tuning_mu;
+static std::once_flag g_tuning_once;
+static void tuning_read(Tuning &t) {
+  auto rd = [](const char *k) {
+    const char *v = getenv(k);
+    return (v && *v) ? atoi(v) : kTuneUnset;
+  };
+  t.panel = rd("DGS_PANEL");
+  t.panel_kb = rd("DGS_PANEL_KB");
+  t.panel_lead = rd("DGS_PANEL_LEAD");
+  t.panel_tlong = rd("DGS_PANEL_TLONG");
+  t.min_waves = rd("DGS_MIN_WAVES");
+  t.nbu = rd("DGS_NBU");
+  t.strict_mid = rd("DGS_STRICT_MID");
+  t.strict_hub = rd("DGS_STRICT_HUB");
+  t.strict_nbu = rd("DGS_STRICT_NBU");
+  t.sddmm_fused = rd("DGS_SDDMM_FUSED");
+  t.plan_tslice = rd("DGS_PLAN_TSLICE");
+  t.plan_unit = rd("DGS_PLAN_UNIT");
+  t.plan_ch = rd("DGS_PLAN_CH");
+  t.plan_nocut = rd("DGS_PLAN_NOCUT");
+  t.hub_chain = rd("DGS_HUB_CHAIN");
+}
+static void tuning_publish() {
+  std::lock_guard<std::mutex> lk(g_tuning_mu);
+  const Tuning *cur = g_tuning_cur.load(std::memory_order_relaxed);
+  Tuning &next = g_tuning[cur == &g_tuning[0] ? 1 : 0];
+  tuning_read(next);
+  g_tuning_cur.store(&next, std::memory_order_release);
+}
+const Tuning &tuning() {
+  std::call_once(g_tuning_once, tuning_publish);
+  return *g_tuning_cur.load(std::memory_order_acquire);
+}
+int cu_count() {
+  static std::atomic<int> n[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = n[dev].load(std::memory_order_relaxed);
+  if (!v) {
+    hipDeviceProp_t prop;
+    v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    n[dev].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 
 // One row per G-lane group, V floats per lane: dst[i,:] = src[ids[i],:]
 template <int V>
@@ -186,3 +241,8 @@ DGS_GESPMM_ALIAS(csrspmm_seqreduce_rowbalance)
 DGS_GESPMM_ALIAS(csrspmm_seqreduce_nnzbalance)
 DGS_GESPMM_ALIAS(csrspmm_rowcaching_rowbalance)
 DGS_GESPMM_ALIAS(csrspmm_rowcaching_nnzbalance)
+
+extern "C" void dgs_reload_tuning(void) {
+  dgs::tuning();  // make sure the first snapshot exists, then publish a fresh one beside it (readers keep a valid pointer)
+  dgs::tuning_publish();
+}

@@ -15,6 +15,8 @@
 //   * the 64 results go through LDS and leave with one coalesced store.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "dgs_common.h"
 #include "sddmm_panel.h"
 #include "sddmm_fused.h"
@@ -323,20 +325,6 @@ static int dispatch_sddmm(int G, int64_t M, int64_t F, int tiles, int64_t nnz, c
 }
 
 // ---- column-panel schedule for dense graphs (sddmm_panel.h) ----
-static inline int sd_env_int(const char *k, int dflt) {
-  const char *v = getenv(k);
-  return v ? atoi(v) : dflt;
-}
-static inline int sd_cu_count() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
 
 struct SdPanelPlan {
   bool use;
@@ -346,9 +334,10 @@ struct SdPanelPlan {
 
 static SdPanelPlan sd_panel_plan(int64_t M, int64_t K, int64_t F, int64_t nnz, int tiles, int G, int V, bool mask) {
   SdPanelPlan P{};
-  const int force = sd_env_int("DGS_PANEL", -1);
+  const Tuning &T = tuning();
+  const int force = tune(T.panel, -1);
   if (force == 0 || (tiles != 1 && G != 64) || V != 4 || G < 8 || M <= 0 || K <= 0) return P;
-  P.nwg = sd_cu_count();
+  P.nwg = cu_count();
   const int64_t W = F < 256 ? F : 256;  // feature tile per launch
   int slots = (int)(kSdPanelBytes / (W * (mask ? 8 : 4)));
   if (slots > kPanelRMax) slots = kPanelRMax;
@@ -357,7 +346,9 @@ static SdPanelPlan sd_panel_plan(int64_t M, int64_t K, int64_t F, int64_t nnz, i
   // several times per XCD and a row visit must still hold a handful of nnz
   const double deg = (double)nnz / (double)M;
   const double reuse = (P.nwg / 8.0) * slots * deg / (double)K;
-  int64_t pc = (int64_t)sd_env_int("DGS_PANEL_KB", 6144) * 1024 / (W * 4);
+  int pkb = tune(T.panel_kb, 6144);
+  if (pkb < 1) pkb = 1;
+  int64_t pc = (int64_t)pkb * 1024 / (W * 4);
   if (pc < 64) pc = 64;
   const double visit = deg * (double)pc / (double)K;
   const bool pays = reuse >= 5.5 || (reuse >= 4.0 && visit >= 10.0);
@@ -366,8 +357,8 @@ static SdPanelPlan sd_panel_plan(int64_t M, int64_t K, int64_t F, int64_t nnz, i
   P.R = (int)((M + (int64_t)P.nwg * P.nsb - 1) / ((int64_t)P.nwg * P.nsb));
   P.pcols = (int)pc;
   P.npanels = (int)((K + pc - 1) / pc);
-  P.lead = sd_env_int("DGS_PANEL_LEAD", 1);
-  P.tlong = sd_env_int("DGS_PANEL_TLONG", 2048);
+  P.lead = tune(T.panel_lead, 1);
+  P.tlong = tune(T.panel_tlong, 2048);
   if (P.tlong < 1) P.tlong = 1;
   P.lds = (size_t)P.R * W * (mask ? 8 : 4);
   P.use = true;
@@ -378,7 +369,7 @@ template <int G, bool MEAN, bool MASK>
 static int launch_sddmm_panel(const SdPanelPlan &P, int64_t M, int64_t F, const int *rowptr, const int *col,
                               const float *D1, const float *D2, const int *E, float *out, hipStream_t st) {
   auto kern = sddmm_panel<G, MEAN, MASK>;
-  static bool attr_set[64] = {};  // per instantiation and device: allow the large dynamic LDS
+  static std::atomic<bool> attr_set[64];  // per instantiation and device: allow the large dynamic LDS
   int dev_id = 0;
   if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) return DGS_ELAUNCH;
   if (!attr_set[dev_id]) {
@@ -467,7 +458,7 @@ extern "C" int dgs_sddmm_csr_plan_f32(int reduce_op, int64_t M, int64_t K, int64
     // worth it on hub-heavy graphs, where the units of the column-cut rows (n_pslots of them, ~64..256 nnz each) hold about a
     // third of the nnz or more: 1M-row power-law graph (alpha 2.1) 493 -> 465 us; products-shaped (alpha 2.4, 0.0031 cut
     // units per nnz) 2232 -> 2280 us, so that one stays on the nnz-balanced kernel.  DGS_SDDMM_FUSED=0/1 overrides.
-    const int force = sd_env_int("DGS_SDDMM_FUSED", -1);
+    const int force = tune(tuning().sddmm_fused, -1);
     fused = fm.tiles == 1 && fm.V == 4 && fm.G >= 8 && !sd_panel_plan(M, K, F, nnz, fm.tiles, fm.G, fm.V, false).use &&
             force != 0 && (force == 1 || (int64_t)info->n_pslots * 256 >= nnz);
     if (fused) {

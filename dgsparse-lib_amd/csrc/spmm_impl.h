@@ -47,6 +47,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "dgs_common.h"
 #include "spmm_panel.h"
 
@@ -1153,26 +1155,11 @@ struct PlanHdr {
 };
 static_assert(sizeof(PlanHdr) <= 256, "plan header must fit its 256-byte slot");
 
-static inline int cu_count() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
-
-static inline int env_int(const char *k, int dflt) {
-  const char *v = getenv(k);
-  return v ? atoi(v) : dflt;
-}
-
 // Column-panel schedule (spmm_panel.h): dense graphs whose dense operand does not fit the L2s.
 static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
   PanelPlan P{};
-  const int force = env_int("DGS_PANEL", -1);
+  const Tuning &T = tuning();
+  const int force = tune(T.panel, -1);
   // the sweep needs one workgroup per CU, all co-resident: not on a GPU the caller shares with other kernels
   if (force == 0 || !a.ws || (tiles != 1 && G != 64) || G < 8 || a.N % 4 || a.M <= 0 || (a.hints & DGS_ALG_SHARED_GPU)) return P;
   P.nwg = cu_count();
@@ -1192,7 +1179,9 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
   const double bbytes = (double)a.K * W * 4.0;
   const double deg = (double)a.nnz / (double)a.M;
   const double reuse = (P.nwg / 8.0) * slots * deg / (double)(a.K > 0 ? a.K : 1);
-  const int64_t pbytes = (int64_t)env_int("DGS_PANEL_KB", 6144) * 1024;
+  int pkb = tune(T.panel_kb, 6144);
+  if (pkb < 1) pkb = 1;
+  const int64_t pbytes = (int64_t)pkb * 1024;
   int64_t pc = pbytes / (W * (a.reduce_op == kOpMaskSum ? 8 : 4));  // masked sum gathers grad AND arg-id rows
   if (pc < 64) pc = 64;
   const double visit = deg * (double)pc / (double)(a.K > 0 ? a.K : 1);
@@ -1203,8 +1192,8 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
   P.pcols = (int)pc;
   P.npanels = (int)((a.K + pc - 1) / pc);
   if (P.npanels < 1) P.npanels = 1;
-  P.lead = env_int("DGS_PANEL_LEAD", 1);
-  P.tlong = env_int("DGS_PANEL_TLONG", 4096);
+  P.lead = tune(T.panel_lead, 1);
+  P.tlong = tune(T.panel_tlong, 4096);
   P.lds = (((size_t)P.R * W * ebytes + 15) & ~size_t(15)) + (size_t)P.R * kPanelRowState;
   P.use = true;
   return P;
@@ -1231,7 +1220,7 @@ static int launch_impl(const SpmmArgs &a) {
       hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, tl, a.rowptr, hdr,
                          units, longrows);
       auto kern = spmm_panel<G, OP, HAS_VAL>;
-      static bool attr_set[64] = {};  // per instantiation and device: allow the large dynamic LDS
+      static std::atomic<bool> attr_set[64];  // per instantiation and device: allow the large dynamic LDS (setting it twice is harmless)
       int dev_id = 0;
       if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) return DGS_ELAUNCH;
       if (!attr_set[dev_id]) {
@@ -1272,7 +1261,7 @@ static int launch_impl(const SpmmArgs &a) {
   // rows per wave: 64 when there are plenty of rows; mid-size graphs (arxiv-shaped: 169 k rows, 6.5 nnz/row) get fewer,
   // so that the chip still sees >= ~8k waves and a group's sequential stream stays a few gather rounds long
   int rpw = kRowsPerWave;
-  const int min_waves = env_int("DGS_MIN_WAVES", 8192);
+  const int min_waves = tune(tuning().min_waves, 8192);
   while (rpw > 8 && a.M / rpw < min_waves) rpw >>= 1;
   const int rows_per_block = (kBlock / kWave) * rpw;
   const int64_t nbr = (a.M + rows_per_block - 1) / rows_per_block;
@@ -1290,7 +1279,9 @@ static int launch_impl(const SpmmArgs &a) {
                      reinterpret_cast<const int4 *>(pb + (a.plan_off_long ? (size_t)a.plan_off_long : PL.off_long))};
     int64_t ub = ((int64_t)a.plan_units + 3) / 4;
     ub = (ub + 7) & ~int64_t(7);  // a multiple of 8 so that the XCD mapping of the unit blocks applies
-    const int nbu_cap = (env_int("DGS_NBU", DGS_NBU) + 7) & ~7;
+    int nbu_req = tune(tuning().nbu, DGS_NBU);
+    if (nbu_req < 8) nbu_req = 8;  // an override of 0 would leave the units without a single block
+    const int nbu_cap = (nbu_req + 7) & ~7;
     const int nbu = (int)(ub < nbu_cap ? (ub < 8 ? 8 : ub) : nbu_cap);
     hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
                        a.st, (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.acc);
@@ -1316,7 +1307,8 @@ static int launch_impl(const SpmmArgs &a) {
                      longrows);
   // unit / multi counts live on the device: a bounded number of persistent unit blocks stride over the table
   const int64_t ub = (L.max_units + 3) / 4;
-  const int nbu_cap = env_int("DGS_NBU", DGS_NBU);
+  int nbu_cap = tune(tuning().nbu, DGS_NBU);
+  if (nbu_cap < 1) nbu_cap = 1;
   const int nbu = (int)(ub < nbu_cap ? (ub < 1 ? 1 : ub) : nbu_cap);
   hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
                      a.st, (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.acc);
@@ -1350,7 +1342,7 @@ static int launch_strict(const SpmmArgs &a) {
   SpmmWs *hdr = reinterpret_cast<SpmmWs *>(w);
   int4 *units = reinterpret_cast<int4 *>(w + L.off_units);
   // (DGS_STRICT_MID / _HUB: experiment overrides of the slicing thresholds; the table capacities assume hub >= kStrictHub)
-  int tmid = env_int("DGS_STRICT_MID", kStrictMid), thub = env_int("DGS_STRICT_HUB", kStrictHub);
+  int tmid = tune(tuning().strict_mid, kStrictMid), thub = tune(tuning().strict_hub, kStrictHub);
   if (thub < (strict_coop(G, V) ? kStrictMid : kStrictHub)) thub = strict_coop(G, V) ? kStrictMid : kStrictHub;
   if (tmid < kStrictMid) tmid = kStrictMid;
   if (tmid > thub) tmid = thub;
@@ -1359,7 +1351,9 @@ static int launch_strict(const SpmmArgs &a) {
   // unit blocks: first in the grid (the long chains must start first), twice as many as fit the chip at once (4 workgroups
   // per CU): the later ones take over as the early ones run out of units, and the row blocks follow as those drain.
   // Measured on the headline graph: 512 blocks 0.84 ms, 1024 0.67, 2048 0.58, 4096 0.58, 16384 0.61
-  const int nbu = (env_int("DGS_STRICT_NBU", 8 * cu_count()) + 7) & ~7;  // a multiple of 8: one share per XCD
+  int nbu_req = tune(tuning().strict_nbu, 8 * cu_count());
+  if (nbu_req < 8) nbu_req = 8;
+  const int nbu = (nbu_req + 7) & ~7;  // a multiple of 8: one share per XCD
   if constexpr (V == 4 && G >= 8 && STRICT == 1) {
     const PanelPlan P = panel_plan(a, a.tiles, G);
     if (P.use) {
@@ -1369,7 +1363,7 @@ static int launch_strict(const SpmmArgs &a) {
       hipLaunchKernelGGL(spmm_classify_strict, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, tl, tl, tl,
                          strict_smid(G), strict_shub(G, V), ht, a.rowptr, hdr, units);
       auto kern = spmm_panel<G, OP, HAS_VAL>;
-      static bool attr_set[64] = {};
+      static std::atomic<bool> attr_set[64];
       int dev_id = 0;
       if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) return DGS_ELAUNCH;
       if (!attr_set[dev_id]) {
@@ -1391,7 +1385,7 @@ static int launch_strict(const SpmmArgs &a) {
     }
   }
   int rpw = kRowsPerWave;
-  const int min_waves = env_int("DGS_MIN_WAVES", 8192);
+  const int min_waves = tune(tuning().min_waves, 8192);
   while (rpw > 8 && a.M / rpw < min_waves) rpw >>= 1;
   const int rows_per_block = (kBlock / kWave) * rpw;
   const int64_t nbr = (a.M + rows_per_block - 1) / rows_per_block;

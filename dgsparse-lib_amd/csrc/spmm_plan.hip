@@ -182,7 +182,7 @@ __device__ __forceinline__ int cut_row(const int *__restrict__ col, const int *_
 
 // One wave per long row: is it cut on the column grid (long enough AND sorted)?  how many units?
 // info[i] = {units, units that need a partial slot (0 for a single-unit row), 1 if multi-unit, 1 + level if cut | 0}
-__global__ __launch_bounds__(kBlock) void plan_rowunits(int ch, int tslice, int unit, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(kBlock) void plan_rowunits(int ch, int tslice, int nocut, int unit, const int *__restrict__ rowptr,
                                                         const int *__restrict__ col, const PlanWs *__restrict__ pw,
                                                         const int *__restrict__ bounds, const int *__restrict__ list,
                                                         int4 *__restrict__ info) {
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void plan_rowunits(int ch, int tslice, int 
   for (int i = blockIdx.x * (kBlock / kWave) + wave; i < n; i += gridDim.x * (kBlock / kWave)) {
     const int r = list[i];
     const int rs = rowptr[r], re = rowptr[r + 1];
-    bool sliced = (re - rs) > tslice;
+    bool sliced = (re - rs) > tslice && (re - rs) <= nocut;
     if (sliced) {
       bool ok = true;
       for (int p = rs + lane; p + 1 < re; p += kWave) ok &= col[p] <= col[p + 1];
@@ -283,12 +283,12 @@ __global__ void plan_xcd(const unsigned long long *__restrict__ keys, PlanHdr *_
 using namespace dgs;
 
 static int plan_tslice() {
-  int t = env_int("DGS_PLAN_TSLICE", 256);
+  int t = tune(tuning().plan_tslice, 256);
   if (t < kPlanSliceMin) t = kPlanSliceMin;
   return t;
 }
 static int plan_unit() {  // nnz per cell a cut row should keep (decides how fine long rows are cut on the column grid)
-  int u = env_int("DGS_PLAN_UNIT", 64);
+  int u = tune(tuning().plan_unit, 64);
   if (u < kPlanUnitMin) u = kPlanUnitMin;
   return u;
 }
@@ -342,7 +342,7 @@ extern "C" int dgs_spmm_plan_build2(int64_t M, int64_t K, int64_t nnz, const int
   void *tmp = ws + WL.off_tmp;
   // unit length: 256 nnz when there is plenty of work; smaller inputs get shorter units (a unit is a chain of up to
   // ch/64 dependent tiles, and a mid-size graph has too few units to hide it)
-  int ch = env_int("DGS_PLAN_CH", nnz >= (8 << 20) ? kPlanCh : (nnz >= (2 << 20) ? 128 : 64));
+  int ch = tune(tuning().plan_ch, nnz >= (8 << 20) ? kPlanCh : (nnz >= (2 << 20) ? 128 : 64));
   ch = ch < kPlanChMin ? kPlanChMin : (ch > (1 << 20) ? (1 << 20) : ch);  // the table capacities assume ch >= kPlanChMin
   const int tslice = plan_tslice(), unit = plan_unit();
 
@@ -364,7 +364,10 @@ extern "C" int dgs_spmm_plan_build2(int64_t M, int64_t K, int64_t nnz, const int
                      unit);
   hipLaunchKernelGGL(plan_longlist, dim3((unsigned)((M + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int)M, kT1, rowptr,
                      pw, list);
-  hipLaunchKernelGGL(plan_rowunits, dim3(1024), dim3(kBlock), 0, st, ch, tslice, unit, rowptr, col, pw, bounds, list, rinfo);
+  // DGS_PLAN_NOCUT (experiment): rows longer than this are chunked without column cuts (what a hub row costs when it leaves
+  // the column-slice order)
+  hipLaunchKernelGGL(plan_rowunits, dim3(1024), dim3(kBlock), 0, st, ch, tslice, tune(tuning().plan_nocut, INT_MAX), unit, rowptr,
+                     col, pw, bounds, list, rinfo);
   tb = WL.tmp_bytes;
   if (rocprim::exclusive_scan(tmp, tb, rinfo, rscan, make_int4(0, 0, 0, 0), (size_t)WL.cap_long, I4Plus(), st, false) !=
       hipSuccess)
@@ -425,7 +428,7 @@ extern "C" void dgs_spmm_plan_thresholds(int32_t *t1, int32_t *tslice) {
 extern "C" int dgs_spmm_plan_provisional_info(int64_t nnz, int64_t rows_gt_t1, int64_t nnz_gt_t1, int64_t rows_gt_tslice,
                                               int64_t nnz_gt_tslice, dgsSpmmPlanInfo *info) {
   if (!info || nnz <= 0 || rows_gt_t1 < rows_gt_tslice || nnz_gt_t1 < nnz_gt_tslice || rows_gt_tslice < 0) return DGS_EINVAL;
-  int ch = env_int("DGS_PLAN_CH", nnz >= (8 << 20) ? kPlanCh : (nnz >= (2 << 20) ? 128 : 64));
+  int ch = tune(tuning().plan_ch, nnz >= (8 << 20) ? kPlanCh : (nnz >= (2 << 20) ? 128 : 64));
   ch = ch < kPlanChMin ? kPlanChMin : (ch > (1 << 20) ? (1 << 20) : ch);
   const int unit = plan_unit();
   const int64_t mid_rows = rows_gt_t1 - rows_gt_tslice, mid_nnz = nnz_gt_t1 - nnz_gt_tslice;

@@ -72,10 +72,10 @@ __host__ __device__ __forceinline__ int hub_class(int len, int thub) {
 }
 
 constexpr int strict_smid(int G) { return G < 4 ? G : 4; }
-// hub rows: feature tiles of >= 64 floats with 16-byte lanes are cut into 4 slices, each worked by a whole workgroup
+// hub rows: feature tiles of >= 32 floats with 16-byte lanes are cut into 4 slices (2 for a 32-float tile), each worked by a whole workgroup
 // (strict_hub_coop: four waves gather, one chains); narrower tiles into up to 16 wave-level slices
-constexpr bool strict_coop(int G, int V) { return V == 4 && G >= 16; }
-constexpr int strict_shub(int G, int V) { return strict_coop(G, V) ? 4 : (G < 16 ? G : 16); }
+constexpr bool strict_coop(int G, int V) { return V == 4 && G >= 8; }
+constexpr int strict_shub(int G, int V) { return strict_coop(G, V) ? (G >= 16 ? 4 : 2) : (G < 16 ? G : 16); }
 
 // One wave, one feature slice [fbase, fbase + GP*V) of one row [p0, p0+len): returns the chain results in the CHAIN
 // layout: lane c < CL holds features fbase + c*VP .. + VP-1 (VP = 1 unless the slice is wider than 64 floats).
@@ -216,112 +216,143 @@ __device__ __forceinline__ void strict_unit(const int row, const int p0, const i
   }
 }
 
-// Hub rows, block-cooperative: ONE workgroup per (row, quarter of the feature tile).  A chain of L steps is a chain of L LDS
+// Hub rows, block-cooperative: ONE workgroup per (row, slice of the feature tile).  A chain of L steps is a chain of L LDS
 // reads as well, and an LDS instruction costs its cycles whatever the number of active lanes: sixteen 4-feature slices per
 // row, each chained by its own wave (the first version), made the LDS pipeline the bound (8 chaining waves per CU = 32
-// cycles per step) and the call 3.5x slower than the default schedule.  Here the four waves of the workgroup gather (8 KB in
-// flight each: 128 KB per row over its four workgroups, as before), the gathered rows are laid out FEATURE-major in LDS, and
-// wave 0 alone chains W = 16 .. 64 features with one ds_read_b128 of x and one of w per FOUR steps.
+// cycles per step) and the call 3.5x slower than the default schedule.  Here the four waves of the workgroup gather, the
+// gathered rows are laid out FEATURE-major in LDS, and wave 0 alone chains W = 16 .. 64 features with one ds_read_b128 of x
+// and one of w per FOUR steps.
+//
+// Round 4 (experiments/lds_dma_gather.cpp part 2, profiles/r04_lds_dma_gather.txt): with the fabric saturated by the rest of
+// the launch a gather takes ~2.5 - 3 us to come back whatever is done about it (an L2 prefetcher on the same XCD changes
+// nothing: hits queue behind everybody's misses), so a row is fed at (bytes in flight for it) / 3 us and nothing else
+// matters - Little's law.  Two changes follow.  (a) TWO register sets of kUS gathers per lane, used by alternating phases of
+// NRB nnz: a set has two phases to land instead of one, i.e. twice the bytes in flight per row (256 KB over the four slices
+// at N = 64).  (b) The chain itself: the ISA of the first version waited for the NEXT batch's LDS reads before the first fma
+// of the current one (the prefetch sat in a conditional block, so the merged wait count was the worst case of both paths):
+// ~11 clocks per link.  The window below is straight-line - every read is issued, its index clamped into the tile - and
+// rolls four b128 pairs (16 links) ahead of the fmas.
 template <int GP, bool MEAN, bool HAS_VAL, bool FMA>
 __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, const int len, const int tbase, const int sl,
                                                 const int N, const int *__restrict__ col, const float *__restrict__ val,
                                                 const float *__restrict__ B, float *__restrict__ C, float *lds) {
-  constexpr int V = 4, NW = kBlock / kWave;
+  constexpr int V = 4, NWG = kBlock / kWave - 1;  // gather waves (wave 0 chains and does nothing else)
   constexpr int NGP = kWave / GP, W = GP * V;   // nnz per load instruction; floats (= chain lanes) of the slice
-  constexpr int NWV = kUS * NGP;                // nnz per wave and round
-  constexpr int NRB = NW * NWV;                 // nnz per workgroup round
+  constexpr int NWV = kUS * NGP;                // nnz per gather wave and phase
+  constexpr int NRB = NWG * NWV;                // nnz per workgroup phase
   constexpr int LD = NRB + 4;                   // row pitch of the feature-major tile: conflict-free ds_read_b128 across lanes
-  static_assert(W * LD + NRB <= kStrictBlockFloats && W <= kWave, "strict_hub_coop LDS");
+  static_assert(W * LD + NRB <= kStrictBlockFloats && W <= kWave && NRB % 16 == 0, "strict_hub_coop LDS");
   float *xt = lds, *wt = lds + W * LD;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int gp = lane / GP, lp = lane % GP;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int fbase = tbase + sl * W;
+  const int nph = (len + NRB - 1) / NRB;
+  // Roles: the two kinds of waves share nothing but the tile and two barriers per phase (A: tile written, B: tile chained), so
+  // the kernel's register budget is the larger of the two roles, not their sum (the first round-4 version, every wave with two
+  // gather sets AND the chain window, spilled the chain's addresses to scratch and drained vmcnt inside the chain loop).
+  if (wave == 0) {
+    float acc = 0.0f;
+    const float *xr = xt + (lane < W ? lane : 0) * LD;
+    const float4 *xr4 = reinterpret_cast<const float4 *>(__builtin_assume_aligned(xr, 16));
+    const float4 *wt4 = reinterpret_cast<const float4 *>(__builtin_assume_aligned(wt, 16));
+    // the chain is the critical path of the whole call and a dependent sequence: give it the SIMD's issue slots ahead of the
+    // waves that share them (DGS_STRICT_PRIO=0 builds measure the difference)
+    if (DGS_STRICT_PRIO) __builtin_amdgcn_s_setprio(3);
+    for (int ph = 0; ph < nph; ph++) {
+      const int cnt = min(NRB, len - ph * NRB);
+      __syncthreads();  // A
+      // Rolling window of P b128 pairs (x of this lane's feature, w broadcast) = 4 P links ahead of the fmas.  Every read is
+      // issued (the window over-reads up to 4 P floats past the phase: still inside the block's LDS, never chained) and the
+      // sched_barriers pin reads and fmas where they are written - left alone, hipcc gathers the reads at the loop top and
+      // waits for all of them before the first fma
+      constexpr int P = 4;
+      static_assert(W * LD + NRB + 4 * P <= kStrictBlockFloats, "chain window over-read");
+      const int nq = cnt >> 2;  // whole quads of this phase
+      float4 xq[P], wq[P];
+#pragma unroll
+      for (int p = 0; p < P; p++) {  // same issue order as the loop body: its first wait is then lgkmcnt(2 P - 2) on both edges
+        xq[p] = xr4[p];
+        wq[p] = HAS_VAL ? wt4[p] : make_float4(1.f, 1.f, 1.f, 1.f);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      int i = 0;
+      for (; i + P <= nq; i += P) {
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+          acc = chain_step<FMA>(wq[p].x, xq[p].x, acc);
+          acc = chain_step<FMA>(wq[p].y, xq[p].y, acc);
+          acc = chain_step<FMA>(wq[p].z, xq[p].z, acc);
+          acc = chain_step<FMA>(wq[p].w, xq[p].w, acc);
+          __builtin_amdgcn_sched_barrier(0);
+          xq[p] = xr4[i + P + p];
+          if constexpr (HAS_VAL) wq[p] = wt4[i + P + p];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      for (int k = i * 4; k < cnt; k++) acc = chain_step<FMA>(HAS_VAL ? wt[k] : 1.0f, xr[k], acc);
+      __syncthreads();  // B
+    }
+    if (DGS_STRICT_PRIO) __builtin_amdgcn_s_setprio(0);
+    if (lane < W && fbase + lane < N) {
+      if constexpr (MEAN) acc /= (float)len;
+      float o[1] = {acc};
+      store_vec_stream<1>(C + (int64_t)row * N + fbase + lane, o);
+    }
+    return;
+  }
+  const int gp = lane / GP, lp = lane % GP;
   const int f0 = fbase + lp * V;
   const float *Bl = B + (f0 < N ? f0 : 0);
-  const int mine = wave * NWV + gp;  // this lane's nnz of gather q inside a round: mine + q * NGP
-  float acc = 0.0f;
-  int c[kUS];
-  float w[kUS], x[kUS][V];
+  const int mine = (wave - 1) * NWV + gp;  // this lane's nnz of gather q inside a phase: mine + q * NGP
+  float xa[kUS][V], xb[kUS][V];  // the two gather sets (even / odd phases)
+  int ce[kUS], co[kUS];          // columns of the next gathers of the even / odd set
+  float wn[kUS];                 // weights of the phase written NEXT
+  // slots past the end of the row repeat its last nnz (never chained)
+  auto load_cols = [&](int ph, int (&c)[kUS]) {
 #pragma unroll
-  for (int q = 0; q < kUS; q++) {
-    const int i = p0 + min(mine + q * NGP, len - 1);
-    c[q] = ld_stream(col + i);
-    w[q] = HAS_VAL ? ld_stream(val + i) : 1.0f;
-  }
+    for (int q = 0; q < kUS; q++) c[q] = ld_stream(col + p0 + min(ph * NRB + mine + q * NGP, len - 1));
+  };
+  auto load_w = [&](int ph) {
 #pragma unroll
-  for (int q = 0; q < kUS; q++) load_vec_gather<V>(Bl + (int64_t)c[q] * N, x[q]);
-  for (int r0 = 0; r0 < len; r0 += NRB) {
-    const int cnt = min(NRB, len - r0);
-    int cn[kUS];
-    float wn[kUS];
+    for (int q = 0; q < kUS; q++) wn[q] = HAS_VAL ? ld_stream(val + p0 + min(ph * NRB + mine + q * NGP, len - 1)) : 1.0f;
+  };
+  auto issue = [&](float (&x)[kUS][V], const int (&c)[kUS]) {
 #pragma unroll
-    for (int q = 0; q < kUS; q++) {
-      const int i = p0 + min(r0 + NRB + mine + q * NGP, len - 1);
-      cn[q] = ld_stream(col + i);
-      wn[q] = HAS_VAL ? ld_stream(val + i) : 1.0f;
-    }
-    __syncthreads();  // the chain of the previous round has left the tile
+    for (int q = 0; q < kUS; q++) load_vec_gather<V>(Bl + (int64_t)c[q] * N, x[q]);
+  };
+  // Loads return in order, so whatever a phase waits for must be OLDER than the gathers it wants to keep in flight: the
+  // columns (and weights) a phase needs were requested one phase earlier, BEFORE that phase's gathers.
+  auto phase = [&](const int ph, float (&x)[kUS][V], const int (&cuse)[kUS], int (&cload)[kUS]) {
 #pragma unroll
     for (int q = 0; q < kUS; q++) {
       const int i = mine + q * NGP;
 #pragma unroll
       for (int v = 0; v < V; v++) xt[(lp * V + v) * LD + i] = x[q][v];
-      if (HAS_VAL && lp == 0) wt[i] = w[q];
+      if (HAS_VAL && lp == 0) wt[i] = wn[q];
     }
-#pragma unroll
-    for (int q = 0; q < kUS; q++) {  // the next round's gathers fly under the chain
-      load_vec_gather<V>(Bl + (int64_t)cn[q] * N, x[q]);
-      w[q] = wn[q];
-    }
-    __syncthreads();
-    if (wave == 0 && lane < W) {
-      // the chain is the critical path of the whole call and a dependent sequence: give it the SIMD's issue slots ahead of
-      // the three other waves that share them (DGS_STRICT_PRIO=0 builds measure the difference)
-      if (DGS_STRICT_PRIO) __builtin_amdgcn_s_setprio(3);
-      const float *xr = xt + lane * LD;
-      constexpr int CB = 4;  // b128 pairs per batch = 16 steps
-      float4 xa[CB], wa[CB], xn[CB], wn4[CB];
-      auto rdb = [&](int i0, float4 (&xx)[CB], float4 (&ww)[CB]) {
-#pragma unroll
-        for (int u = 0; u < CB; u++) {
-          xx[u] = *reinterpret_cast<const float4 *>(xr + i0 + 4 * u);
-          if constexpr (HAS_VAL) ww[u] = *reinterpret_cast<const float4 *>(wt + i0 + 4 * u);
-          else ww[u] = make_float4(1.f, 1.f, 1.f, 1.f);
-        }
-      };
-      auto fmab = [&](const float4 (&xx)[CB], const float4 (&ww)[CB]) {
-#pragma unroll
-        for (int u = 0; u < CB; u++) {
-          acc = chain_step<FMA>(ww[u].x, xx[u].x, acc);
-          acc = chain_step<FMA>(ww[u].y, xx[u].y, acc);
-          acc = chain_step<FMA>(ww[u].z, xx[u].z, acc);
-          acc = chain_step<FMA>(ww[u].w, xx[u].w, acc);
-        }
-      };
-      constexpr int ST = 4 * CB;
-      int i = 0;
-      if (cnt >= ST) {
-        rdb(0, xa, wa);
-        while (true) {
-          if (i + 2 * ST <= cnt) rdb(i + ST, xn, wn4);
-          fmab(xa, wa);
-          i += ST;
-          if (i + ST > cnt) break;
-          if (i + 2 * ST <= cnt) rdb(i + ST, xa, wa);
-          fmab(xn, wn4);
-          i += ST;
-          if (i + ST > cnt) break;
-        }
-      }
-      for (; i < cnt; i++) acc = chain_step<FMA>(HAS_VAL ? wt[i] : 1.0f, xr[i], acc);
-      if (DGS_STRICT_PRIO) __builtin_amdgcn_s_setprio(0);
-    }
+    __syncthreads();  // A: the tile of phase ph is complete
+    load_cols(ph + 3, cload);
+    load_w(ph + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(x, cuse);   // this set's next gathers (phase ph + 2) fly under two chains
+    __syncthreads();  // B: the chain has left the tile
+  };
+  load_cols(0, ce);
+  load_cols(1, co);
+  load_w(0);
+  __builtin_amdgcn_sched_barrier(0);
+  issue(xa, ce);
+  __builtin_amdgcn_sched_barrier(0);  // (hipcc issued set b first: set a's writes then waited for everything)
+  issue(xb, co);
+  __builtin_amdgcn_sched_barrier(0);
+  load_cols(2, ce);
+  // (an odd last phase is peeled: with `if (ph + 1 < nph)` inside the loop the CFG has a path from one even phase straight into
+  // the next, on which set a's gathers are the youngest loads, and hipcc's merged wait at the loop header drains everything)
+  int ph = 0;
+  for (; ph + 1 < nph; ph += 2) {
+    phase(ph, xa, ce, co);
+    phase(ph + 1, xb, co, ce);
   }
-  if (wave == 0 && lane < W && fbase + lane < N) {
-    if constexpr (MEAN) acc /= (float)len;
-    float o[1] = {acc};
-    store_vec_stream<1>(C + (int64_t)row * N + fbase + lane, o);
-  }
+  if (ph < nph) phase(ph, xa, ce, co);
 }
 
 // Unit blocks of the strict fused launch.  Order of work: hub classes longest first, then the 4-slice units, then the

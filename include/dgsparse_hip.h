@@ -41,6 +41,9 @@ enum {
 int dgs_version(void);
 const char *dgs_arch(void);
 const char *dgs_strerror(int code);
+/* The DGS_* tuning overrides (tests / experiments) are read from the environment once per process; this re-reads them.
+ * Thread-safe with respect to concurrent launches (they keep the snapshot they started with). */
+void dgs_reload_tuning(void);
 
 /*
  * CSR SpMM with reduce:  C[r,:] = reduce_{p in row r} val[p] * B[col[p],:]

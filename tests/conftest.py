@@ -28,3 +28,30 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _dgs_tuning_follows_env(monkeypatch):
+    """The library snapshots its DGS_* tuning overrides once per process (no getenv() on the launch path); tests flip them
+    through monkeypatch, so every DGS_* change made that way - and the restore at teardown - is followed by a reload."""
+    try:
+        from dgsparse import _capi
+    except Exception:  # CPU-only collection of tests that never import the package
+        yield
+        return
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def _setenv(name, value, *a, **k):
+        setenv(name, value, *a, **k)
+        if name.startswith('DGS_'):
+            _capi.reload_tuning()
+
+    def _delenv(name, *a, **k):
+        delenv(name, *a, **k)
+        if name.startswith('DGS_'):
+            _capi.reload_tuning()
+
+    monkeypatch.setenv, monkeypatch.delenv = _setenv, _delenv
+    yield
+    monkeypatch.undo()
+    _capi.reload_tuning()

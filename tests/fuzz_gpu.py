@@ -95,12 +95,14 @@ def one_case(rng, it):
                     assert_bitexact(E.cpu().numpy(), Eo, tag + ' plan E ' + reduce)
             if N % 4 == 0 and 32 <= N <= 256:  # round 3: SDDMM on the fused row-block / unit schedule over the same plan
                 os.environ['DGS_SDDMM_FUSED'] = '1'
+                capi.reload_tuning()
                 D1p = (rng.integers(-3, 4, (M, N)) / 8).astype(np.float32)
                 for mean in (False, True):
                     got = capi.sddmm(drp, dcol, dev(D1p), dX, reduce_op=capi.MEAN if mean else capi.SUM, plan=plan)
                     assert_close(got.cpu().numpy(), oracle.sddmm(rp, col, D1p, X, reduce='mean' if mean else 'sum', fma=True), 1e-5, 1e-5,
                                  tag + f' sddmm over the plan mean={mean}')
                 os.environ.pop('DGS_SDDMM_FUSED', None)
+                capi.reload_tuning()
         capi.canary_check(tag + ' plan')
         C0 = (rng.integers(-4, 5, (M, N)) / 4).astype(np.float32)
         Cacc = dev(C0)

@@ -95,6 +95,7 @@ def test_strict_on_the_column_panel_schedule(capi):
     old = {k: os.environ.get(k) for k in ('DGS_PANEL', 'DGS_PANEL_TLONG')}
     os.environ['DGS_PANEL'] = '1'
     os.environ['DGS_PANEL_TLONG'] = '2500'
+    capi.reload_tuning()
     try:
         assert np.diff(rp).max() > 2500
         C = run(capi, 'sum', rp, col, val, X, capi.ALG_STRICT_SUM)
@@ -105,6 +106,7 @@ def test_strict_on_the_column_panel_schedule(capi):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        capi.reload_tuning()
     ref, _ = oracle.spmm('sum', rp, col, val, X, fma=True, threads=oracle.max_threads())
     assert_bitexact(C, ref, 'strict sum on the panel schedule')
     refn, _ = oracle.spmm('mean', rp, col, val, X, fma=False, threads=oracle.max_threads())

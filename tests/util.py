@@ -12,7 +12,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 def golden_names(pattern='*'):
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, pattern + '.npz'))
-                  if 'p2p' not in p and 'gspmm' not in p)
+                  if 'p2p' not in p and 'gspmm' not in p and 'ca_condmat' not in p)
 
 
 def load_golden(name):
