@@ -112,6 +112,8 @@ struct UnitTab {
   const int *xcd_start;  // [9] first unit of each XCD's share, or nullptr = equal eighths of the table
   const int4 *units;
   const int4 *longrows;
+  const int *xcd_end = nullptr;  // [8] where each XCD's walk stops (a plan's hub-row units are skipped when the hub blocks
+                                 // chain those rows), or nullptr = the next share's start
 };
 
 struct WsLayout {
@@ -166,9 +168,11 @@ constexpr int kPlanChMin = 64;        // ... and the shortest one it uses (small
 constexpr int kPlanSliceMin = 128;    // smallest row length that may be cut on the column grid
 constexpr int kPlanUnitMin = 16;      // smallest nnz-per-cell target of a cut row
 constexpr int kPlanCells = 128;       // finest column grid: 8 slices (one per XCD) x 16 cells
+constexpr int kHubChain = 8192;     // default hub threshold of the sum / mean launches (DGS_HUB_CHAIN; 0 = no hub chains)
+constexpr int kHubChainMin = 1024;  // smallest threshold accepted (bounds the hub tables: nnz / 1024 rows)
 struct PlanLayout {
-  int64_t max_units, max_long;
-  size_t off_bounds, off_units, off_long, total;
+  int64_t max_units, max_long, max_hub;
+  size_t off_bounds, off_units, off_long, off_hub, total;
 };
 static inline PlanLayout plan_layout(int64_t nnz) {
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
@@ -178,8 +182,10 @@ static inline PlanLayout plan_layout(int64_t nnz) {
   L.max_long = nnz / kPlanSliceMin + nnz / kPlanChMin + 2;
   L.off_bounds = 256;
   L.off_units = 256 + 768;  // (kPlanCells + 1) ints
+  L.max_hub = nnz / kHubChainMin + 16;
   L.off_long = L.off_units + up((size_t)L.max_units * sizeof(int4));
-  L.total = L.off_long + up((size_t)L.max_long * sizeof(int4)) + 256;
+  L.off_hub = L.off_long + up((size_t)L.max_long * sizeof(int4));
+  L.total = L.off_hub + up((size_t)L.max_hub * sizeof(int4)) + 256;
   return L;
 }
 
@@ -301,6 +307,44 @@ __device__ __forceinline__ void seq_redo(unsigned mask, int rs, int re, int N, i
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Hub rows are taken longest first (a 50 k-nnz row is the critical path of the whole call): class c holds the rows with
+// kStrictHub << c < nnz <= kStrictHub << (c + 1) (the last class: everything longer), each class has its own region of the
+// unit table behind the front entries, sized for the worst case, and the unit waves walk class 5, 4, ... 0, then the front.
+constexpr int kHubClasses = 6;
+struct HubTab {
+  int base[kHubClasses];  // first table entry of each class region (one entry {row, first nnz, nnz, -} per hub row)
+  int mid_top;            // strict schedule: the 4-slice units grow down from here (whole-tile units grow up from entry 0)
+};
+// Regions behind `first` entries; class c holds at most nnz / (thub << c) rows.
+static inline HubTab hub_tab(int64_t nnz, int thub, int64_t first) {
+  HubTab t;
+  int64_t o = first;
+  t.mid_top = (int)o;
+  for (int c = 0; c < kHubClasses; c++) {
+    t.base[c] = (int)o;
+    o += nnz / ((int64_t)thub << c) + 16;
+  }
+  return t;
+}
+static inline int64_t hub_tab_entries(int64_t nnz, int thub) {  // sum of the class regions: <= 2 nnz / thub + 96
+  int64_t o = 0;
+  for (int c = 0; c < kHubClasses; c++) o += nnz / ((int64_t)thub << c) + 16;
+  return o;
+}
+__host__ __device__ __forceinline__ int hub_class(int len, int thub) {
+  int c = 0;
+  while (c < kHubClasses - 1 && len > (thub << (c + 1))) c++;
+  return c;
+}
+// What the hub blocks of a launch walk: per-class row counts (device: the classify pass or the plan wrote them) + the table.
+struct HubArg {
+  const int *cnt;     // [ncls] rows per class
+  const int4 *rows;   // table the class regions of `ht` index
+  HubTab ht;
+  int ncls;           // kHubClasses (tables of a classify pass), 1 (a plan's table: dense, sorted longest first), 0 = none
+};
+
+// ---------------------------------------------------------------------------------------------------------
 // K0: scan rowptr once and cut every long row (len > tlong) into units of <= ch nnz; multi-unit rows also get an entry
 // of the long-row table (what spmm_combine folds).  Each thread looks at kK0Rows rows, a block-level exclusive scan
 // turns the per-thread counts into offsets, and ONE 64-bit atomicAdd per block reserves the block's range of the unit
@@ -308,7 +352,9 @@ __device__ __forceinline__ void seq_redo(unsigned mask, int rs, int re, int N, i
 // made this kernel 44 us, per-block ones ~5); blocks that own multi-unit rows add one more for the long-row table.
 // Only the position of a row's entries in the tables depends on the atomics, never a value.
 constexpr int kK0Rows = 16;
-static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, int tlong,
+// Rows longer than thub (INT_MAX = none) are not cut at all: they go to the hub table (one entry per row in the region of its
+// length class, HubTab) and are chained whole by the hub blocks of the fused launch (spmm_hub_body).
+static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, int tlong, int thub, const HubTab ht,
                                                                const int *__restrict__ rowptr,
                                                                SpmmWs *__restrict__ hdr, int4 *__restrict__ units,
                                                                int4 *__restrict__ longrows) {
@@ -320,13 +366,15 @@ static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, in
   const int tid = blockIdx.x * kBlock * kK0Rows + threadIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int mine = 0, pmine = 0, lmine = 0;  // units of this thread's rows; units that need a partial slot; multi-unit rows
-  unsigned hugemask = 0;
+  unsigned hugemask = 0, hubmask = 0;
 #pragma unroll
   for (int i = 0; i < kK0Rows; i++) {
     const int r = i * nthreads + tid;
     if (r < M) {
       const int len = rowptr[r + 1] - rowptr[r];
-      if (len > tlong) {
+      if (len > thub) {
+        hubmask |= 1u << i;
+      } else if (len > tlong) {
         const int nch = (len + ch - 1) / ch;
         mine += nch;
         if (nch > 1) {
@@ -379,6 +427,14 @@ static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, in
     s_lbase = ltotal ? atomicAdd(&hdr->n_long, ltotal) : 0;
   }
   __syncthreads();
+  while (hubmask) {  // rare (hundreds in a million rows): one atomicAdd per row on the counter of its length class
+    const int i = __ffs((int)hubmask) - 1;
+    hubmask &= hubmask - 1;
+    const int r = i * nthreads + tid;
+    const int rs = rowptr[r], len = rowptr[r + 1] - rs;
+    const int c = hub_class(len, thub);
+    units[ht.base[c] + atomicAdd(&hdr->hub[c], 1)] = make_int4(r, rs, len, 0);
+  }
   if (!mine) return;
   int off = s_base + woff + incl - mine;
   int poff = s_pbase + pwoff + pincl - pmine;
@@ -858,7 +914,7 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
   if ((nblocks & 7) == 0) {
     const int x = bid & 7, wx = (nblocks >> 3) * (kBlock / kWave);
     const int lo = ut.xcd_start ? ut.xcd_start[x] : (int)(((long long)n_units * x) >> 3);
-    uend = ut.xcd_start ? ut.xcd_start[x + 1] : (int)(((long long)n_units * (x + 1)) >> 3);
+    uend = ut.xcd_end ? ut.xcd_end[x] : (ut.xcd_start ? ut.xcd_start[x + 1] : (int)(((long long)n_units * (x + 1)) >> 3));
     u = lo + (bid >> 3) * (kBlock / kWave) + wave;
     wstride = wx;
   } else
@@ -933,27 +989,56 @@ constexpr int fused_waves_per_simd(int op) { return (op == DGS_MAX || op == DGS_
 // Fused launch: blocks [0, nbu) walk the unit table of the huge rows (persistent, strided), the remaining blocks
 // each own 4 x 64 consecutive rows.  Unit blocks come first so that the longest-running work starts first; the
 // two kinds of work share the CUs, so the fabric-bound unit gathers overlap the row kernel's latency phases.
-template <int G, int V, int OP, bool HAS_VAL, bool ACC = false>
-__global__ __launch_bounds__(kBlock, fused_waves_per_simd(OP)) void spmm_fused(int M, int N, int nbu, int rpw, const int *__restrict__ rowptr,
+// HUB (sum / mean, 16-byte lanes, tiles of >= 16 floats): the first nbh blocks chain the hub rows (spmm_hub_body: every row
+// longer than the hub threshold one sequential fmaf chain per feature, like the rows up to T1 - the rows in between keep the
+// fixed tree); they come first in the grid because a 50 k-nnz chain is the longest job of the launch.
+template <int OP, int V, int G, bool ACC>
+constexpr bool hub_ok() { return (OP == DGS_SUM || OP == DGS_MEAN) && !ACC && strict_coop(G, V); }
+struct HubLds {
+  alignas(16) float f[kHubBlockFloats];
+};
+template <bool HUB>
+struct FusedLds {
+  RowsLds r;
+};
+template <>
+struct FusedLds<true> {
+  union {
+    RowsLds r;
+    HubLds h;
+  };
+  __device__ FusedLds() {}
+};
+template <int G, int V, int OP, bool HAS_VAL, bool ACC = false, bool HUB = false>
+__global__ __launch_bounds__(kBlock, fused_waves_per_simd(OP)) void spmm_fused(int M, int N, int nbh, int nbu, int rpw, const int *__restrict__ rowptr,
                                                      const int *__restrict__ col, const float *__restrict__ val,
                                                      const float *__restrict__ B, float *__restrict__ C,
                                                      int *__restrict__ E, const UnitTab ut, float *__restrict__ part,
-                                                     int *__restrict__ parte, const AccArg aa) {
-  __shared__ RowsLds lds;
-  if ((int)blockIdx.x < nbu)
-    spmm_units_body<G, V, OP, HAS_VAL, ACC>(blockIdx.x, nbu, lds, N, rowptr, col, val, B, C, E, ut, part, parte, aa);
+                                                     int *__restrict__ parte, const AccArg aa, const HubArg ha) {
+  __shared__ FusedLds<HUB> lds;
+  int bx = blockIdx.x;
+  if constexpr (HUB) {
+    if (bx < nbh) {
+      spmm_hub_body<G, V, OP == DGS_MEAN, HAS_VAL, true, kHubBlockFloats>(bx, nbh, lds.h.f, N, col, val, B, C, ha, aa.epi);
+      return;
+    }
+    bx -= nbh;  // nbh is a multiple of 8: block index and XCD keep their relation
+  }
+  const int ngrid = (int)gridDim.x - (HUB ? nbh : 0);
+  if (bx < nbu)
+    spmm_units_body<G, V, OP, HAS_VAL, ACC>(bx, nbu, lds.r, N, rowptr, col, val, B, C, E, ut, part, parte, aa);
   else {
     // XCD-aware row mapping: workgroups are dealt round-robin to the 8 XCDs (observed: block b -> XCD b % 8), each
     // with a private L2.  Give every XCD a CONTIGUOUS eighth of the row blocks, so that neighbouring rows - which
     // in a locality-preserving ordering share columns - hit the same L2 instead of fetching the same B rows 8x.
     // Pure speed hint: any placement gives the same result.
-    int rb = blockIdx.x - nbu;
+    int rb = bx - nbu;
 #if DGS_XCD_REMAP
-    const int nbr = gridDim.x - nbu;
+    const int nbr = ngrid - nbu;
     const int per = nbr / 8;
     if (rb < per * 8) rb = (rb % 8) * per + rb / 8;
 #endif
-    spmm_rows_body<G, V, OP, HAS_VAL, false, ACC>(rb, rpw, lds, M, N, rowptr, col, val, B, C, E, aa);
+    spmm_rows_body<G, V, OP, HAS_VAL, false, ACC>(rb, rpw, lds.r, M, N, rowptr, col, val, B, C, E, aa);
   }
 }
 
@@ -1015,7 +1100,7 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
                                                        const float *__restrict__ B, float *__restrict__ C,
                                                        int *__restrict__ E, const UnitTab ut,
                                                        const float *__restrict__ part,
-                                                       const int *__restrict__ parte, const AccArg aa) {
+                                                       const int *__restrict__ parte, const AccArg aa, const int skip_hub) {
   constexpr int NG = kWave / G;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
 #ifndef DGS_COMBINE_UP
@@ -1035,7 +1120,8 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
   const int n_long = *ut.n_long;
   const int wstride = gridDim.x * (kBlock / kWave);
   for (int i = blockIdx.x * (kBlock / kWave) + wave; i < n_long; i += wstride) {
-    const int4 d = ut.longrows[i];  // {row, first partial slot, units in the row, -}
+    const int4 d = ut.longrows[i];  // {row, first partial slot, units in the row, 1 = a plan's hub row}
+    if (skip_hub && d.w) continue;  // chained whole by the hub blocks of the fused launch: nothing to fold
     {
     float acc[V];
     int ei[V], ep[V], el[V];
@@ -1136,7 +1222,7 @@ struct SpmmArgs {
   int reduce_op;
   // cached plan (dgs_spmm_plan_build): device tables + the counts the host needs to size grids and the workspace
   const struct PlanHdr *plan = nullptr;
-  int plan_units = 0, plan_long = 0, plan_pslots = 0, plan_off_long = 0;
+  int plan_units = 0, plan_long = 0, plan_pslots = 0, plan_off_long = 0, plan_hub = 0, plan_off_hub = 0;
   int hints = 0;  // DGS_ALG_* bits of the `algorithm` argument
   bool accumulate = false;      // merge into C (and E) instead of overwriting (sum, max, min): see AccArg
   AccArg acc{};
@@ -1151,7 +1237,9 @@ struct PlanHdr {
   int ch, t1, tslice, unit;
   int xcd_start[9];     // first unit of each XCD's share of the (sorted) unit table
   int slice_bound[9];   // column-slice boundaries (slice x = columns [b[x], b[x+1]))
-  int reserved[5];      // (popularity classes of an abandoned cache-policy experiment: DESIGN.md 4.1d)
+  int thub, n_hub;      // rows longer than thub are ALSO listed in the hub table, sorted longest first (sum / mean chain them)
+  int xcd_hub[8];       // first hub-row unit of each XCD's share (they sit behind the share's other units)
+  int reserved[3];
 };
 static_assert(sizeof(PlanHdr) <= 256, "plan header must fit its 256-byte slot");
 
@@ -1199,6 +1287,38 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
   return P;
 }
 
+// Hub threshold of the default sum / mean launches: rows longer than this are chained whole (spmm_hub_body) instead of being
+// folded by the fixed tree.  The reference's result is a sequential fp32 chain (include/cuda/spmm_cuda.cuh:27-47), whose own
+// rounding error grows like sqrt(len): on the headline graph it stays below 5e-6 of the exact sum up to 8192 nnz and reaches
+// 1.2e-5 on the 50 k-nnz rows (profiles/r04_chain_error_by_length.txt) - a tree that is closer to the exact sum than that is
+// further than 1e-5 from the REFERENCE there.  Above the threshold the chain is reproduced bit for bit; below it the tree is
+// within ~5e-6 of it (non-negative data; DGS_ALG_STRICT_SUM chains every row).
+static inline int hub_threshold() {
+  int t = tune(tuning().hub_chain, kHubChain);
+  if (t <= 0) return INT_MAX;
+  return t < kHubChainMin ? kHubChainMin : t;
+}
+static inline int hub_blocks(int64_t tasks) {  // a multiple of 8 (XCD mapping), at most one workgroup per CU
+  int64_t b = (tasks + 7) & ~int64_t(7);
+  const int cap = (cu_count() + 7) & ~7;
+  return (int)(b < cap ? b : cap);
+}
+
+template <int G, int V, int OP, bool HAS_VAL, bool ACC>
+static void launch_fused(const SpmmArgs &a, int nbh, int nbu, int64_t nbr, int rpw, const UnitTab &ut, float *part, int *parte,
+                         const HubArg &ha) {
+  if constexpr (hub_ok<OP, V, G, ACC>()) {
+    if (nbh > 0) {
+      hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC, true>), dim3((unsigned)(nbh + nbu + nbr), (unsigned)a.tiles),
+                         dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, nbh, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part,
+                         parte, a.acc, ha);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC, false>), dim3((unsigned)(nbu + nbr), (unsigned)a.tiles), dim3(kBlock), 0,
+                     a.st, (int)a.M, (int)a.N, 0, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.acc, HubArg{});
+}
+
 template <int G, int V, int OP, bool HAS_VAL, bool ACC>
 static int launch_impl(const SpmmArgs &a) {
   if constexpr (V == 4 && G >= 8 && !ACC) {
@@ -1217,7 +1337,10 @@ static int launch_impl(const SpmmArgs &a) {
       const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
       int tl = P.tlong > L.ch ? P.tlong : L.ch;  // every long row has >= 2 units => all go through combine
       if (tl > 65534) tl = 65534;  // max keeps 16-bit arg positions (unit lengths never exceed 32768: still >= 2 units)
-      hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, tl, a.rowptr, hdr,
+      int thub = hub_ok<OP, V, G, ACC>() ? hub_threshold() : INT_MAX;
+      if (thub < tl) thub = tl;  // rows up to tl belong to the panel sweep (one sequential chain per row already)
+      const HubTab ht = hub_tab(a.nnz, thub < INT_MAX ? thub : kHubChainMin, a.nnz / kT1 + 2);
+      hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, tl, thub, ht, a.rowptr, hdr,
                          units, longrows);
       auto kern = spmm_panel<G, OP, HAS_VAL>;
       static std::atomic<bool> attr_set[64];  // per instantiation and device: allow the large dynamic LDS (setting it twice is harmless)
@@ -1238,12 +1361,12 @@ static int launch_impl(const SpmmArgs &a) {
                            Epi{a.acc.epi.bias ? a.acc.epi.bias + fb : nullptr, a.acc.epi.rscale, a.acc.epi.relu});
       }
       const int nbu = 1024;
-      hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC>), dim3((unsigned)nbu, (unsigned)a.tiles), dim3(kBlock), 0, a.st, (int)a.M,
-                         (int)a.N, nbu, kRowsPerWave, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.acc);
+      launch_fused<G, V, OP, HAS_VAL, ACC>(a, thub < INT_MAX ? hub_blocks(cu_count()) : 0, nbu, 0, kRowsPerWave, ut, part, parte,
+                                           HubArg{hdr->hub, units, ht, kHubClasses});
       const int64_t cb = (L.max_long + 3) / 4;
       const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
       hipLaunchKernelGGL((spmm_combine<G, V, OP, ACC>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B,
-                         a.C, a.E, ut, part, parte, a.acc);
+                         a.C, a.E, ut, part, parte, a.acc, 0);
       return check_launch();
     }
   }
@@ -1275,21 +1398,27 @@ static int launch_impl(const SpmmArgs &a) {
     int *parte = reinterpret_cast<int *>(w + L.off_parte);
     const PlanHdr *ph = a.plan;
     const PlanLayout PL = plan_layout(a.nnz);
-    const UnitTab ut{&ph->n_units, &ph->n_long, ph->xcd_start, reinterpret_cast<const int4 *>(pb + PL.off_units),
-                     reinterpret_cast<const int4 *>(pb + (a.plan_off_long ? (size_t)a.plan_off_long : PL.off_long))};
+    UnitTab ut{&ph->n_units, &ph->n_long, ph->xcd_start, reinterpret_cast<const int4 *>(pb + PL.off_units),
+               reinterpret_cast<const int4 *>(pb + (a.plan_off_long ? (size_t)a.plan_off_long : PL.off_long))};
     int64_t ub = ((int64_t)a.plan_units + 3) / 4;
     ub = (ub + 7) & ~int64_t(7);  // a multiple of 8 so that the XCD mapping of the unit blocks applies
     int nbu_req = tune(tuning().nbu, DGS_NBU);
     if (nbu_req < 8) nbu_req = 8;  // an override of 0 would leave the units without a single block
     const int nbu_cap = (nbu_req + 7) & ~7;
     const int nbu = (int)(ub < nbu_cap ? (ub < 8 ? 8 : ub) : nbu_cap);
-    hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
-                       a.st, (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.acc);
+    // hub rows of the plan (longer than the plan's thub): one dense table, longest first, for the sum / mean launches; their
+    // units stay in the table (sorted behind the other units of each XCD's share) for every other reduce
+    const bool use_hub = hub_ok<OP, V, G, ACC>() && a.plan_hub > 0 && hub_threshold() < INT_MAX;
+    HubTab ht{};
+    const HubArg ha{&ph->n_hub, reinterpret_cast<const int4 *>(pb + (a.plan_off_hub ? (size_t)a.plan_off_hub : PL.off_hub)), ht, 1};
+    const int nbh = use_hub ? hub_blocks((int64_t)a.plan_hub * strict_shub(G, V)) : 0;
+    if (use_hub) ut.xcd_end = ph->xcd_hub;  // the hub rows' units (behind the others of each share) are not walked
+    launch_fused<G, V, OP, HAS_VAL, ACC>(a, nbh, nbu, nbr, rpw, ut, part, parte, ha);
     if (a.plan_long > 0) {
       const int64_t cb = ((int64_t)a.plan_long + 3) / 4;
       const dim3 g3((unsigned)(cb < 2048 ? cb : 2048), (unsigned)a.tiles);
       hipLaunchKernelGGL((spmm_combine<G, V, OP, ACC>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B,
-                         a.C, a.E, ut, part, parte, a.acc);
+                         a.C, a.E, ut, part, parte, a.acc, use_hub ? 1 : 0);
     }
     return check_launch();
   }
@@ -1303,20 +1432,24 @@ static int launch_impl(const SpmmArgs &a) {
   const UnitTab ut{&hdr->n_units, &hdr->n_long, nullptr, units, longrows};
   if (hipMemsetAsync(hdr, 0, sizeof(SpmmWs), a.st) != hipSuccess) return DGS_ELAUNCH;
   const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
-  hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, kT2, a.rowptr, hdr, units,
-                     longrows);
+  const int thub = hub_ok<OP, V, G, ACC>() ? hub_threshold() : INT_MAX;
+  const HubTab ht = hub_tab(a.nnz, thub < INT_MAX ? thub : kHubChainMin, a.nnz / kT1 + 2);
+  hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, kT2, thub, ht, a.rowptr, hdr,
+                     units, longrows);
   // unit / multi counts live on the device: a bounded number of persistent unit blocks stride over the table
   const int64_t ub = (L.max_units + 3) / 4;
   int nbu_cap = tune(tuning().nbu, DGS_NBU);
   if (nbu_cap < 1) nbu_cap = 1;
   const int nbu = (int)(ub < nbu_cap ? (ub < 1 ? 1 : ub) : nbu_cap);
-  hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles), dim3(kBlock), 0,
-                     a.st, (int)a.M, (int)a.N, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.acc);
+  // (the hub count lives on the device: one hub workgroup per CU is launched whenever hub chains are on; without hub rows they
+  // read six zeros and leave)
+  launch_fused<G, V, OP, HAS_VAL, ACC>(a, thub < INT_MAX ? hub_blocks(cu_count()) : 0, nbu, nbr, rpw, ut, part, parte,
+                                       HubArg{hdr->hub, units, ht, kHubClasses});
   // combine: one wave per multi-unit row
   const int64_t cb = (L.max_long + 3) / 4;
   const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
   hipLaunchKernelGGL((spmm_combine<G, V, OP, ACC>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B, a.C,
-                     a.E, ut, part, parte, a.acc);
+                     a.E, ut, part, parte, a.acc, 0);
   return check_launch();
 }
 
@@ -1359,9 +1492,9 @@ static int launch_strict(const SpmmArgs &a) {
     if (P.use) {
       int tl = P.tlong > kStrictHub ? P.tlong : kStrictHub;
       if (tl > 65534) tl = 65534;
-      const HubTab ht = hub_tab(a.nnz, strict_shub(G, V), tl);
-      hipLaunchKernelGGL(spmm_classify_strict, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, tl, tl, tl,
-                         strict_smid(G), strict_shub(G, V), ht, a.rowptr, hdr, units);
+      const HubTab ht = hub_tab(a.nnz, tl, a.nnz / kT1 + 2);
+      hipLaunchKernelGGL(spmm_classify_strict, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, tl, tl, tl, ht, a.rowptr,
+                         hdr, units);
       auto kern = spmm_panel<G, OP, HAS_VAL>;
       static std::atomic<bool> attr_set[64];
       int dev_id = 0;
@@ -1389,9 +1522,9 @@ static int launch_strict(const SpmmArgs &a) {
   while (rpw > 8 && a.M / rpw < min_waves) rpw >>= 1;
   const int rows_per_block = (kBlock / kWave) * rpw;
   const int64_t nbr = (a.M + rows_per_block - 1) / rows_per_block;
-  const HubTab ht = hub_tab(a.nnz, strict_shub(G, V), thub);
-  hipLaunchKernelGGL(spmm_classify_strict, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, kT1, tmid, thub,
-                     strict_smid(G), strict_shub(G, V), ht, a.rowptr, hdr, units);
+  const HubTab ht = hub_tab(a.nnz, thub, a.nnz / kT1 + 2);
+  hipLaunchKernelGGL(spmm_classify_strict, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, kT1, tmid, thub, ht, a.rowptr,
+                     hdr, units);
   hipLaunchKernelGGL((spmm_fused_strict<G, V, OP, HAS_VAL, STRICT>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles),
                      dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, nbu, rpw, ht, a.rowptr, a.col, a.val, a.B, a.C, hdr, units);
   return check_launch();

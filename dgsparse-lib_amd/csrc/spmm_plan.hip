@@ -28,11 +28,13 @@ static_assert(kT1 == kT2, "spmm_plan.hip assumes DGS_T2 == DGS_T1 (rows in (T1, 
 
 struct PlanWs {  // build-time counters (zeroed by the first memset)
   int n_longlist;
-  int pad[3];
+  int n_hub;
+  int pad[2];
 };
 
 struct PlanWsLayout {
-  size_t off_cnt, off_cum, off_list, off_info, off_scan, off_keys_in, off_keys_out, off_units_in, off_tmp, tmp_bytes, total;
+  size_t off_cnt, off_cum, off_list, off_info, off_scan, off_keys_in, off_keys_out, off_units_in, off_hkeys_in, off_hkeys_out,
+      off_hub_in, off_tmp, tmp_bytes, total;
   int64_t cap_long;
 };
 
@@ -53,8 +55,12 @@ static PlanWsLayout plan_ws_layout(int64_t K, int64_t nnz) {
   unsigned long long *kp = nullptr;
   (void)rocprim::exclusive_scan(nullptr, t1, ip, ip, 0, (size_t)(K + 1), rocprim::plus<int>(), nullptr, false);
   (void)rocprim::exclusive_scan(nullptr, t2, i4, i4, make_int4(0, 0, 0, 0), (size_t)L.cap_long, I4Plus(), nullptr, false);
-  (void)rocprim::radix_sort_pairs(nullptr, t3, kp, kp, i4, i4, (size_t)PL.max_units, 0, 36, nullptr, false);
+  (void)rocprim::radix_sort_pairs(nullptr, t3, kp, kp, i4, i4, (size_t)PL.max_units, 0, 37, nullptr, false);
+  size_t t4 = 0;
+  unsigned *hp = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, t4, hp, hp, i4, i4, (size_t)PL.max_hub, 0, 32, nullptr, false);
   L.tmp_bytes = t1 > t2 ? (t1 > t3 ? t1 : t3) : (t2 > t3 ? t2 : t3);
+  if (t4 > L.tmp_bytes) L.tmp_bytes = t4;
   size_t o = up(sizeof(PlanWs));
   L.off_cnt = o;          o += up((size_t)(K + 1) * 4);
   L.off_cum = o;          o += up((size_t)(K + 1) * 4);
@@ -64,6 +70,9 @@ static PlanWsLayout plan_ws_layout(int64_t K, int64_t nnz) {
   L.off_keys_in = o;      o += up((size_t)PL.max_units * 8);
   L.off_keys_out = o;     o += up((size_t)PL.max_units * 8);
   L.off_units_in = o;     o += up((size_t)PL.max_units * 16);
+  L.off_hkeys_in = o;     o += up((size_t)PL.max_hub * 4);
+  L.off_hkeys_out = o;    o += up((size_t)PL.max_hub * 4);
+  L.off_hub_in = o;       o += up((size_t)PL.max_hub * 16);
   L.off_tmp = o;          o += up(L.tmp_bytes);
   L.total = o + 256;
   return L;
@@ -82,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void plan_hist(int nnz, int K, const int *_
 // below it) >= c * nnz / kPlanCells.  8 slices (one per XCD) of kPlanCells/8 cells each; a row is cut on the grid at a
 // level that leaves it about `unit` nnz per cell: level j = (8 << j) cells, each the union of (16 >> j) finest cells.
 __global__ void plan_bounds(int K, int nnz, const int *__restrict__ cum, PlanHdr *__restrict__ hdr, int *__restrict__ bounds,
-                            int M, int ch, int t1, int tslice, int unit) {
+                            int M, int ch, int t1, int tslice, int unit, int thub) {
   const int x = threadIdx.x;
   if (x == 0) {
     hdr->magic = kPlanMagic;
@@ -94,6 +103,7 @@ __global__ void plan_bounds(int K, int nnz, const int *__restrict__ cum, PlanHdr
     hdr->t1 = t1;
     hdr->tslice = tslice;
     hdr->unit = unit;
+    hdr->thub = thub;
   }
   if (x > kPlanCells) return;
   int b;
@@ -182,10 +192,13 @@ __device__ __forceinline__ int cut_row(const int *__restrict__ col, const int *_
 
 // One wave per long row: is it cut on the column grid (long enough AND sorted)?  how many units?
 // info[i] = {units, units that need a partial slot (0 for a single-unit row), 1 if multi-unit, 1 + level if cut | 0}
-__global__ __launch_bounds__(kBlock) void plan_rowunits(int ch, int tslice, int nocut, int unit, const int *__restrict__ rowptr,
-                                                        const int *__restrict__ col, const PlanWs *__restrict__ pw,
-                                                        const int *__restrict__ bounds, const int *__restrict__ list,
-                                                        int4 *__restrict__ info) {
+// Rows longer than thub are ALSO appended to the hub staging list {row, first nnz, nnz, -} with key ~nnz (sorted longest first
+// afterwards): the sum / mean launches chain them whole and skip their units, every other reduce folds them as before.
+__global__ __launch_bounds__(kBlock) void plan_rowunits(int ch, int tslice, int nocut, int unit, int thub, int max_hub,
+                                                        const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                        PlanWs *__restrict__ pw, const int *__restrict__ bounds,
+                                                        const int *__restrict__ list, int4 *__restrict__ info,
+                                                        unsigned *__restrict__ hkeys, int4 *__restrict__ hub_in) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = pw->n_longlist;
   for (int i = blockIdx.x * (kBlock / kWave) + wave; i < n; i += gridDim.x * (kBlock / kWave)) {
@@ -205,7 +218,17 @@ __global__ __launch_bounds__(kBlock) void plan_rowunits(int ch, int tslice, int 
     } else {
       nu = (re - rs + ch - 1) / ch;
     }
-    if (lane == 0) info[i] = make_int4(nu, nu > 1 ? nu : 0, nu > 1 ? 1 : 0, sliced ? 1 + lvl : 0);
+    const bool hub = (re - rs) > thub;
+    if (lane == 0) {
+      info[i] = make_int4(nu, nu > 1 ? nu : 0, nu > 1 ? 1 : 0, (sliced ? 1 + lvl : 0) | (hub ? 64 : 0));
+      if (hub) {
+        const int h = atomicAdd(&pw->n_hub, 1);
+        if (h < max_hub) {  // (always: a hub row has more than kHubChainMin nnz and the capacity is nnz / kHubChainMin + 16)
+          hkeys[h] = ~(unsigned)(re - rs);
+          hub_in[h] = make_int4(r, rs, re - rs, 0);
+        }
+      }
+    }
   }
 }
 
@@ -217,6 +240,7 @@ __global__ void plan_totals(const PlanWs *__restrict__ pw, const int4 *__restric
   hdr->n_units = t.x;
   hdr->n_pslots = t.y;
   hdr->n_long = t.z;
+  hdr->n_hub = pw->n_hub;
 }
 
 __device__ __forceinline__ unsigned hash32(unsigned x) {
@@ -241,9 +265,10 @@ __global__ __launch_bounds__(kBlock) void plan_emit(int ch, const int *__restric
     const int4 inf = info[i], sc = scan[i];  // sc = {first unit, first partial slot, long-row index, -}
     const int rs = rowptr[r], re = rowptr[r + 1];
     const int nu = inf.x;
-    if (lane == 0 && nu > 1) longrows[sc.z] = make_int4(r, sc.y, nu, 0);
-    if (inf.w) {
-      const int j = inf.w - 1;
+    const unsigned long long hub = (inf.w & 64) ? 1ull : 0ull;  // hub rows: units behind the others of their slice, long row flagged
+    if (lane == 0 && nu > 1) longrows[sc.z] = make_int4(r, sc.y, nu, (int)hub);
+    if (inf.w & 63) {
+      const int j = (inf.w & 63) - 1;
       RowCut rc;
       cut_row(col, bounds, rs, re, j, ch, lane, rc);
       // units are numbered in position order (= column order of the sorted row): cell 2l first, then cell 2l+1
@@ -253,29 +278,31 @@ __global__ __launch_bounds__(kBlock) void plan_emit(int ch, const int *__restric
         const unsigned long long slice = (unsigned long long)((2 * lane + q) >> j);
         for (int p0 = a; p0 < b; p0 += ch, k++) {
           units[sc.x + k] = make_int4(r, p0, min(ch, b - p0), nu > 1 ? sc.y + k : -1);
-          keys[sc.x + k] = (slice << 32) | (unsigned)col[p0];
+          keys[sc.x + k] = (slice << 33) | (hub << 32) | (unsigned)col[p0];
         }
       }
     } else {
       for (int k = lane; k < nu; k += kWave) {
         const int p0 = rs + k * ch;
         units[sc.x + k] = make_int4(r, p0, min(ch, re - p0), nu > 1 ? sc.y + k : -1);
-        keys[sc.x + k] = ((unsigned long long)(hash32((unsigned)r * 31u + (unsigned)k) & 7u) << 32) | (unsigned)col[p0];
+        keys[sc.x + k] = ((unsigned long long)(hash32((unsigned)r * 31u + (unsigned)k) & 7u) << 33) | (hub << 32) | (unsigned)col[p0];
       }
     }
   }
 }
 
 __global__ void plan_xcd(const unsigned long long *__restrict__ keys, PlanHdr *__restrict__ hdr) {
-  const int x = threadIdx.x;
-  if (x > 8) return;
+  const int t = threadIdx.x;
+  if (t > 16) return;
+  // t even: first unit of slice t / 2; t odd: first HUB-row unit of slice t / 2 (sorted behind the slice's other units)
   const int n = hdr->n_units;
-  int lo = 0, hi = n;  // first unit whose slice >= x
+  int lo = 0, hi = n;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
-    if ((keys[mid] >> 32) < (unsigned long long)x) lo = mid + 1; else hi = mid;
+    if ((keys[mid] >> 32) < (unsigned long long)t) lo = mid + 1; else hi = mid;
   }
-  hdr->xcd_start[x] = lo;
+  if (t & 1) hdr->xcd_hub[t >> 1] = lo;
+  else hdr->xcd_start[t >> 1] = lo;
 }
 
 }  // namespace dgs
@@ -339,18 +366,27 @@ extern "C" int dgs_spmm_plan_build2(int64_t M, int64_t K, int64_t nnz, const int
   unsigned long long *keys_in = reinterpret_cast<unsigned long long *>(ws + WL.off_keys_in);
   unsigned long long *keys_out = reinterpret_cast<unsigned long long *>(ws + WL.off_keys_out);
   int4 *units_in = reinterpret_cast<int4 *>(ws + WL.off_units_in);
+  unsigned *hkeys_in = reinterpret_cast<unsigned *>(ws + WL.off_hkeys_in);
+  unsigned *hkeys_out = reinterpret_cast<unsigned *>(ws + WL.off_hkeys_out);
+  int4 *hub_in = reinterpret_cast<int4 *>(ws + WL.off_hub_in);
+  int4 *hub_rows = reinterpret_cast<int4 *>(pb + PL.off_hub);
   void *tmp = ws + WL.off_tmp;
   // unit length: 256 nnz when there is plenty of work; smaller inputs get shorter units (a unit is a chain of up to
   // ch/64 dependent tiles, and a mid-size graph has too few units to hide it)
   int ch = tune(tuning().plan_ch, nnz >= (8 << 20) ? kPlanCh : (nnz >= (2 << 20) ? 128 : 64));
   ch = ch < kPlanChMin ? kPlanChMin : (ch > (1 << 20) ? (1 << 20) : ch);  // the table capacities assume ch >= kPlanChMin
   const int tslice = plan_tslice(), unit = plan_unit();
+  // hub rows (dgs_common.h Tuning::hub_chain; spmm_impl.h hub_threshold): listed longest first for the sum / mean launches
+  int thub = tune(tuning().hub_chain, kHubChain);
+  thub = thub <= 0 ? INT_MAX : (thub < kHubChainMin ? kHubChainMin : thub);
 
   if (hipMemsetAsync(hdr, 0, PL.off_units, st) != hipSuccess) return DGS_ELAUNCH;
   if (hipMemsetAsync(ws, 0, WL.off_list, st) != hipSuccess) return DGS_ELAUNCH;           // counters, cnt, cum
   if (hipMemsetAsync(rinfo, 0, (size_t)WL.cap_long * 16, st) != hipSuccess) return DGS_ELAUNCH;
   if (hipMemsetAsync(keys_in, 0xFF, (size_t)PL.max_units * 8, st) != hipSuccess) return DGS_ELAUNCH;  // unused = last
   if (hipMemsetAsync(units_in, 0, (size_t)PL.max_units * 16, st) != hipSuccess) return DGS_ELAUNCH;
+  if (hipMemsetAsync(hkeys_in, 0xFF, (size_t)PL.max_hub * 4, st) != hipSuccess) return DGS_ELAUNCH;
+  if (hipMemsetAsync(hub_in, 0, (size_t)PL.max_hub * 16, st) != hipSuccess) return DGS_ELAUNCH;
 
   size_t tb = WL.tmp_bytes;
   const int *prefix = col_prefix;
@@ -361,13 +397,17 @@ extern "C" int dgs_spmm_plan_build2(int64_t M, int64_t K, int64_t nnz, const int
     prefix = cum;
   }
   hipLaunchKernelGGL(plan_bounds, dim3(1), dim3(192), 0, st, (int)K, (int)nnz, prefix, hdr, bounds, (int)M, ch, kT1, tslice,
-                     unit);
+                     unit, thub);
   hipLaunchKernelGGL(plan_longlist, dim3((unsigned)((M + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int)M, kT1, rowptr,
                      pw, list);
   // DGS_PLAN_NOCUT (experiment): rows longer than this are chunked without column cuts (what a hub row costs when it leaves
   // the column-slice order)
-  hipLaunchKernelGGL(plan_rowunits, dim3(1024), dim3(kBlock), 0, st, ch, tslice, tune(tuning().plan_nocut, INT_MAX), unit, rowptr,
-                     col, pw, bounds, list, rinfo);
+  hipLaunchKernelGGL(plan_rowunits, dim3(1024), dim3(kBlock), 0, st, ch, tslice, tune(tuning().plan_nocut, INT_MAX), unit, thub,
+                     (int)PL.max_hub, rowptr, col, pw, bounds, list, rinfo, hkeys_in, hub_in);
+  tb = WL.tmp_bytes;
+  if (rocprim::radix_sort_pairs(tmp, tb, hkeys_in, hkeys_out, hub_in, hub_rows, (size_t)PL.max_hub, 0, 32, st, false) !=
+      hipSuccess)
+    return DGS_ELAUNCH;
   tb = WL.tmp_bytes;
   if (rocprim::exclusive_scan(tmp, tb, rinfo, rscan, make_int4(0, 0, 0, 0), (size_t)WL.cap_long, I4Plus(), st, false) !=
       hipSuccess)
@@ -376,7 +416,7 @@ extern "C" int dgs_spmm_plan_build2(int64_t M, int64_t K, int64_t nnz, const int
   hipLaunchKernelGGL(plan_emit, dim3(1024), dim3(kBlock), 0, st, ch, rowptr, col, pw, bounds, list, rinfo, rscan, units_in,
                      keys_in, longrows);
   tb = WL.tmp_bytes;
-  if (rocprim::radix_sort_pairs(tmp, tb, keys_in, keys_out, units_in, units, (size_t)PL.max_units, 0, 36, st, false) !=
+  if (rocprim::radix_sort_pairs(tmp, tb, keys_in, keys_out, units_in, units, (size_t)PL.max_units, 0, 37, st, false) !=
       hipSuccess)
     return DGS_ELAUNCH;
   hipLaunchKernelGGL(plan_xcd, dim3(1), dim3(64), 0, st, keys_out, hdr);
@@ -388,10 +428,10 @@ extern "C" int dgs_spmm_plan_build2(int64_t M, int64_t K, int64_t nnz, const int
     info->n_units = h.n_units;
     info->n_long = h.n_long;
     info->n_pslots = h.n_pslots;
-    info->has_pcol = 0;
+    info->n_hub = h.n_hub;
     info->tslice = h.tslice;
     info->off_long = 0;
-    info->reserved = 0;
+    info->off_hub = 0;
     for (int x = 0; x < 9; x++) info->xcd_start[x] = h.xcd_start[x];
   }
   return DGS_OK;
@@ -408,10 +448,10 @@ extern "C" int dgs_spmm_plan_info_from_header(const void *host_header, size_t by
   info->n_units = h.n_units;
   info->n_long = h.n_long;
   info->n_pslots = h.n_pslots;
-  info->has_pcol = 0;
+  info->n_hub = h.n_hub;
   info->tslice = h.tslice;
   info->off_long = 0;
-  info->reserved = 0;
+  info->off_hub = 0;
   for (int x = 0; x < 9; x++) info->xcd_start[x] = h.xcd_start[x];
   return DGS_OK;
 }
@@ -442,6 +482,13 @@ extern "C" int dgs_spmm_plan_provisional_info(int64_t nnz, int64_t rows_gt_t1, i
   info->n_pslots = (int32_t)units;
   info->tslice = plan_tslice();
   info->off_long = 0;  // the build-time layout
+  {  // hub rows: at most every row longer than tslice, and no more than fit nnz (a bound: it only sizes the hub grid)
+    int thub = tune(tuning().hub_chain, kHubChain);
+    thub = thub <= 0 ? INT_MAX : (thub < kHubChainMin ? kHubChainMin : thub);
+    const int64_t hb = thub == INT_MAX ? 0 : (rows_gt_tslice < nnz_gt_tslice / thub ? rows_gt_tslice : nnz_gt_tslice / thub);
+    info->n_hub = (int32_t)(hb < PL.max_hub ? hb : PL.max_hub);
+  }
+  info->off_hub = 0;
   return DGS_OK;
 }
 
@@ -454,12 +501,13 @@ extern "C" size_t dgs_spmm_csr_plan_workspace_bytes(int reduce_op, int64_t M, in
 extern "C" size_t dgs_spmm_plan_compact_bytes(const dgsSpmmPlanInfo *info) {
   if (!info) return 0;
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
-  return 256 + 768 + up((size_t)info->n_units * sizeof(int4)) + up((size_t)info->n_long * sizeof(int4)) + 256;
+  return 256 + 768 + up((size_t)info->n_units * sizeof(int4)) + up((size_t)info->n_long * sizeof(int4)) +
+         up((size_t)info->n_hub * sizeof(int4)) + 256;
 }
 
 extern "C" int dgs_spmm_plan_compact(const void *plan, dgsSpmmPlanInfo *info, void *compact, size_t compact_bytes,
                                      int64_t nnz, dgsStream_t stream) {
-  if (!plan || !info || !compact || nnz <= 0 || info->off_long != 0) return DGS_EINVAL;
+  if (!plan || !info || !compact || nnz <= 0 || info->off_long != 0 || info->off_hub != 0 || info->n_hub < 0) return DGS_EINVAL;
   if (compact_bytes < dgs_spmm_plan_compact_bytes(info)) return DGS_EWORKSPACE;
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
   const PlanLayout PL = plan_layout(nnz);
@@ -467,11 +515,14 @@ extern "C" int dgs_spmm_plan_compact(const void *plan, dgsSpmmPlanInfo *info, vo
   const char *src = static_cast<const char *>(plan);
   char *dst = static_cast<char *>(compact);
   const size_t ub = (size_t)info->n_units * sizeof(int4), lb = (size_t)info->n_long * sizeof(int4);
-  const size_t off_long = PL.off_units + up(ub);
-  if (off_long > (size_t)INT32_MAX) return DGS_ERANGE;  // info->off_long is 32-bit (2^27 units: beyond any int32 nnz / 64)
+  const size_t hb = (size_t)info->n_hub * sizeof(int4);
+  const size_t off_long = PL.off_units + up(ub), off_hub = off_long + up(lb);
+  if (off_hub + up(hb) > (size_t)INT32_MAX) return DGS_ERANGE;  // the offsets are 32-bit (2^27 units: beyond any int32 nnz / 64)
   if (hipMemcpyAsync(dst, src, PL.off_units + ub, hipMemcpyDeviceToDevice, st) != hipSuccess) return DGS_ELAUNCH;
   if (lb && hipMemcpyAsync(dst + off_long, src + PL.off_long, lb, hipMemcpyDeviceToDevice, st) != hipSuccess)
     return DGS_ELAUNCH;
+  if (hb && hipMemcpyAsync(dst + off_hub, src + PL.off_hub, hb, hipMemcpyDeviceToDevice, st) != hipSuccess) return DGS_ELAUNCH;
   info->off_long = (int32_t)off_long;
+  info->off_hub = (int32_t)off_hub;
   return DGS_OK;
 }

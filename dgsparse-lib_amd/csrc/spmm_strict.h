@@ -47,35 +47,12 @@ struct StrictLds {
   alignas(16) float f[kStrictBlockFloats];
   __device__ float *wave_region(int wave) { return f + wave * kStrictWaveFloats; }
 };
-// Hub rows are taken longest first (a 50 k-nnz row is the critical path of the whole call): class c holds the rows with
-// kStrictHub << c < nnz <= kStrictHub << (c + 1) (the last class: everything longer), each class has its own region of the
-// unit table behind the front entries, sized for the worst case, and the unit waves walk class 5, 4, ... 0, then the front.
-constexpr int kHubClasses = 6;
-struct HubTab {
-  int base[kHubClasses];  // first table entry of each class region
-  int mid_top;            // the 4-slice units grow down from here (the whole-tile units grow up from entry 0)
-};
-static inline HubTab hub_tab(int64_t nnz, int shub, int thub) {
-  HubTab t;
-  int64_t o = nnz / kT1 + 2;
-  t.mid_top = (int)o;
-  for (int c = 0; c < kHubClasses; c++) {
-    t.base[c] = (int)o;
-    o += (int64_t)shub * (nnz / ((int64_t)thub << c)) + 16;
-  }
-  return t;
-}
-__host__ __device__ __forceinline__ int hub_class(int len, int thub) {
-  int c = 0;
-  while (c < kHubClasses - 1 && len > (thub << (c + 1))) c++;
-  return c;
-}
-
+// (HubTab / hub_tab / hub_class / HubArg: spmm_impl.h, next to the classify pass that fills the tables)
 constexpr int strict_smid(int G) { return G < 4 ? G : 4; }
-// hub rows: feature tiles of >= 32 floats with 16-byte lanes are cut into 4 slices (2 for a 32-float tile), each worked by a whole workgroup
+// hub rows: feature tiles of >= 16 floats with 16-byte lanes are cut into slices of >= 16 floats (4 slices from 64 floats on), each worked by a whole workgroup
 // (strict_hub_coop: four waves gather, one chains); narrower tiles into up to 16 wave-level slices
-constexpr bool strict_coop(int G, int V) { return V == 4 && G >= 8; }
-constexpr int strict_shub(int G, int V) { return strict_coop(G, V) ? (G >= 16 ? 4 : 2) : (G < 16 ? G : 16); }
+constexpr bool strict_coop(int G, int V) { return V == 4 && G >= 4; }
+constexpr int strict_shub(int G, int V) { return strict_coop(G, V) ? (G >= 16 ? 4 : G / 4) : (G < 16 ? G : 16); }
 
 // One wave, one feature slice [fbase, fbase + GP*V) of one row [p0, p0+len): returns the chain results in the CHAIN
 // layout: lane c < CL holds features fbase + c*VP .. + VP-1 (VP = 1 unless the slice is wider than 64 floats).
@@ -200,7 +177,7 @@ template <int V, int GP, bool MEAN, bool HAS_VAL, bool FMA>
 __device__ __forceinline__ void strict_unit(const int row, const int p0, const int len, const int tbase, const int sl,
                                             const int lane, const int N, const int *__restrict__ col,
                                             const float *__restrict__ val, const float *__restrict__ B,
-                                            float *__restrict__ C, float *xb) {
+                                            float *__restrict__ C, float *xb, const Epi &epi = Epi{}) {
   constexpr int W = GP * V, VP = W > 64 ? W / 64 : 1, CL = W / VP;
   const int fbase = tbase + sl * W;
   float acc[VP];
@@ -212,6 +189,7 @@ __device__ __forceinline__ void strict_unit(const int row, const int p0, const i
 #pragma unroll
       for (int v = 0; v < VP; v++) acc[v] /= d;
     }
+    epi_apply<VP>(acc, row, f, epi);
     store_vec_stream<VP>(C + (int64_t)row * N + f, acc);
   }
 }
@@ -232,17 +210,20 @@ __device__ __forceinline__ void strict_unit(const int row, const int p0, const i
 // of the current one (the prefetch sat in a conditional block, so the merged wait count was the worst case of both paths):
 // ~11 clocks per link.  The window below is straight-line - every read is issued, its index clamped into the tile - and
 // rolls four b128 pairs (16 links) ahead of the fmas.
-template <int GP, bool MEAN, bool HAS_VAL, bool FMA>
+constexpr int kHubBlockFloats = 7008;  // what strict_hub_coop needs at most (16 x 388 + 2 x 384 + 16): 28 KB, 5 workgroups per CU
+template <int GP, bool MEAN, bool HAS_VAL, bool FMA, int LDSF = kStrictBlockFloats>
 __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, const int len, const int tbase, const int sl,
                                                 const int N, const int *__restrict__ col, const float *__restrict__ val,
-                                                const float *__restrict__ B, float *__restrict__ C, float *lds) {
+                                                const float *__restrict__ B, float *__restrict__ C, float *lds,
+                                                const Epi &epi = Epi{}) {
   constexpr int V = 4, NWG = kBlock / kWave - 1;  // gather waves (wave 0 chains and does nothing else)
   constexpr int NGP = kWave / GP, W = GP * V;   // nnz per load instruction; floats (= chain lanes) of the slice
   constexpr int NWV = kUS * NGP;                // nnz per gather wave and phase
   constexpr int NRB = NWG * NWV;                // nnz per workgroup phase
   constexpr int LD = NRB + 4;                   // row pitch of the feature-major tile: conflict-free ds_read_b128 across lanes
-  static_assert(W * LD + NRB <= kStrictBlockFloats && W <= kWave && NRB % 16 == 0, "strict_hub_coop LDS");
-  float *xt = lds, *wt = lds + W * LD;
+  static_assert(W * LD + 2 * NRB + 16 <= LDSF && W <= kWave && NRB % 16 == 0, "strict_hub_coop LDS");
+  float *xt = lds, *wt = lds + W * LD;             // gathered rows (feature-major), weights of the phase being chained
+  int *ct = reinterpret_cast<int *>(wt + NRB);     // columns of the phase whose gathers are issued next
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int fbase = tbase + sl * W;
   const int nph = (len + NRB - 1) / NRB;
@@ -256,6 +237,10 @@ __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, con
     const float4 *wt4 = reinterpret_cast<const float4 *>(__builtin_assume_aligned(wt, 16));
     // the chain is the critical path of the whole call and a dependent sequence: give it the SIMD's issue slots ahead of the
     // waves that share them (DGS_STRICT_PRIO=0 builds measure the difference)
+    __syncthreads();  // P1 .. P4: the gather waves' prologue (column tiles of phases 0 and 1)
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
     if (DGS_STRICT_PRIO) __builtin_amdgcn_s_setprio(3);
     for (int ph = 0; ph < nph; ph++) {
       const int cnt = min(NRB, len - ph * NRB);
@@ -265,7 +250,7 @@ __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, con
       // sched_barriers pin reads and fmas where they are written - left alone, hipcc gathers the reads at the loop top and
       // waits for all of them before the first fma
       constexpr int P = 4;
-      static_assert(W * LD + NRB + 4 * P <= kStrictBlockFloats, "chain window over-read");
+      static_assert(4 * P <= NRB, "chain window over-read");  // (past the weights: the column tile; past a feature row: the next one)
       const int nq = cnt >> 2;  // whole quads of this phase
       float4 xq[P], wq[P];
 #pragma unroll
@@ -295,6 +280,7 @@ __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, con
     if (lane < W && fbase + lane < N) {
       if constexpr (MEAN) acc /= (float)len;
       float o[1] = {acc};
+      epi_apply<1>(o, row, fbase + lane, epi);
       store_vec_stream<1>(C + (int64_t)row * N + fbase + lane, o);
     }
     return;
@@ -303,125 +289,171 @@ __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, con
   const int f0 = fbase + lp * V;
   const float *Bl = B + (f0 < N ? f0 : 0);
   const int mine = (wave - 1) * NWV + gp;  // this lane's nnz of gather q inside a phase: mine + q * NGP
+  const int gt = (wave - 1) * kWave + lane;  // gather-thread index: the (col, val) stream of a phase is loaded coalesced,
+  constexpr int NGT = NWG * kWave;           // CPT entries per gather thread, and handed round through LDS (ct / wt)
+  constexpr int CPT = (NRB + NGT - 1) / NGT;
+  constexpr bool CFULL = NRB % NGT == 0;     // (256-float tiles: 96 nnz per phase, half of the gather threads carry an entry)
   float xa[kUS][V], xb[kUS][V];  // the two gather sets (even / odd phases)
-  int ce[kUS], co[kUS];          // columns of the next gathers of the even / odd set
-  float wn[kUS];                 // weights of the phase written NEXT
+  int cv[CPT];                   // columns of the phase whose gathers are issued NEXT (two phases ahead of the chain)
+  float wv[CPT];                 // weights of the phase written NEXT
   // slots past the end of the row repeat its last nnz (never chained)
-  auto load_cols = [&](int ph, int (&c)[kUS]) {
+  auto load_cols = [&](int ph) {
 #pragma unroll
-    for (int q = 0; q < kUS; q++) c[q] = ld_stream(col + p0 + min(ph * NRB + mine + q * NGP, len - 1));
+    for (int k = 0; k < CPT; k++) cv[k] = ld_stream(col + p0 + min(ph * NRB + min(k * NGT + gt, NRB - 1), len - 1));
   };
   auto load_w = [&](int ph) {
 #pragma unroll
-    for (int q = 0; q < kUS; q++) wn[q] = HAS_VAL ? ld_stream(val + p0 + min(ph * NRB + mine + q * NGP, len - 1)) : 1.0f;
+    for (int k = 0; k < CPT; k++) wv[k] = HAS_VAL ? ld_stream(val + p0 + min(ph * NRB + min(k * NGT + gt, NRB - 1), len - 1)) : 1.0f;
   };
-  auto issue = [&](float (&x)[kUS][V], const int (&c)[kUS]) {
+  auto put_cols = [&]() {
+#pragma unroll
+    for (int k = 0; k < CPT; k++)
+      if (CFULL || k * NGT + gt < NRB) ct[k * NGT + gt] = cv[k];
+  };
+  auto issue = [&](float (&x)[kUS][V]) {
+    int c[kUS];
+#pragma unroll
+    for (int q = 0; q < kUS; q++) c[q] = ct[mine + q * NGP];
 #pragma unroll
     for (int q = 0; q < kUS; q++) load_vec_gather<V>(Bl + (int64_t)c[q] * N, x[q]);
   };
   // Loads return in order, so whatever a phase waits for must be OLDER than the gathers it wants to keep in flight: the
-  // columns (and weights) a phase needs were requested one phase earlier, BEFORE that phase's gathers.
-  auto phase = [&](const int ph, float (&x)[kUS][V], const int (&cuse)[kUS], int (&cload)[kUS]) {
+  // (col, val) entries a phase needs were requested one phase earlier, BEFORE that phase's gathers.
+  auto phase = [&](const int ph, float (&x)[kUS][V]) {
 #pragma unroll
     for (int q = 0; q < kUS; q++) {
       const int i = mine + q * NGP;
 #pragma unroll
       for (int v = 0; v < V; v++) xt[(lp * V + v) * LD + i] = x[q][v];
-      if (HAS_VAL && lp == 0) wt[i] = wn[q];
     }
-    __syncthreads();  // A: the tile of phase ph is complete
-    load_cols(ph + 3, cload);
+    if constexpr (HAS_VAL) {
+#pragma unroll
+      for (int k = 0; k < CPT; k++)
+        if (CFULL || k * NGT + gt < NRB) wt[k * NGT + gt] = wv[k];
+    }
+    put_cols();       // columns of phase ph + 2
+    __syncthreads();  // A: the tile of phase ph is complete (and so is the column tile the gathers below read)
+    load_cols(ph + 3);
     load_w(ph + 1);
     __builtin_amdgcn_sched_barrier(0);
-    issue(x, cuse);   // this set's next gathers (phase ph + 2) fly under two chains
-    __syncthreads();  // B: the chain has left the tile
+    issue(x);         // this set's next gathers (phase ph + 2) fly under two chains
+    __syncthreads();  // B: the chain has left the tile, every wave has read its columns
   };
-  load_cols(0, ce);
-  load_cols(1, co);
+  // prologue: gathers of phases 0 and 1 (their columns go through the tile like everybody's), (col, val) of what follows
+  // (four extra barriers per row, matched by the chain wave: the column tile is written by all gather threads and read by all)
+  load_cols(0);
   load_w(0);
+  put_cols();
+  __syncthreads();  // P1: columns of phase 0 in the tile
+  issue(xa);
   __builtin_amdgcn_sched_barrier(0);
-  issue(xa, ce);
-  __builtin_amdgcn_sched_barrier(0);  // (hipcc issued set b first: set a's writes then waited for everything)
-  issue(xb, co);
+  load_cols(1);
+  __syncthreads();  // P2: everybody has read them
+  put_cols();
+  __syncthreads();  // P3: columns of phase 1 in the tile
+  load_cols(2);     // (before the gathers: the wait for them at phase 0 must not cover set b - loads return in order)
   __builtin_amdgcn_sched_barrier(0);
-  load_cols(2, ce);
+  issue(xb);
+  __syncthreads();  // P4: ... and read (phase 0 overwrites them with those of phase 2)
   // (an odd last phase is peeled: with `if (ph + 1 < nph)` inside the loop the CFG has a path from one even phase straight into
   // the next, on which set a's gathers are the youngest loads, and hipcc's merged wait at the loop header drains everything)
   int ph = 0;
   for (; ph + 1 < nph; ph += 2) {
-    phase(ph, xa, ce, co);
-    phase(ph + 1, xb, co, ce);
+    phase(ph, xa);
+    phase(ph + 1, xb);
   }
-  if (ph < nph) phase(ph, xa, ce, co);
+  if (ph < nph) phase(ph, xa);
+}
+
+// Work deal shared by the strict unit blocks and the hub blocks of the default launch.  One segment = `ngroups` groups of gs
+// tasks (a row's feature slices); group g belongs to XCD g % nx, and the worker (a wave, or a whole workgroup for cooperative
+// hub tasks) that is slot `slot` of `nslots` on XCD x takes every nslots-th task of that XCD's groups.  `rot` carries the deal
+// round-robin from one segment to the next.  All slices of a row read the SAME rows of the dense operand, so they must share
+// an L2: a row's group of slices goes to ONE XCD (block b runs on XCD b % 8 - observed placement, a speed hint only) and to
+// neighbouring workers of it, which run in step.  (First version: slices dealt round-robin over all waves = over all 8 XCDs -
+// every line of a hub row was fetched from memory 8 times, 7.8 GB per call on the headline graph, and the call took 1.4 ms.)
+template <typename F>
+__device__ __forceinline__ void strict_deal(int ngroups, int gs, int x, int nx, int slot, int nslots, int &rot, F &&fn) {
+  const int gx = ngroups > x ? (ngroups - x + nx - 1) / nx : 0;  // groups of this XCD: x, x + nx, ...
+  const int ux = gx * gs;
+  int u = slot - rot;
+  if (u < 0) u += nslots;
+  for (; u < ux; u += nslots) fn(x + nx * (u / gs), u % gs);
+  rot = (rot + ux) % nslots;
+}
+
+// Hub rows (longer than the hub threshold): every one a sequential chain per feature, longest class first.  Used by the strict
+// launch (all rows > kStrictHub) and by the DEFAULT sum / mean launches for the rows above the hub-chain threshold - the rows
+// whose fixed-tree sum can be more than 1e-5 away from the reference's own sequential result.  Returns the
+// wave-slot rotation the caller's following segments continue from.
+template <int G, int V, bool MEAN, bool HAS_VAL, bool FMA, int LDSF = kStrictBlockFloats>
+__device__ __forceinline__ int spmm_hub_body(int bid, int nblocks, float *ldsf, int N, const int *__restrict__ col,
+                                             const float *__restrict__ val, const float *__restrict__ B,
+                                             float *__restrict__ C, const HubArg &ha, const Epi &epi = Epi{}) {
+  constexpr int SH = strict_shub(G, V);
+  constexpr bool COOP = strict_coop(G, V);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tbase = blockIdx.y * G * V;
+  const int nx = (nblocks & 7) == 0 ? 8 : 1;  // XCDs the mapping distinguishes
+  const int x = bid % nx;
+  const int SP = (nblocks / nx) * (kBlock / kWave);  // wave slots of this XCD
+  int rot = 0;
+  if constexpr (COOP) {
+    const int sb = bid / nx, SPB = nblocks / nx;  // workgroup slots of this XCD
+    int rotb = 0;
+    for (int c = ha.ncls - 1; c >= 0; c--)
+      strict_deal(ha.cnt[c], SH, x, nx, sb, SPB, rotb, [&](int g, int j) {
+        const int4 d = ha.rows[ha.ht.base[c] + g];
+        strict_hub_coop<G / SH, MEAN, HAS_VAL, FMA, LDSF>(d.x, d.y, d.z, tbase, j, N, col, val, B, C, ldsf, epi);
+      });
+    __syncthreads();  // the last chain has left the LDS before the waves reuse it one by one
+    rot = (rotb * (kBlock / kWave)) % SP;
+  } else {
+    static_assert(LDSF >= (kBlock / kWave) * kStrictWaveFloats, "wave-level hub slices need the strict kernel's LDS");
+    const int s = (bid / nx) * (kBlock / kWave) + wave;
+    float *xb = ldsf + wave * kStrictWaveFloats;
+    for (int c = ha.ncls - 1; c >= 0; c--)
+      strict_deal(ha.cnt[c], SH, x, nx, s, SP, rot, [&](int g, int j) {
+        const int4 d = ha.rows[ha.ht.base[c] + g];
+        strict_unit<V, G / SH, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, j, lane, N, col, val, B, C, xb, epi);
+      });
+  }
+  return rot;
 }
 
 // Unit blocks of the strict fused launch.  Order of work: hub classes longest first, then the 4-slice units, then the
-// whole-tile ones.  All slices of a row read the SAME rows of the dense operand, so they must share an L2: a row's group
-// of slices goes to ONE XCD (block b runs on XCD b % 8 - observed placement, a speed hint only) and to neighbouring waves
-// of it, which run in step.  (First version: slices dealt round-robin over all waves = over all 8 XCDs - every line of a hub
-// row was fetched from memory 8 times, 7.8 GB per call on the headline graph, and the call took 1.4 ms.)
+// whole-tile ones.
 template <int G, int V, bool MEAN, bool HAS_VAL, bool FMA>
 __device__ __forceinline__ void spmm_units_strict_body(int bid, int nblocks, StrictLds &lds, int N,
                                                        const int *__restrict__ col, const float *__restrict__ val,
                                                        const float *__restrict__ B, float *__restrict__ C,
                                                        const SpmmWs *__restrict__ hdr, const int4 *__restrict__ units,
                                                        const HubTab ht) {
-  constexpr int SM = strict_smid(G), SH = strict_shub(G, V);
-  constexpr bool COOP = strict_coop(G, V);
+  constexpr int SM = strict_smid(G);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float *xb = lds.wave_region(wave);
   const int tbase = blockIdx.y * G * V;
-  const int nx = (nblocks & 7) == 0 ? 8 : 1;  // XCDs the mapping distinguishes
+  const int nx = (nblocks & 7) == 0 ? 8 : 1;
   const int x = bid % nx;
-  auto run = [&](const int4 d) {  // wave-level unit {row, first nnz, nnz, slice | slices << 8}
-    const int S = d.w >> 8, sl = d.w & 255;
-    if (S == 1) strict_unit<V, G, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, sl, lane, N, col, val, B, C, xb);
-    if constexpr (SM > 1) {
-      if (S == SM && S != 1) strict_unit<V, G / SM, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, sl, lane, N, col, val, B, C, xb);
-    }
-    if constexpr (!COOP && SH > SM) {
-      if (S == SH) strict_unit<V, G / SH, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, sl, lane, N, col, val, B, C, xb);
-    }
-  };
-  // one segment: `cnt` units in groups of gs (a row's slices), group g at table entries first(g) .. first(g) + gs - 1; the
-  // worker (a wave, or a whole workgroup for cooperative hub units) is slot `slot` of `nslots` on its XCD
-  auto segment = [&](int cnt, int gs, int base, bool down, int slot, int nslots, int &rot, auto &&fn) {
-    const int ngroups = cnt / gs;
-    const int gx = ngroups > x ? (ngroups - x + nx - 1) / nx : 0;  // groups of this XCD: x, x + nx, ...
-    const int ux = gx * gs;
-    int u = slot - rot;
-    if (u < 0) u += nslots;
-    for (; u < ux; u += nslots) {
-      const int g = x + nx * (u / gs), j = u % gs;
-      fn(units[(down ? base - (g + 1) * gs : base + g * gs) + j]);
-    }
-    rot = (rot + ux) % nslots;
-  };
   const int s = (bid / nx) * (kBlock / kWave) + wave, SP = (nblocks / nx) * (kBlock / kWave);  // wave slots of this XCD
-  int rot = 0;  // slots used up by earlier segments (keeps the deal round-robin across segments)
-  if constexpr (COOP) {
-    const int sb = bid / nx, SPB = nblocks / nx;  // workgroup slots of this XCD
-    int rotb = 0;
-    auto coop = [&](const int4 d) {
-      strict_hub_coop<G / SH, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, d.w & 255, N, col, val, B, C, lds.f);
-    };
-#pragma unroll
-    for (int c = kHubClasses - 1; c >= 0; c--) segment(hdr->hub[c], SH, ht.base[c], false, sb, SPB, rotb, coop);
-    __syncthreads();  // the last chain has left the LDS before the waves reuse it one by one
-    rot = (rotb * (kBlock / kWave)) % SP;
-  } else {
-#pragma unroll
-    for (int c = kHubClasses - 1; c >= 0; c--) segment(hdr->hub[c], SH, ht.base[c], false, s, SP, rot, run);
-  }
-  segment(hdr->n_pslots, SM, ht.mid_top, true, s, SP, rot, run);
-  segment(hdr->n_units, 1, 0, false, s, SP, rot, run);
+  int rot = spmm_hub_body<G, V, MEAN, HAS_VAL, FMA>(bid, nblocks, lds.f, N, col, val, B, C, HubArg{hdr->hub, units, ht, kHubClasses});
+  // 4-slice units {row, first nnz, nnz, -}: SM entries' worth of work per row, table grows down from mid_top
+  if constexpr (SM > 1)
+    strict_deal(hdr->n_pslots, SM, x, nx, s, SP, rot, [&](int g, int j) {
+      const int4 d = units[ht.mid_top - 1 - g];
+      strict_unit<V, G / SM, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, j, lane, N, col, val, B, C, xb);
+    });
+  strict_deal(hdr->n_units, 1, x, nx, s, SP, rot, [&](int g, int) {
+    const int4 d = units[g];
+    strict_unit<V, G, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, 0, lane, N, col, val, B, C, xb);
+  });
 }
 
-// Unit table of the strict schedule.  Whole-tile units grow up from entry 0 and 4-slice units down from mid_top (together
-// at most nnz / T1 entries); same structure as spmm_classify (a block owns 4096 consecutive rows, per-thread counts -> block
+// Unit table of the strict schedule: one entry {row, first nnz, nnz, -} per row longer than T1.  Whole-tile rows grow up from
+// entry 0 and the rows worked as 4 feature slices down from mid_top (together at most nnz / T1 entries); same structure as spmm_classify (a block owns 4096 consecutive rows, per-thread counts -> block
 // scan -> ONE atomicAdd per block and kind).  Hub rows are rare (hundreds in a million rows): one atomicAdd per row on the
 // counter of its length class.
-static __global__ __launch_bounds__(kBlock) void spmm_classify_strict(int M, int t1, int tmid, int thub, int smid, int shub,
+static __global__ __launch_bounds__(kBlock) void spmm_classify_strict(int M, int t1, int tmid, int thub,
                                                                       const HubTab ht, const int *__restrict__ rowptr,
                                                                       SpmmWs *__restrict__ hdr, int4 *__restrict__ units) {
   __shared__ int s_f[kBlock / kWave], s_m[kBlock / kWave];
@@ -437,7 +469,7 @@ static __global__ __launch_bounds__(kBlock) void spmm_classify_strict(int M, int
       const int len = rowptr[r + 1] - rowptr[r];
       if (len > t1) {
         if (len <= tmid) fm++;
-        else if (len <= thub) mm += smid;
+        else if (len <= thub) mm++;
         mask |= 1u << i;
       }
     }
@@ -481,14 +513,11 @@ static __global__ __launch_bounds__(kBlock) void spmm_classify_strict(int M, int
     const int rs = rowptr[r], len = rowptr[r + 1] - rs;
     if (len > thub) {
       const int c = hub_class(len, thub);
-      const int o = ht.base[c] + atomicAdd(&hdr->hub[c], shub);
-      for (int s = 0; s < shub; s++) units[o + s] = make_int4(r, rs, len, s | (shub << 8));
+      units[ht.base[c] + atomicAdd(&hdr->hub[c], 1)] = make_int4(r, rs, len, 0);
     } else if (len > tmid) {
-      const int o = ht.mid_top - moff - smid;
-      for (int s = 0; s < smid; s++) units[o + s] = make_int4(r, rs, len, s | (smid << 8));
-      moff += smid;
+      units[ht.mid_top - 1 - moff++] = make_int4(r, rs, len, 0);
     } else {
-      units[foff++] = make_int4(r, rs, len, 1 << 8);
+      units[foff++] = make_int4(r, rs, len, 0);
     }
   }
 }

@@ -114,6 +114,8 @@ extern "C" int dgs_spmm_csr_ex_f32(int reduce_op, int64_t M, int64_t K, int64_t 
     a.plan_long = info->n_long;
     a.plan_pslots = info->n_pslots;
     a.plan_off_long = info->off_long;
+    a.plan_hub = info->n_hub;
+    a.plan_off_hub = info->off_hub;
   }
   return run(fm, a);
 }
@@ -145,6 +147,8 @@ extern "C" int dgs_spmm_csr_plan_f32(int reduce_op, int64_t M, int64_t K, int64_
   a.plan_long = info->n_long;
   a.plan_pslots = info->n_pslots;
   a.plan_off_long = info->off_long;
+  a.plan_hub = info->n_hub;
+  a.plan_off_hub = info->off_hub;
   return run(fm, a);
 }
 
@@ -174,6 +178,8 @@ extern "C" int dgs_spmm_csr_acc_f32(int64_t M, int64_t K, int64_t N, int64_t nnz
     a.plan_long = info->n_long;
     a.plan_pslots = info->n_pslots;
     a.plan_off_long = info->off_long;
+    a.plan_hub = info->n_hub;
+    a.plan_off_hub = info->off_hub;
   }
   return run(fm, a);
 }
@@ -206,6 +212,8 @@ extern "C" int dgs_spmm_csr_acc_max_f32(int64_t M, int64_t K, int64_t N, int64_t
     a.plan_long = info->n_long;
     a.plan_pslots = info->n_pslots;
     a.plan_off_long = info->off_long;
+    a.plan_hub = info->n_hub;
+    a.plan_off_hub = info->off_hub;
   }
   return run(fm, a);
 }
@@ -238,6 +246,8 @@ extern "C" int dgs_spmm_csr_acc_min_f32(int64_t M, int64_t K, int64_t N, int64_t
     a.plan_long = info->n_long;
     a.plan_pslots = info->n_pslots;
     a.plan_off_long = info->off_long;
+    a.plan_hub = info->n_hub;
+    a.plan_off_hub = info->off_hub;
   }
   return run(fm, a);
 }

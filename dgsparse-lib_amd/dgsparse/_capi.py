@@ -45,8 +45,8 @@ _lib.dgs_spmm_csr_f32.argtypes = [_int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _
 class PlanInfo(ctypes.Structure):
     """dgsSpmmPlanInfo (include/dgsparse_hip.h)."""
     _fields_ = [('n_units', ctypes.c_int32), ('n_long', ctypes.c_int32), ('n_pslots', ctypes.c_int32),
-                ('has_pcol', ctypes.c_int32), ('tslice', ctypes.c_int32), ('xcd_start', ctypes.c_int32 * 9),
-                ('off_long', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+                ('n_hub', ctypes.c_int32), ('tslice', ctypes.c_int32), ('xcd_start', ctypes.c_int32 * 9),
+                ('off_long', ctypes.c_int32), ('off_hub', ctypes.c_int32)]
 
 
 _lib.dgs_spmm_plan_bytes.restype = _sz

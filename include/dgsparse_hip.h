@@ -113,11 +113,11 @@ typedef struct dgsSpmmPlanInfo {
   int32_t n_units;      /* entries of the unit table */
   int32_t n_long;       /* multi-unit rows */
   int32_t n_pslots;     /* partial rows a call needs in its workspace */
-  int32_t has_pcol;     /* reserved (0) */
+  int32_t n_hub;        /* hub rows (longer than DGS_HUB_CHAIN = 8192 nnz): sum / mean chain them whole, see dgs_spmm_csr_f32 */
   int32_t tslice;       /* rows longer than this were cut at column-slice boundaries */
   int32_t xcd_start[9]; /* first unit of each XCD's share */
   int32_t off_long;     /* byte offset of the long-row table inside the plan buffer; 0 = the build-time layout */
-  int32_t reserved;
+  int32_t off_hub;      /* ... of the hub-row table */
 } dgsSpmmPlanInfo;
 size_t dgs_spmm_plan_bytes(int64_t M, int64_t K, int64_t nnz);
 size_t dgs_spmm_plan_workspace_bytes(int64_t M, int64_t K, int64_t nnz);
