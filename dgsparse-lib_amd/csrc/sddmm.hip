@@ -460,7 +460,10 @@ extern "C" int dgs_sddmm_csr_plan_f32(int reduce_op, int64_t M, int64_t K, int64
     // units per nnz) 2232 -> 2280 us, so that one stays on the nnz-balanced kernel.  DGS_SDDMM_FUSED=0/1 overrides.
     const int force = tune(tuning().sddmm_fused, -1);
     fused = fm.tiles == 1 && fm.V == 4 && fm.G >= 8 && !sd_panel_plan(M, K, F, nnz, fm.tiles, fm.G, fm.V, false).use &&
-            force != 0 && (force == 1 || (int64_t)info->n_pslots * 256 >= nnz);
+            force != 0 && (force == 1 || ((int64_t)info->n_pslots * 256 >= nnz && info->xcd_start[8] > 0));
+    // (xcd_start[8] = the real unit count; a PROVISIONAL info (dgs_spmm_plan_provisional_info: upper bounds, zeros here) must
+    // not decide - its n_pslots bounds every unit, the rule would pick this kernel where the real counts reject it, and the
+    // value-gradient bits of a caller would change once more when the compact plan arrives.  ADVICE r3.)
     if (fused) {
       const PlanHdr *ph = static_cast<const PlanHdr *>(plan);
       const bool mean = reduce_op == DGS_MEAN;

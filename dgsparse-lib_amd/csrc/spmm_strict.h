@@ -373,7 +373,7 @@ __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, con
 // neighbouring workers of it, which run in step.  (First version: slices dealt round-robin over all waves = over all 8 XCDs -
 // every line of a hub row was fetched from memory 8 times, 7.8 GB per call on the headline graph, and the call took 1.4 ms.)
 template <typename F>
-__device__ __forceinline__ void strict_deal(int ngroups, int gs, int x, int nx, int slot, int nslots, int &rot, F &&fn) {
+__host__ __device__ __forceinline__ void strict_deal(int ngroups, int gs, int x, int nx, int slot, int nslots, int &rot, F &&fn) {
   const int gx = ngroups > x ? (ngroups - x + nx - 1) / nx : 0;  // groups of this XCD: x, x + nx, ...
   const int ux = gx * gs;
   int u = slot - rot;

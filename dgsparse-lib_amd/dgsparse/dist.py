@@ -456,14 +456,23 @@ class DistSpMM:
             # it and the higher-rank ones BEHIND it (MIN keeps the later operand's bits on a tie, so only in-order folds
             # are exact; two accumulating launches).  MIN cannot be folded across a NaN product at all, so features and
             # edge values are scanned for NaN / inf on the way (stream-ordered flag, no host sync) and the rows that have
-            # remote entries are recomputed sequentially when the flag is up
+            # remote entries are recomputed sequentially when the flag is up.  Cost of that guard: one scan of the local
+            # features (under the exchange), one of the arrived halo, one of a caller-supplied ``val`` (the engine's own edge
+            # values are scanned once and the verdict kept: they never change); a single infinity anywhere - a false alarm,
+            # inf * 0 is the NaN the detector is after - sends every row with remote entries through the sequential redo,
+            # which is correct but costs about what the one-pass min costs
             B_ext, work = self.exchange(B_loc, async_op=True)
-            v_all = p.val if val is None else val
+            v_all = p.val if val is None else val.contiguous()  # (a strided override is fine for the products, not for the scan)
             vl = plan.loc[2] if val is None else val[plan.nnz_pos_loc]
             flag = torch.zeros(1, dtype=torch.int32, device=B_ext.device)
             C, E = self.ops.spmm(2, plan.loc[0], plan.loc[1], vl, B_ext[:p.n_local], shared_gpu=True)
             self.ops.nonfinite_flag(B_ext[:p.n_local], flag)
-            if v_all is not None:
+            if val is None and v_all is not None:
+                if getattr(self, '_val_flag', None) is None:  # constant per engine: scanned once, OR-ed in from then on
+                    self._val_flag = torch.zeros(1, dtype=torch.int32, device=B_ext.device)
+                    self.ops.nonfinite_flag(v_all, self._val_flag)
+                flag |= self._val_flag
+            elif v_all is not None:
                 self.ops.nonfinite_flag(v_all, flag)
             if work is not None:
                 work.wait()

@@ -14,6 +14,16 @@ Next to the CSC view the Storage keeps, with the same lifetime: the locality pla
 all (dgsparse/spmm.py:5-28), so a plan must never cost a caller that uses a matrix once: it is built at the
 (DGS_PLAN_AFTER + 1)-th use, queued on the caller's stream without any host synchronisation (see _SharedPlan), and
 Storages over the same (rowptr, col) buffers share one plan.
+
+Reproducibility.  The plan-free and the planned schedule fold rows of 65 .. 8192 nnz with different (fixed) trees,
+so sum / mean of such rows can differ in the last bits between them (max / min, rows up to 64 nnz and the hub rows above 8192
+nnz are bit-identical on both).  The switch between the two is a pure function of the NUMBER of uses of the matrix - use
+DGS_PLAN_AFTER + 1 is the first planned one, whatever the timing (nothing is polled: the first planned use waits for four
+sums over the row lengths queued one use earlier, a few microseconds of GPU work) - so two runs of the same program agree
+bit for bit.  Callers that need one schedule for the whole life of a matrix have three switches:
+``torch.use_deterministic_algorithms(True)`` or ``DGS_REPRODUCIBLE=1`` (a Storage then never changes schedule on its own:
+plan-free until ``storage.spmm_plan(which, n_feat, wait=True)`` is called, planned from then on), ``DGS_PLAN_AFTER=0`` (planned
+from the first use) and ``DGS_PLAN=0`` (never planned).
 """
 import os
 import weakref
@@ -24,6 +34,11 @@ import torch
 from . import _capi
 
 _INDEX = torch.int32
+
+
+def _reproducible() -> bool:
+    """One schedule per matrix for its whole life: no plan is started behind the caller's back."""
+    return os.environ.get('DGS_REPRODUCIBLE', '0') == '1' or torch.are_deterministic_algorithms_enabled()
 
 
 def _plan_after() -> int:
@@ -42,11 +57,12 @@ class _SharedPlan:
     """Plan state of ONE (pointer array, index array) pair, shared by every Storage built over the same buffers.  Holds
     the arrays, so their memory cannot be recycled under a live key.
 
-    Life of a plan, no host synchronisation anywhere: construction queues four sums over the row lengths and their copy
-    to pinned memory; the (DGS_PLAN_AFTER + 1)-th use queues the build on the CALLER's stream and from that very call on
-    hands out the build buffer with PROVISIONAL counts (upper bounds from those sums: the kernels read the real counts
-    from the device header, the host only sizes grids and the workspace with them); once the build's event has
-    completed, a later use swaps in the compacted plan with the real counts and drops the worst-case build buffer."""
+    Life of a plan: the DGS_PLAN_AFTER-th use (the last plan-free one) queues four sums over the row lengths and their copy
+    to pinned memory; the next use waits for that copy (long done), queues the build on the CALLER's stream and from that very
+    call on hands out the build buffer with PROVISIONAL counts (upper bounds from those sums: the kernels read the real counts
+    from the device header, the host only sizes grids and the workspace with them); once the build's event has completed, a
+    later use swaps in the compacted plan with the real counts and drops the worst-case build buffer (same tables, same bits).
+    Which use is the first planned one depends on the use count alone, never on what has or has not completed yet."""
     __slots__ = ('ptr', 'idx', 'K', 'prefix', 'calls', 'ready', 'prov', '__weakref__')
 
     def __init__(self, ptr, idx, K, prefix=None):
@@ -62,10 +78,7 @@ class _SharedPlan:
         cur = torch.cuda.current_stream(self.ptr.device)
         if self.prov is None:
             host, ev = stats
-            if wait:
-                ev.synchronize()
-            elif not ev.query():
-                return (None, None)  # the sums have not arrived yet (only right after construction): next time
+            ev.synchronize()  # four sums queued one use ago (or just now, DGS_PLAN_AFTER=0 / wait=True): never a poll
             buf, hdr = torch.ops.dgsparse_spmm.spmm_plan_start(self.ptr, self.idx, self.K, self.prefix)  # queued on `cur`
             done = torch.cuda.Event()
             done.record(cur)
@@ -87,17 +100,30 @@ class _SharedPlan:
 _SHARED_PLANS = weakref.WeakValueDictionary()
 
 
+_STATS_STREAMS = {}
+
+
 def _length_stats(ptr: torch.Tensor):
     """Queues the four sums over the row lengths the provisional plan counts need (rows longer than t1 / tslice: how many,
-    how many nnz) and their copy to pinned memory; returns (pinned int64[4], event).  No synchronisation."""
-    t1, ts = _capi.plan_thresholds()
-    deg = (ptr[1:] - ptr[:-1]).long()
-    m1, m2 = deg > t1, deg > ts
-    dev_stats = torch.stack([m1.sum(), (deg * m1).sum(), m2.sum(), (deg * m2).sum()])
-    host = torch.empty(4, dtype=torch.int64, pin_memory=True)
-    host.copy_(dev_stats, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(ptr.device))
+    how many nnz) and their copy to pinned memory; returns (pinned int64[4], event).  They run on a side stream behind what
+    the caller's stream holds NOW, so the event completes a few microseconds of GPU work later however long the caller's
+    queue grows in the meantime - the use that waits for it (``_SharedPlan.get``) does not wait for the caller's own kernels."""
+    dev = ptr.device
+    cur = torch.cuda.current_stream(dev)
+    side = _STATS_STREAMS.get(dev.index)
+    if side is None:
+        side = _STATS_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        t1, ts = _capi.plan_thresholds()
+        deg = (ptr[1:] - ptr[:-1]).long()
+        m1, m2 = deg > t1, deg > ts
+        dev_stats = torch.stack([m1.sum(), (deg * m1).sum(), m2.sum(), (deg * m2).sum()])
+        host = torch.empty(4, dtype=torch.int64, pin_memory=True)
+        host.copy_(dev_stats, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    ptr.record_stream(side)
     return host, ev
 
 
@@ -172,8 +198,6 @@ class Storage(object):
         self._tvalues = None   # (weakref to values, version, values in CSC order)
         self._len_stats = {}   # 'csr' / 'csc' -> (pinned sums over the row lengths, event): what a provisional plan needs
         self.csr2csc_convert()
-        if nnz and col.is_cuda and n_rows > 0:  # queued here, long complete by the (DGS_PLAN_AFTER + 1)-th use
-            self._len_stats = {'csr': _length_stats(self._rowptr), 'csc': _length_stats(self._colptr)}
 
     @classmethod
     def empty(cls):
@@ -242,9 +266,20 @@ class Storage(object):
         if torch.cuda.is_current_stream_capturing():
             return (None, None)
         if sp.prov is None:
-            sp.calls += 1
-            if not wait and sp.calls <= _plan_after():
-                return (None, None)
+            if not wait:
+                if _reproducible():
+                    return (None, None)  # plan-free until the caller asks for the plan (wait=True): one schedule per matrix
+                sp.calls += 1
+                after = _plan_after()
+                if sp.calls <= after:
+                    # a matrix used once (sampled mini-batches) pays nothing; its SECOND use (or the last plan-free one) queues
+                    # the row-length sums the build needs on a side stream (they used to be queued at construction,
+                    # for every Storage, used or not)
+                    if (sp.calls == 2 or sp.calls == after) and which not in self._len_stats:
+                        self._len_stats[which] = _length_stats(ptr)
+                    return (None, None)
+            if which not in self._len_stats:
+                self._len_stats[which] = _length_stats(ptr)
         return sp.get(self._len_stats[which], wait)
 
     def csc_values(self) -> torch.Tensor:

@@ -488,6 +488,59 @@ def test_plan_lifecycle_lazy_async_shared(monkeypatch):
     assert torch.allclose(y, ref, rtol=1e-5, atol=1e-6)
 
 
+def test_schedule_switch_is_a_function_of_the_use_count_and_reproducible_mode(monkeypatch):
+    """the plan-free and the planned schedule fold rows of 65 .. 8192 nnz with different trees, so WHEN a matrix
+    switches must not depend on timing.  (i) Two fresh tensors over clones of the same arrays, one driven in a tight loop and
+    one with a device synchronisation after every call, agree bit for bit call by call; calls 1 .. DGS_PLAN_AFTER equal each
+    other and so do all later ones.  (ii) DGS_REPRODUCIBLE=1 / torch.use_deterministic_algorithms: one schedule for the whole
+    life of the matrix - plan-free until spmm_plan(wait=True), planned after it."""
+    import dgsparse
+    from bench import graphgen
+    from dgsparse import storage as dst
+    monkeypatch.delenv('DGS_PLAN_AFTER', raising=False)
+    monkeypatch.delenv('DGS_REPRODUCIBLE', raising=False)
+    rp, col, st = graphgen.powerlaw_csr(70000, 900000, alpha=1.9, dmax=20000, seed=12, device='cuda', as_torch=True)
+    N = 64
+    g = torch.Generator(device='cuda')
+    g.manual_seed(5)
+    X = torch.rand((st['K'], N), generator=g, device='cuda')
+    val = torch.rand(st['nnz'], generator=g, device='cuda')
+    n_calls, after = 8, dst._plan_after()
+    runs = []
+    for sync in (False, True):
+        A = dgsparse.SparseTensor(rowptr=rp.clone(), col=col.clone(), values=val.clone(), has_value=True)
+        outs = []
+        for _ in range(n_calls):
+            outs.append(dgsparse.spmm_sum(A, X, 0))
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        runs.append(outs)
+        assert A.storage._plans['csr'].prov is not None or A.storage._plans['csr'].ready is not None, 'the plan was started'
+    for k in range(n_calls):
+        assert torch.equal(runs[0][k], runs[1][k]), f'call {k + 1}: tight loop and synchronised loop differ'
+    for k in range(1, after):
+        assert torch.equal(runs[0][k], runs[0][0]), f'call {k + 1} is plan-free like call 1'
+    for k in range(after + 1, n_calls):
+        assert torch.equal(runs[0][k], runs[0][after]), f'call {k + 1} is planned like call {after + 1}'
+    # (ii) reproducible mode
+    monkeypatch.setenv('DGS_REPRODUCIBLE', '1')
+    A = dgsparse.SparseTensor(rowptr=rp.clone(), col=col.clone(), values=val.clone(), has_value=True)
+    outs = [dgsparse.spmm_sum(A, X, 0) for _ in range(n_calls)]
+    sp = A.storage._plans['csr']
+    assert sp.prov is None and sp.ready is None, 'nothing is built behind the caller in reproducible mode'
+    assert all(torch.equal(o, outs[0]) for o in outs) and torch.equal(outs[0], runs[0][0])
+    assert A.storage.spmm_plan('csr', N, wait=True)[0] is not None
+    outs = [dgsparse.spmm_sum(A, X, 0) for _ in range(4)]
+    assert all(torch.equal(o, outs[0]) for o in outs) and torch.equal(outs[0], runs[0][after])
+    monkeypatch.delenv('DGS_REPRODUCIBLE')
+    torch.use_deterministic_algorithms(True)
+    try:
+        assert dst._reproducible()
+    finally:
+        torch.use_deterministic_algorithms(False)
+
+
 def test_gin_cached_neighbourhood_is_keyed_on_the_graph():
     """cached=True must not reuse the first adjacency for another edge_index."""
     from dgsparse import nn as dnn

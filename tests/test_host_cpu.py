@@ -216,3 +216,20 @@ def test_nnz_balanced_row_offsets():
     assert dd.row_offsets(torch.tensor([0, 0, 0]), 2, 'nnz') == [0, 0, 2]
     with pytest.raises(ValueError):
         dd.row_offsets(torch.from_numpy(rp), 2, 'cols')
+
+
+def test_hub_work_deal_covers_every_task_once(tmp_path):
+    """csrc/spmm_strict.h strict_deal + the hub-table regions, checked on the host (tests/host/deal_test.cpp): every (row, slice)
+    task of every segment goes to exactly one worker on the row's XCD, for grids that are and are not multiples of 8."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    exe = str(tmp_path / 'deal_test')
+    src = os.path.join(ROOT, 'tests', 'host', 'deal_test.cpp')
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O1', '-std=c++17', '-I' + os.path.join(ROOT, 'dgsparse-lib_amd', 'csrc'),
+                        '-I' + os.path.join(ROOT, 'include'), '-Wno-unused-function', src, '-o', exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == 'ok', r.stdout + r.stderr
