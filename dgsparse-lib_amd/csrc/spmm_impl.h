@@ -993,7 +993,7 @@ constexpr int fused_waves_per_simd(int op) { return (op == DGS_MAX || op == DGS_
 // longer than the hub threshold one sequential fmaf chain per feature, like the rows up to T1 - the rows in between keep the
 // fixed tree); they come first in the grid because a 50 k-nnz chain is the longest job of the launch.
 template <int OP, int V, int G, bool ACC>
-constexpr bool hub_ok() { return (OP == DGS_SUM || OP == DGS_MEAN) && !ACC && strict_coop(G, V); }
+constexpr bool hub_ok() { return DGS_HUB_COOP_V2 && (OP == DGS_SUM || OP == DGS_MEAN) && !ACC && strict_coop(G, V); }
 struct HubLds {
   alignas(16) float f[kHubBlockFloats];
 };

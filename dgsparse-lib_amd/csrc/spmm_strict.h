@@ -32,6 +32,9 @@ namespace dgs {
 #ifndef DGS_STRICT_PRIO
 #define DGS_STRICT_PRIO 1
 #endif
+#ifndef DGS_HUB_COOP_V2
+#define DGS_HUB_COOP_V2 1  // 0: the round-3 hub workgroup (one gather set per wave, wave 0 gathers and chains)
+#endif
 #ifndef DGS_STRICT_DBG
 #define DGS_STRICT_DBG 0  // experiment builds: 1 = no chain, 2 = no gathers, 3 = no LDS writes and no chain
 #endif
@@ -365,6 +368,113 @@ __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, con
   if (ph < nph) phase(ph, xa);
 }
 
+// The round-3 form of the hub workgroup (every wave gathers ONE set of kUS rows per lane, wave 0 chains between two barriers;
+// ~8 ns per link under load): kept selectable (-DDGS_HUB_COOP_V2=0) as the measured baseline of the round-4 version above
+// and as its fallback.  It needs 16 x 516 + 512 floats of LDS, so only the strict launch (kStrictBlockFloats) can host it.
+template <int GP, bool MEAN, bool HAS_VAL, bool FMA>
+__device__ __forceinline__ void strict_hub_coop_v1(const int row, const int p0, const int len, const int tbase, const int sl,
+                                                const int N, const int *__restrict__ col, const float *__restrict__ val,
+                                                const float *__restrict__ B, float *__restrict__ C, float *lds,
+                                                   const Epi &epi = Epi{}) {
+  constexpr int V = 4, NW = kBlock / kWave;
+  constexpr int NGP = kWave / GP, W = GP * V;   // nnz per load instruction; floats (= chain lanes) of the slice
+  constexpr int NWV = kUS * NGP;                // nnz per wave and round
+  constexpr int NRB = NW * NWV;                 // nnz per workgroup round
+  constexpr int LD = NRB + 4;                   // row pitch of the feature-major tile: conflict-free ds_read_b128 across lanes
+  static_assert(W * LD + NRB <= kStrictBlockFloats && W <= kWave, "strict_hub_coop LDS");
+  float *xt = lds, *wt = lds + W * LD;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int gp = lane / GP, lp = lane % GP;
+  const int fbase = tbase + sl * W;
+  const int f0 = fbase + lp * V;
+  const float *Bl = B + (f0 < N ? f0 : 0);
+  const int mine = wave * NWV + gp;  // this lane's nnz of gather q inside a round: mine + q * NGP
+  float acc = 0.0f;
+  int c[kUS];
+  float w[kUS], x[kUS][V];
+#pragma unroll
+  for (int q = 0; q < kUS; q++) {
+    const int i = p0 + min(mine + q * NGP, len - 1);
+    c[q] = ld_stream(col + i);
+    w[q] = HAS_VAL ? ld_stream(val + i) : 1.0f;
+  }
+#pragma unroll
+  for (int q = 0; q < kUS; q++) load_vec_gather<V>(Bl + (int64_t)c[q] * N, x[q]);
+  for (int r0 = 0; r0 < len; r0 += NRB) {
+    const int cnt = min(NRB, len - r0);
+    int cn[kUS];
+    float wn[kUS];
+#pragma unroll
+    for (int q = 0; q < kUS; q++) {
+      const int i = p0 + min(r0 + NRB + mine + q * NGP, len - 1);
+      cn[q] = ld_stream(col + i);
+      wn[q] = HAS_VAL ? ld_stream(val + i) : 1.0f;
+    }
+    __syncthreads();  // the chain of the previous round has left the tile
+#pragma unroll
+    for (int q = 0; q < kUS; q++) {
+      const int i = mine + q * NGP;
+#pragma unroll
+      for (int v = 0; v < V; v++) xt[(lp * V + v) * LD + i] = x[q][v];
+      if (HAS_VAL && lp == 0) wt[i] = w[q];
+    }
+#pragma unroll
+    for (int q = 0; q < kUS; q++) {  // the next round's gathers fly under the chain
+      load_vec_gather<V>(Bl + (int64_t)cn[q] * N, x[q]);
+      w[q] = wn[q];
+    }
+    __syncthreads();
+    if (wave == 0 && lane < W) {
+      // the chain is the critical path of the whole call and a dependent sequence: give it the SIMD's issue slots ahead of
+      // the three other waves that share them (DGS_STRICT_PRIO=0 builds measure the difference)
+      if (DGS_STRICT_PRIO) __builtin_amdgcn_s_setprio(3);
+      const float *xr = xt + lane * LD;
+      constexpr int CB = 4;  // b128 pairs per batch = 16 steps
+      float4 xa[CB], wa[CB], xn[CB], wn4[CB];
+      auto rdb = [&](int i0, float4 (&xx)[CB], float4 (&ww)[CB]) {
+#pragma unroll
+        for (int u = 0; u < CB; u++) {
+          xx[u] = *reinterpret_cast<const float4 *>(xr + i0 + 4 * u);
+          if constexpr (HAS_VAL) ww[u] = *reinterpret_cast<const float4 *>(wt + i0 + 4 * u);
+          else ww[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+      };
+      auto fmab = [&](const float4 (&xx)[CB], const float4 (&ww)[CB]) {
+#pragma unroll
+        for (int u = 0; u < CB; u++) {
+          acc = chain_step<FMA>(ww[u].x, xx[u].x, acc);
+          acc = chain_step<FMA>(ww[u].y, xx[u].y, acc);
+          acc = chain_step<FMA>(ww[u].z, xx[u].z, acc);
+          acc = chain_step<FMA>(ww[u].w, xx[u].w, acc);
+        }
+      };
+      constexpr int ST = 4 * CB;
+      int i = 0;
+      if (cnt >= ST) {
+        rdb(0, xa, wa);
+        while (true) {
+          if (i + 2 * ST <= cnt) rdb(i + ST, xn, wn4);
+          fmab(xa, wa);
+          i += ST;
+          if (i + ST > cnt) break;
+          if (i + 2 * ST <= cnt) rdb(i + ST, xa, wa);
+          fmab(xn, wn4);
+          i += ST;
+          if (i + ST > cnt) break;
+        }
+      }
+      for (; i < cnt; i++) acc = chain_step<FMA>(HAS_VAL ? wt[i] : 1.0f, xr[i], acc);
+      if (DGS_STRICT_PRIO) __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  if (wave == 0 && lane < W && fbase + lane < N) {
+    if constexpr (MEAN) acc /= (float)len;
+    float o[1] = {acc};
+    epi_apply<1>(o, row, fbase + lane, epi);
+    store_vec_stream<1>(C + (int64_t)row * N + fbase + lane, o);
+  }
+}
+
 // Work deal shared by the strict unit blocks and the hub blocks of the default launch.  One segment = `ngroups` groups of gs
 // tasks (a row's feature slices); group g belongs to XCD g % nx, and the worker (a wave, or a whole workgroup for cooperative
 // hub tasks) that is slot `slot` of `nslots` on XCD x takes every nslots-th task of that XCD's groups.  `rot` carries the deal
@@ -404,7 +514,12 @@ __device__ __forceinline__ int spmm_hub_body(int bid, int nblocks, float *ldsf, 
     for (int c = ha.ncls - 1; c >= 0; c--)
       strict_deal(ha.cnt[c], SH, x, nx, sb, SPB, rotb, [&](int g, int j) {
         const int4 d = ha.rows[ha.ht.base[c] + g];
+#if DGS_HUB_COOP_V2
         strict_hub_coop<G / SH, MEAN, HAS_VAL, FMA, LDSF>(d.x, d.y, d.z, tbase, j, N, col, val, B, C, ldsf, epi);
+#else
+        static_assert(LDSF >= kStrictBlockFloats, "the round-3 hub workgroup needs the strict launch's LDS");
+        strict_hub_coop_v1<G / SH, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, j, N, col, val, B, C, ldsf, epi);
+#endif
       });
     __syncthreads();  // the last chain has left the LDS before the waves reuse it one by one
     rot = (rotb * (kBlock / kWave)) % SP;
