@@ -541,6 +541,63 @@ def test_schedule_switch_is_a_function_of_the_use_count_and_reproducible_mode(mo
         torch.use_deterministic_algorithms(False)
 
 
+def test_two_host_threads_two_streams_two_plans():
+    """the launchers keep no mutable global state (the tuning snapshot is immutable, per-device facts are
+    atomics), so two host threads may launch concurrently, each on its own stream with its own plan and workspace: every
+    result of every iteration must be the single-threaded one, bit for bit (plan-free / planned / max over the shared plan /
+    the dense-graph schedule whose launcher sets a per-instantiation attribute on first use)."""
+    import threading
+    from bench import graphgen
+    from dgsparse import _capi
+    graphs = []
+    for seed in (31, 32):
+        rp, col, st = graphgen.powerlaw_csr(60000, 800000, alpha=1.9, dmax=15000, seed=seed, device='cuda', as_torch=True)
+        g = torch.Generator(device='cuda')
+        g.manual_seed(seed)
+        val = torch.rand(st['nnz'], generator=g, device='cuda')
+        X = torch.rand((st['K'], 64), generator=g, device='cuda')
+        plan = _capi.spmm_plan(rp, col, st['K'], 64, force=True)
+        graphs.append((rp, col, val, X, plan))
+    torch.cuda.synchronize()
+
+    def work(gr, out):
+        rp, col, val, X, plan = gr
+        out.append(_capi.spmm(_capi.SUM, rp, col, val, X)[0])
+        out.append(_capi.spmm(_capi.SUM, rp, col, val, X, plan=plan)[0])
+        out.extend(_capi.spmm(_capi.MAX, rp, col, val, X, plan=plan))
+        out.append(_capi.spmm(_capi.MEAN, rp, col, val, X, plan=plan)[0])
+
+    want = []
+    for gr in graphs:
+        o = []
+        work(gr, o)
+        want.append(o)
+    torch.cuda.synchronize()
+    errors = []
+
+    def thread(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(20):
+                    o = []
+                    work(graphs[i], o)
+                    s.synchronize()
+                    for a, b in zip(o, want[i]):
+                        if not torch.equal(a, b):
+                            errors.append(f'thread {i}: result differs from the single-threaded run')
+                            return
+        except Exception as e:  # noqa: BLE001
+            errors.append(f'thread {i}: {e!r}')
+
+    ts = [threading.Thread(target=thread, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
 def test_gin_cached_neighbourhood_is_keyed_on_the_graph():
     """cached=True must not reuse the first adjacency for another edge_index."""
     from dgsparse import nn as dnn

@@ -141,3 +141,113 @@ def test_strict_headline_graph_all_rows(capi, N):
         C, _ = capi.spmm(capi.SUM, rp, col, val, X, algorithm=alg)
         ref, _ = oracle.spmm('sum', rpc, colc, valc, Xc, fma=fma, threads=oracle.max_threads())
         assert_bitexact(C.cpu().numpy(), ref, f'headline graph strict fma={fma} N={N}')
+
+
+# ---- round 4: the DEFAULT sum / mean chain the hub rows (longer than DGS_HUB_CHAIN nnz) -----------------------------------
+def _default(capi, op, rp, col, val, X, plan=False, **kw):
+    d = 'cuda'
+    drp, dcol = torch.from_numpy(rp).to(d), torch.from_numpy(col).to(d)
+    dX = torch.from_numpy(X).to(d)
+    pl = capi.spmm_plan(drp, dcol, X.shape[0], X.shape[1], force=True) if plan else None
+    C, _ = capi.spmm({'sum': capi.SUM, 'mean': capi.MEAN}[op], drp, dcol, None if val is None else torch.from_numpy(val).to(d),
+                     dX, plan=pl, **kw)
+    torch.cuda.synchronize()
+    return C.cpu().numpy(), pl
+
+
+@pytest.mark.parametrize('N', [16, 32, 64, 128, 256, 48, 384])
+@pytest.mark.parametrize('plan', [False, True], ids=['plan-free', 'plan'])
+def test_default_sum_chains_the_hub_rows(capi, monkeypatch, N, plan):
+    """Rows above the hub threshold are ONE fmaf chain per feature in the default schedule too - bit for bit the oracle's
+    sequential chain, like the rows up to 64 nnz; the rows in between keep the fixed tree (1e-5).  Plan-free (hub table from
+    the classify pass) and planned (hub table of the plan, the hub rows' units skipped), every 16-byte feature mapping,
+    widths that leave a slice partly or wholly empty (48) and several feature tiles (384)."""
+    monkeypatch.setenv('DGS_HUB_CHAIN', '1024')
+    rp, col, st = graphgen.powerlaw_csr(70000, 900000, alpha=1.9, dmax=20000, seed=21)
+    lens = np.diff(rp)
+    hub = lens > 1024
+    assert hub.sum() >= 8 and lens.max() > 8000
+    val = graphgen.weights(col.shape[0], 'uniform', 5)
+    X = graphgen.features(st['K'], N, 6)
+    ref, _ = oracle.spmm('sum', rp, col, val, X, fma=True, threads=oracle.max_threads())
+    C, pl = _default(capi, 'sum', rp, col, val, X, plan)
+    if plan:
+        assert pl is not None and pl.info.n_hub == int(hub.sum())
+    assert_bitexact(C[hub], ref[hub], f'hub rows N={N}')
+    assert_bitexact(C[lens <= 64], ref[lens <= 64], f'short rows N={N}')
+    rel = np.abs(C - ref) / np.maximum(np.abs(ref), 1e-6)
+    assert rel.max() <= 1e-5
+    # mean and unit weights through the same path
+    Cm, _ = _default(capi, 'mean', rp, col, None, X, plan)
+    refm, _ = oracle.spmm('mean', rp, col, None, X, fma=True, threads=oracle.max_threads())
+    assert_bitexact(Cm[hub], refm[hub], f'hub rows mean, unit weights N={N}')
+    assert np.abs(Cm - refm).max() <= 1e-5 * np.abs(refm).max() + 1e-6
+
+
+def test_hub_chain_switch_and_other_reduces_share_the_plan(capi, monkeypatch):
+    """DGS_HUB_CHAIN=0 brings the fixed tree back for every row; a plan built WITH hub rows still serves max / min (their
+    units stay in the table, sorted behind the other units of each XCD's share) bit-exactly."""
+    rp, col, st = graphgen.powerlaw_csr(70000, 900000, alpha=1.9, dmax=20000, seed=22)
+    lens = np.diff(rp)
+    val = graphgen.weights(col.shape[0], 'signed', 7)
+    X = graphgen.features(st['K'], 64, 8) - 0.4
+    monkeypatch.setenv('DGS_HUB_CHAIN', '2048')
+    d = 'cuda'
+    drp, dcol, dval, dX = (torch.from_numpy(a).to(d) for a in (rp, col, val, X))
+    pl = capi.spmm_plan(drp, dcol, st['K'], 64, force=True)
+    assert pl.info.n_hub == int((lens > 2048).sum()) > 0
+    for red in ('max', 'min'):
+        C, E = capi.spmm(oracle.REDUCE[red], drp, dcol, dval, dX, plan=pl)
+        Co, Eo = oracle.spmm(red, rp, col, val, X, fma=True)
+        assert_bitexact(C.cpu().numpy(), Co, red + ' over a plan with hub rows')
+        assert_bitexact(E.cpu().numpy(), Eo, red + ' E over a plan with hub rows')
+    Chub, _ = capi.spmm(capi.SUM, drp, dcol, dval, dX, plan=pl)
+    monkeypatch.setenv('DGS_HUB_CHAIN', '0')
+    Ctree, _ = capi.spmm(capi.SUM, drp, dcol, dval, dX, plan=pl)        # same plan, hub blocks off: units of the hub rows walked
+    Cfree, _ = capi.spmm(capi.SUM, drp, dcol, dval, dX)
+    ref, _ = oracle.spmm('sum', rp, col, val, X, fma=True, threads=oracle.max_threads())
+    hub = lens > 2048
+    assert_bitexact(Chub.cpu().numpy()[hub], ref[hub], 'hub rows chained')
+    for name, Cx in (('planned tree', Ctree), ('plan-free tree', Cfree)):
+        Cx = Cx.cpu().numpy()
+        assert not np.array_equal(Cx[hub].view(np.int32), ref[hub].view(np.int32)), name + ': the switch must bring the tree back'
+        C64 = oracle.spmm_sum_f64(rp, col, val, X)
+        S64 = oracle.spmm_sum_f64(rp, col, val, X, absval=True)
+        assert (np.abs(Cx - C64) <= 3e-6 * S64 + 1e-6).all(), name
+
+
+def test_hub_chain_with_the_fused_epilogue_and_the_panel_schedule(capi, monkeypatch):
+    """The epilogue leaves with the hub rows' results as well (bit-identical to the unfused ops), and a dense graph on the
+    column-panel sweep chains its rows above the hub threshold."""
+    monkeypatch.setenv('DGS_HUB_CHAIN', '1024')
+    rp, col, st = graphgen.powerlaw_csr(70000, 900000, alpha=1.9, dmax=20000, seed=23)
+    lens = np.diff(rp)
+    hub = lens > 1024
+    val = graphgen.weights(col.shape[0], 'uniform', 3)
+    X = graphgen.features(st['K'], 64, 4)
+    d = 'cuda'
+    drp, dcol, dval, dX = (torch.from_numpy(a).to(d) for a in (rp, col, val, X))
+    bias = torch.linspace(-1, 1, 64, device=d)
+    rs = torch.rand(rp.size - 1, device=d) + 0.5
+    C0, _ = capi.spmm(capi.SUM, drp, dcol, dval, dX)
+    want = torch.relu(C0 * rs[:, None] + bias)
+    for pl in (None, capi.spmm_plan(drp, dcol, st['K'], 64, force=True)):
+        got, _ = capi.spmm(capi.SUM, drp, dcol, dval, dX, plan=pl, bias=bias, row_scale=rs, relu=True)
+        base, _ = capi.spmm(capi.SUM, drp, dcol, dval, dX, plan=pl)
+        assert torch.equal(got, torch.relu(base * rs[:, None] + bias)), 'fused == unfused bit for bit (hub rows included)'
+        assert torch.equal(got[torch.from_numpy(hub).to(d)], want[torch.from_numpy(hub).to(d)]), 'hub rows do not depend on the plan'
+    # dense graph forced onto the panel schedule: rows above max(tlong, hub threshold) are chains
+    rp2, col2, st2 = graphgen.powerlaw_csr(9000, 2_400_000, alpha=2.6, dmax=8000, seed=5)
+    val2 = graphgen.weights(col2.shape[0], 'uniform', 3)
+    X2 = graphgen.features(st2['K'], 64, 4)
+    monkeypatch.setenv('DGS_PANEL', '1')
+    monkeypatch.setenv('DGS_PANEL_TLONG', '2500')
+    monkeypatch.setenv('DGS_HUB_CHAIN', '3000')
+    assert capi.spmm_schedule(capi.SUM, rp2.size - 1, st2['K'], 64, col2.size) == 'panel'
+    C2, _ = _default(capi, 'sum', rp2, col2, val2, X2)
+    ref2, _ = oracle.spmm('sum', rp2, col2, val2, X2, fma=True, threads=oracle.max_threads())
+    l2 = np.diff(rp2)
+    assert (l2 > 3000).any()
+    assert_bitexact(C2[l2 > 3000], ref2[l2 > 3000], 'panel schedule: hub rows')
+    assert_bitexact(C2[l2 <= 2500], ref2[l2 <= 2500], 'panel schedule: swept rows are chains already')
+    assert (np.abs(C2 - ref2) <= 1e-5 * np.abs(ref2) + 2e-6).all()
