@@ -78,9 +78,29 @@ def self_spawn(n):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    env.setdefault('NCCL_DEBUG', 'WARN')  # first contact with an 8-GPU node: keep what RCCL has to say (see nccl_log_tail)
+    env.setdefault('NCCL_DEBUG_FILE', os.path.join('/tmp', 'dgs_bench_nccl_%h_%p.log'))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr',
            '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+def nccl_log_tail(limit=1500):
+    """Tail of the RCCL debug files of this launch (NCCL_DEBUG_FILE pattern set by self_spawn / the launcher), for the JSON line
+    of a failed multi-GPU run: the driver keeps stdout, not the ranks' files."""
+    import glob
+    pat = os.environ.get('NCCL_DEBUG_FILE', '')
+    if not pat:
+        return None
+    out = []
+    for f in sorted(glob.glob(pat.replace('%h', '*').replace('%p', '*')))[:16]:
+        try:
+            txt = open(f).read().strip()
+        except OSError:
+            continue
+        if txt:
+            out.append(os.path.basename(f) + ': ' + txt[-300:])
+    return ' | '.join(out)[-limit:] if out else None
 
 
 def time_steps(fn, steps, warmup, dist_on):
@@ -210,10 +230,30 @@ def main():
     dev = torch.device('cuda', local_rank)
     if pg:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        if one_gpu:
-            torch.distributed.init_process_group('gloo')
-        else:
-            torch.distributed.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('NCCL_DEBUG', 'WARN')
+        try:
+            if one_gpu:
+                torch.distributed.init_process_group('gloo')
+            else:
+                torch.distributed.init_process_group('nccl', device_id=dev)
+            # first contact: one all-reduce of ones must count every rank before anything is timed
+            ones = torch.ones(1, device=dev, dtype=torch.float32)
+            if one_gpu:
+                h = ones.cpu()
+                torch.distributed.all_reduce(h)
+                ones.copy_(h)
+            else:
+                torch.distributed.all_reduce(ones)
+            torch.cuda.synchronize()
+            rccl_ranks = int(round(ones.item()))
+            if rccl_ranks != world:
+                raise RuntimeError(f'all-reduce of ones counted {rccl_ranks} ranks, WORLD_SIZE is {world}')
+        except Exception as e:  # noqa: BLE001  (a line the driver can read beats a traceback on 8 stderr streams)
+            if rank == 0:
+                print(json.dumps({'metric': f'CSR SpMM GFLOP/s (feat={a.feat}, {a.reduce})', 'value': None, 'unit': 'GFLOP/s',
+                                  'n_gpus': world, 'error': f'process group / first collective failed: {e!r}',
+                                  'backend': 'gloo' if one_gpu else 'nccl', 'nccl_log_tail': nccl_log_tail()}))
+            raise
 
     def allreduce_max(x):  # gloo (dry run) reduces on the host
         if one_gpu:
@@ -231,6 +271,9 @@ def main():
     N = a.feat
     op = {'sum': _capi.SUM, 'mean': _capi.MEAN, 'max': _capi.MAX, 'min': _capi.MIN}[a.reduce]
     extra = {}
+    if pg:
+        extra['rccl_ranks'] = rccl_ranks
+        extra['backend'] = 'gloo (one-GPU dry run)' if one_gpu else 'nccl (RCCL)'
 
     def make_graph(seed):
         rp_, col_, st_ = graphgen.powerlaw_csr(Mloc, Mloc * a.deg, K=(a.ncols or None), alpha=a.alpha, dmax=a.dmax,
@@ -292,6 +335,13 @@ def main():
                    f'max_deg={st["max_deg"]}), cols={a.cols}, SpMM-{a.reduce} feat={N}, fp32 values'
         extra['schedule'] = _capi.spmm_schedule(op, Mloc, K, N, nnz_total) + ('+plan' if planned else '') + \
             (f'+strict-{a.strict}' if strict_alg else '')
+        if a.reduce in ('sum', 'mean') and not strict_alg:
+            th = _capi.hub_threshold()
+            dg = (rp[1:] - rp[:-1]).long()
+            extra['hub_chain'] = dict(threshold=th, rows=int((dg > th).sum()) if th else 0,
+                                      nnz=int(dg[dg > th].sum()) if th else 0,
+                                      note='rows above the threshold are one sequential fmaf chain per feature (like rows <= 64 '
+                                           'nnz); rows in between a fixed tree; DGS_HUB_CHAIN')
     else:
         from dgsparse import dist as ddist
         part = ddist.synthetic_partition(rank, world, Mloc, a.deg, cols=a.cols, locality=a.locality, seed=a.seed,
@@ -329,6 +379,13 @@ def main():
     wall, ev = time_steps(step, a.steps, a.warmup, pg)
     t = torch.tensor([wall, ev], device=dev, dtype=torch.float64)
     if pg:
+        # per-rank step times (min / max over ranks): a straggler or an unbalanced partition shows here, not in the max alone
+        mine = torch.tensor([wall / a.steps * 1e3], dtype=torch.float64, device='cpu' if one_gpu else dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        per_rank = [float(x.item()) for x in allr]
+        extra['per_rank_ms'] = dict(min=round(min(per_rank), 5), max=round(max(per_rank), 5),
+                                    ranks=[round(x, 5) for x in per_rank])
         allreduce_max(t)
     wall, ev = t.tolist()
     flops = 2.0 * nnz_total * N

@@ -47,6 +47,12 @@ extern "C" size_t dgs_spmm_csr_workspace_bytes(int reduce_op, int64_t M, int64_t
   return ws_layout(reduce_op, N, nnz).total;
 }
 
+// Rows longer than this are chained whole by the default sum / mean launches (0 = hub chains are off): spmm_impl.h hub_threshold
+extern "C" int dgs_spmm_hub_threshold(void) {
+  const int t = hub_threshold();
+  return t == INT_MAX ? 0 : t;
+}
+
 extern "C" int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz) {
   if (M <= 0 || N <= 0 || nnz <= 0 || tiny_problem(M, nnz)) return DGS_SCHED_SMALL;
   const FeatMap fm = feat_map(N, true);

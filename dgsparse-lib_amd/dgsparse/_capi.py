@@ -32,6 +32,8 @@ _lib.dgs_version.restype = _int
 _lib.dgs_arch.restype = ctypes.c_char_p
 _lib.dgs_strerror.restype = ctypes.c_char_p
 _lib.dgs_strerror.argtypes = [_int]
+_lib.dgs_spmm_hub_threshold.restype = _int
+_lib.dgs_spmm_hub_threshold.argtypes = []
 _lib.dgs_reload_tuning.restype = None
 _lib.dgs_reload_tuning.argtypes = []
 _lib.dgs_spmm_csr_workspace_bytes.restype = _sz
@@ -117,7 +119,7 @@ _lib.dgs_spmm_min_merge_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp, ctypes.c
 _lib.dgs_scatter_add_rows_f32.restype = _int
 _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
-EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_reload_tuning', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
+EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_reload_tuning', 'dgs_spmm_hub_threshold', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
            'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes', 'dgs_spmm_plan_build', 'dgs_spmm_plan_build2',
            'dgs_spmm_plan_compact_bytes', 'dgs_spmm_plan_compact', 'dgs_spmm_plan_info_from_header',
            'dgs_spmm_plan_thresholds', 'dgs_spmm_plan_provisional_info', 'dgs_spmm_csr_ex_f32', 'dgs_spmm_csr_plan_workspace_bytes',
@@ -176,6 +178,11 @@ def version() -> int:
 
 def arch() -> str:
     return _lib.dgs_arch().decode()
+
+
+def hub_threshold() -> int:
+    """Rows longer than this many nnz are sequential chains in the default sum / mean schedule (0 = off; DGS_HUB_CHAIN)."""
+    return int(_lib.dgs_spmm_hub_threshold())
 
 
 def reload_tuning() -> None:

@@ -93,6 +93,20 @@ int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz
 #define DGS_SCHED_ROWS 1
 #define DGS_SCHED_PANEL 2
 int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz);
+/*
+ * Numerical contract of sum / mean (the reference's result is ONE sequential fp32 chain per (row, feature) in CSR order,
+ * include/cuda/spmm_cuda.cuh:27-47, host twin example/util/sp_util.hpp:73-83):
+ *   rows of <= 64 nnz            that chain (fmaf), bit for bit
+ *   rows of > hub threshold nnz  that chain (fmaf), bit for bit - the HUB rows, each worked by its own workgroups, chained by
+ *                                one wave (16-byte lanes and >= 16 features; other shapes fold them like the rows in between)
+ *   rows in between              a fixed reduction tree (deterministic, closer to the exact sum than the chain; within ~6e-6
+ *                                of the chain on non-negative data at the default threshold)
+ * The threshold is DGS_HUB_CHAIN (default 8192, clamped to >= 1024, 0 = no hub chains: every row above 64 nnz takes the
+ * tree); the chain's own rounding error grows like sqrt(nnz) and passes 1e-5 of the exact sum beyond ~3 10^4 nnz, which is
+ * where a tree - however accurate - stops being within 1e-5 of the REFERENCE.  DGS_ALG_STRICT_SUM / _NOFMA chain every row.
+ * dgs_spmm_hub_threshold() returns the threshold in force (0 = off).
+ */
+int dgs_spmm_hub_threshold(void);
 
 /*
  * Cached locality plan of the row-stream schedule (new; the reference keeps no per-matrix state - the closest thing is
