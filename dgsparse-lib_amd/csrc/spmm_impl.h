@@ -1298,9 +1298,11 @@ static inline int hub_threshold() {
   if (t <= 0) return INT_MAX;
   return t < kHubChainMin ? kHubChainMin : t;
 }
-static inline int hub_blocks(int64_t tasks) {  // a multiple of 8 (XCD mapping), at most one workgroup per CU
+// Hub blocks of a launch: a multiple of 8 (XCD mapping), one per task up to four per CU (they come first in the grid: every hub
+// chain starts at once and the short ones hand their slots to the unit and row blocks within tens of microseconds)
+static inline int hub_blocks(int64_t tasks) {
   int64_t b = (tasks + 7) & ~int64_t(7);
-  const int cap = (cu_count() + 7) & ~7;
+  const int cap = (4 * cu_count() + 7) & ~7;
   return (int)(b < cap ? b : cap);
 }
 
@@ -1361,7 +1363,7 @@ static int launch_impl(const SpmmArgs &a) {
                            Epi{a.acc.epi.bias ? a.acc.epi.bias + fb : nullptr, a.acc.epi.rscale, a.acc.epi.relu});
       }
       const int nbu = 1024;
-      launch_fused<G, V, OP, HAS_VAL, ACC>(a, thub < INT_MAX ? hub_blocks(cu_count()) : 0, nbu, 0, kRowsPerWave, ut, part, parte,
+      launch_fused<G, V, OP, HAS_VAL, ACC>(a, thub < INT_MAX ? hub_blocks(2 * cu_count()) : 0, nbu, 0, kRowsPerWave, ut, part, parte,
                                            HubArg{hdr->hub, units, ht, kHubClasses});
       const int64_t cb = (L.max_long + 3) / 4;
       const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
@@ -1441,9 +1443,9 @@ static int launch_impl(const SpmmArgs &a) {
   int nbu_cap = tune(tuning().nbu, DGS_NBU);
   if (nbu_cap < 1) nbu_cap = 1;
   const int nbu = (int)(ub < nbu_cap ? (ub < 1 ? 1 : ub) : nbu_cap);
-  // (the hub count lives on the device: one hub workgroup per CU is launched whenever hub chains are on; without hub rows they
-  // read six zeros and leave)
-  launch_fused<G, V, OP, HAS_VAL, ACC>(a, thub < INT_MAX ? hub_blocks(cu_count()) : 0, nbu, nbr, rpw, ut, part, parte,
+  // (the hub count lives on the device: two hub workgroups per CU are launched whenever hub chains are on; without hub rows
+  // they read six zeros and leave)
+  launch_fused<G, V, OP, HAS_VAL, ACC>(a, thub < INT_MAX ? hub_blocks(2 * cu_count()) : 0, nbu, nbr, rpw, ut, part, parte,
                                        HubArg{hdr->hub, units, ht, kHubClasses});
   // combine: one wave per multi-unit row
   const int64_t cb = (L.max_long + 3) / 4;

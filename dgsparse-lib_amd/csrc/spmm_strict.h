@@ -486,9 +486,14 @@ template <typename F>
 __host__ __device__ __forceinline__ void strict_deal(int ngroups, int gs, int x, int nx, int slot, int nslots, int &rot, F &&fn) {
   const int gx = ngroups > x ? (ngroups - x + nx - 1) / nx : 0;  // groups of this XCD: x, x + nx, ...
   const int ux = gx * gs;
-  int u = slot - rot;
-  if (u < 0) u += nslots;
-  for (; u < ux; u += nslots) fn(x + nx * (u / gs), u % gs);
+  int s0 = slot - rot;
+  if (s0 < 0) s0 += nslots;
+  // rounds of nslots tasks, dealt boustrophedon: tasks come longest first, so the worker that got the longest task of one
+  // round gets the shortest of the next (a plain stride gave the slots of the 50 k-nnz row the 9th-longest row as well)
+  for (int k = 0; k * nslots < ux; k++) {
+    const int u = k * nslots + ((k & 1) ? nslots - 1 - s0 : s0);
+    if (u < ux) fn(x + nx * (u / gs), u % gs);
+  }
   rot = (rot + ux) % nslots;
 }
 
