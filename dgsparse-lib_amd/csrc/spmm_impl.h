@@ -1294,8 +1294,8 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
 // further than 1e-5 from the REFERENCE there.  Above the threshold the chain is reproduced bit for bit; below it the tree is
 // within ~5e-6 of it (non-negative data; DGS_ALG_STRICT_SUM chains every row).
 static inline int hub_threshold() {
-  int t = tune(tuning().hub_chain, kHubChain);
-  if (t <= 0) return INT_MAX;
+  const int t = tune(tuning().hub_chain, kHubChain);
+  if (t <= 0 || t > (1 << 24)) return INT_MAX;  // (the class bounds thub << c must stay inside an int)
   return t < kHubChainMin ? kHubChainMin : t;
 }
 // Hub blocks of a launch: a multiple of 8 (XCD mapping), one per task up to four per CU (they come first in the grid: every hub

@@ -377,8 +377,7 @@ extern "C" int dgs_spmm_plan_build2(int64_t M, int64_t K, int64_t nnz, const int
   ch = ch < kPlanChMin ? kPlanChMin : (ch > (1 << 20) ? (1 << 20) : ch);  // the table capacities assume ch >= kPlanChMin
   const int tslice = plan_tslice(), unit = plan_unit();
   // hub rows (dgs_common.h Tuning::hub_chain; spmm_impl.h hub_threshold): listed longest first for the sum / mean launches
-  int thub = tune(tuning().hub_chain, kHubChain);
-  thub = thub <= 0 ? INT_MAX : (thub < kHubChainMin ? kHubChainMin : thub);
+  const int thub = hub_threshold();
 
   if (hipMemsetAsync(hdr, 0, PL.off_units, st) != hipSuccess) return DGS_ELAUNCH;
   if (hipMemsetAsync(ws, 0, WL.off_list, st) != hipSuccess) return DGS_ELAUNCH;           // counters, cnt, cum
@@ -483,8 +482,7 @@ extern "C" int dgs_spmm_plan_provisional_info(int64_t nnz, int64_t rows_gt_t1, i
   info->tslice = plan_tslice();
   info->off_long = 0;  // the build-time layout
   {  // hub rows: at most every row longer than tslice, and no more than fit nnz (a bound: it only sizes the hub grid)
-    int thub = tune(tuning().hub_chain, kHubChain);
-    thub = thub <= 0 ? INT_MAX : (thub < kHubChainMin ? kHubChainMin : thub);
+    const int thub = hub_threshold();
     const int64_t hb = thub == INT_MAX ? 0 : (rows_gt_tslice < nnz_gt_tslice / thub ? rows_gt_tslice : nnz_gt_tslice / thub);
     info->n_hub = (int32_t)(hb < PL.max_hub ? hb : PL.max_hub);
   }

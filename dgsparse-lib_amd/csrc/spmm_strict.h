@@ -558,11 +558,10 @@ __device__ __forceinline__ void spmm_units_strict_body(int bid, int nblocks, Str
   const int s = (bid / nx) * (kBlock / kWave) + wave, SP = (nblocks / nx) * (kBlock / kWave);  // wave slots of this XCD
   int rot = spmm_hub_body<G, V, MEAN, HAS_VAL, FMA>(bid, nblocks, lds.f, N, col, val, B, C, HubArg{hdr->hub, units, ht, kHubClasses});
   // 4-slice units {row, first nnz, nnz, -}: SM entries' worth of work per row, table grows down from mid_top
-  if constexpr (SM > 1)
-    strict_deal(hdr->n_pslots, SM, x, nx, s, SP, rot, [&](int g, int j) {
-      const int4 d = units[ht.mid_top - 1 - g];
-      strict_unit<V, G / SM, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, j, lane, N, col, val, B, C, xb);
-    });
+  strict_deal(hdr->n_pslots, SM, x, nx, s, SP, rot, [&](int g, int j) {  // (SM = 1 for one-lane tiles: the whole tile again)
+    const int4 d = units[ht.mid_top - 1 - g];
+    strict_unit<V, G / SM, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, j, lane, N, col, val, B, C, xb);
+  });
   strict_deal(hdr->n_units, 1, x, nx, s, SP, rot, [&](int g, int) {
     const int4 d = units[g];
     strict_unit<V, G, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, 0, lane, N, col, val, B, C, xb);
