@@ -16,7 +16,7 @@ from dgsparse import _capi  # noqa: E402
 
 dev = 'cuda'
 bad = 0
-for M, nnz, dmax, hub in ((70000, 900000, 30000, 2000), (300000, 3000000, 60000, 8192)):
+for M, nnz, dmax, hub in ((70000, 900000, 30000, 2000), (300000, 3000000, 60000, 16384)):
     rp, col, st = graphgen.powerlaw_csr(M, nnz, alpha=2.0, dmax=dmax, seed=3)
     lens = np.diff(rp)
     print(f'graph {M} rows, {col.shape[0]} nnz, max row {lens.max()}, rows > {hub}: {(lens > hub).sum()}', flush=True)

@@ -168,7 +168,7 @@ constexpr int kPlanChMin = 64;        // ... and the shortest one it uses (small
 constexpr int kPlanSliceMin = 128;    // smallest row length that may be cut on the column grid
 constexpr int kPlanUnitMin = 16;      // smallest nnz-per-cell target of a cut row
 constexpr int kPlanCells = 128;       // finest column grid: 8 slices (one per XCD) x 16 cells
-constexpr int kHubChain = 8192;     // default hub threshold of the sum / mean launches (DGS_HUB_CHAIN; 0 = no hub chains)
+constexpr int kHubChain = 16384;    // default hub threshold of the sum / mean launches (DGS_HUB_CHAIN; 0 = no hub chains)
 constexpr int kHubChainMin = 1024;  // smallest threshold accepted (bounds the hub tables: nnz / 1024 rows)
 struct PlanLayout {
   int64_t max_units, max_long, max_hub;
@@ -1289,10 +1289,13 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
 
 // Hub threshold of the default sum / mean launches: rows longer than this are chained whole (spmm_hub_body) instead of being
 // folded by the fixed tree.  The reference's result is a sequential fp32 chain (include/cuda/spmm_cuda.cuh:27-47), whose own
-// rounding error grows like sqrt(len): on the headline graph it stays below 5e-6 of the exact sum up to 8192 nnz and reaches
-// 1.2e-5 on the 50 k-nnz rows (profiles/r04_chain_error_by_length.txt) - a tree that is closer to the exact sum than that is
-// further than 1e-5 from the REFERENCE there.  Above the threshold the chain is reproduced bit for bit; below it the tree is
-// within ~5e-6 of it (non-negative data; DGS_ALG_STRICT_SUM chains every row).
+// rounding error grows like sqrt(len): on the headline graph it stays below 6.3e-6 of the exact sum up to 16384 nnz (5 sigma
+// inside the bar), reaches 7.4e-6 at 16 - 32 k (3.8 sigma: not safe over thousands of elements) and 1.2e-5 on the 50 k-nnz rows
+// (profiles/r04_chain_error_by_length.txt) - a tree that is closer to the exact sum than that is further than 1e-5 from the
+// REFERENCE there.  Above the threshold the chain is reproduced bit for bit; below it the tree is within ~7e-6 of it
+// (non-negative data; DGS_ALG_STRICT_SUM chains every row).  Why not lower: a chain runs at ~3 - 5 ns per link, so a row of L
+// nnz is an L x 4 ns critical path - 16384 nnz are ~70 us, which a launch over millions of nnz hides, while the 9 - 13 k-nnz
+// hub of an arxiv-sized graph (a 48 us call) would not be.
 static inline int hub_threshold() {
   const int t = tune(tuning().hub_chain, kHubChain);
   if (t <= 0 || t > (1 << 24)) return INT_MAX;  // (the class bounds thub << c must stay inside an int)

@@ -15,8 +15,8 @@ all (dgsparse/spmm.py:5-28), so a plan must never cost a caller that uses a matr
 (DGS_PLAN_AFTER + 1)-th use, queued on the caller's stream without any host synchronisation (see _SharedPlan), and
 Storages over the same (rowptr, col) buffers share one plan.
 
-Reproducibility.  The plan-free and the planned schedule fold rows of 65 .. 8192 nnz with different (fixed) trees,
-so sum / mean of such rows can differ in the last bits between them (max / min, rows up to 64 nnz and the hub rows above 8192
+Reproducibility.  The plan-free and the planned schedule fold rows of 65 .. 16384 nnz with different (fixed) trees,
+so sum / mean of such rows can differ in the last bits between them (max / min, rows up to 64 nnz and the hub rows above 16384
 nnz are bit-identical on both).  The switch between the two is a pure function of the NUMBER of uses of the matrix - use
 DGS_PLAN_AFTER + 1 is the first planned one, whatever the timing (nothing is polled: the first planned use waits for four
 sums over the row lengths queued one use earlier, a few microseconds of GPU work) - so two runs of the same program agree

@@ -7,8 +7,8 @@ beyond some row length "within 1e-5 of the reference" and "accurate" part ways. 
 workload's shape (2^20 rows, power-law degrees, non-negative uniform values and features as in bench.py; CPU generator, so
 the numbers are statistics of that distribution, not of the GPU run's exact tensors): the oracle's sequential chains (mul + add
 and fmaf) against a float64 sum, rows longer than 256 nnz, binned by length.  It is what the hub threshold (DGS_HUB_CHAIN =
-8192) of the default sum / mean schedule was chosen from: below it the chain is within 4.7e-6 of the exact sum (the tree within
-~5e-7), above 3 10^4 nnz the chain itself leaves 1e-5.   python experiments/chain_error_by_length.py > profiles/r04_chain_error_by_length.txt
+16384) of the default sum / mean schedule was chosen from: below it the chain is within 6.3e-6 of the exact sum (the tree within
+~5e-7; 1e-5 is more than 5 sigma of the chain's error away), above 3 10^4 nnz the chain itself leaves 1e-5.   python experiments/chain_error_by_length.py > profiles/r04_chain_error_by_length.txt
 """
 import sys, time, numpy as np, torch
 import os

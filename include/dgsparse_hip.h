@@ -99,9 +99,9 @@ int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_
  *   rows of <= 64 nnz            that chain (fmaf), bit for bit
  *   rows of > hub threshold nnz  that chain (fmaf), bit for bit - the HUB rows, each worked by its own workgroups, chained by
  *                                one wave (16-byte lanes and >= 16 features; other shapes fold them like the rows in between)
- *   rows in between              a fixed reduction tree (deterministic, closer to the exact sum than the chain; within ~6e-6
+ *   rows in between              a fixed reduction tree (deterministic, closer to the exact sum than the chain; within ~7e-6
  *                                of the chain on non-negative data at the default threshold)
- * The threshold is DGS_HUB_CHAIN (default 8192, clamped to >= 1024, 0 = no hub chains: every row above 64 nnz takes the
+ * The threshold is DGS_HUB_CHAIN (default 16384, clamped to >= 1024, 0 = no hub chains: every row above 64 nnz takes the
  * tree); the chain's own rounding error grows like sqrt(nnz) and passes 1e-5 of the exact sum beyond ~3 10^4 nnz, which is
  * where a tree - however accurate - stops being within 1e-5 of the REFERENCE.  DGS_ALG_STRICT_SUM / _NOFMA chain every row.
  * dgs_spmm_hub_threshold() returns the threshold in force (0 = off).
@@ -127,7 +127,7 @@ typedef struct dgsSpmmPlanInfo {
   int32_t n_units;      /* entries of the unit table */
   int32_t n_long;       /* multi-unit rows */
   int32_t n_pslots;     /* partial rows a call needs in its workspace */
-  int32_t n_hub;        /* hub rows (longer than DGS_HUB_CHAIN = 8192 nnz): sum / mean chain them whole, see dgs_spmm_csr_f32 */
+  int32_t n_hub;        /* hub rows (longer than DGS_HUB_CHAIN = 16384 nnz): sum / mean chain them whole, see dgs_spmm_csr_f32 */
   int32_t tslice;       /* rows longer than this were cut at column-slice boundaries */
   int32_t xcd_start[9]; /* first unit of each XCD's share */
   int32_t off_long;     /* byte offset of the long-row table inside the plan buffer; 0 = the build-time layout */
