@@ -42,6 +42,9 @@ def main():
     ap.add_argument('--quick', action='store_true')
     ap.add_argument('--only', default='')
     ap.add_argument('--no-plan', action='store_true', help='plan-free calls only (default: cached locality plan where one applies)')
+    ap.add_argument('--cols', default='powerlaw', choices=['powerlaw', 'uniform', 'local'],
+                    help="column structure of the synthetic graphs: 'local' = community-like (columns in a window around the row id, a "
+                         "graph in a locality-preserving order), what the XCD-aware mappings and the plan's column slices are for")
     a = ap.parse_args()
     it = 20 if a.quick else 100
     cfgs = [  # (label, graph, op, feat)
@@ -66,7 +69,7 @@ def main():
         if gname not in cache:
             cache.clear()
             torch.cuda.empty_cache()
-            cache[gname] = graphgen.dataset_shaped(gname, seed=0, device='cuda', as_torch=True)
+            cache[gname] = graphgen.dataset_shaped(gname, seed=0, cols=a.cols, device='cuda', as_torch=True)
         rp, col, st = cache[gname]
         M, K, nnz = st['M'], st['K'], st['nnz']
         g = torch.Generator(device='cuda')
@@ -89,7 +92,7 @@ def main():
             sched = _capi.spmm_schedule(o, M, K, N, nnz) + ('+plan' if plan is not None else '')
             t = timeit(lambda: _capi.spmm(o, rp, col, val, X, plan=plan), iters=it)
             balg = 4 * (M + 1) + 8 * nnz + 4 * K * N + 4 * M * N * (2 if op in ('max', 'min') else 1)
-        print(json.dumps(dict(config=label, graph=gname, M=M, nnz=nnz, max_deg=st['max_deg'], op=op, feat=N, schedule=sched,
+        print(json.dumps(dict(config=label, graph=gname, cols=a.cols, M=M, nnz=nnz, max_deg=st['max_deg'], op=op, feat=N, schedule=sched,
                               us=round(t * 1e6, 2), gflops=round(2.0 * nnz * N / t / 1e9, 1),
                               alg_gbs=round(balg / t / 1e9, 1), frac=round(balg / t / 1e9 / PEAK, 4))), flush=True)
 

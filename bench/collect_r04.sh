@@ -27,3 +27,9 @@ timeout 400 bash bench/prof_pmc.sh $OUT/pmc_strict --no-dense --no-protocol --st
 timeout 300 python bench/bench_configs.py > $OUT/configs.jsonl 2>/dev/null
 timeout 900 python bench/mtx_bench.py --out $OUT/r04_mtx > $OUT/mtx_bench.txt 2>&1
 ls -la $OUT
+# the locality machinery on structured graphs (community-like columns) next to the random ones
+timeout 600 python bench/bench_configs.py --cols local > $OUT/configs_local.jsonl 2>/dev/null
+timeout 600 python bench.py --cols local --no-dense --no-protocol > $OUT/bench_line_cols_local.json 2>/dev/null
+DGS_SDDMM_FUSED=1 timeout 300 python bench/bench_configs.py --cols local --only SDDMM > $OUT/configs_local_sddmm_fused.jsonl 2>/dev/null
+DGS_SDDMM_FUSED=0 timeout 300 python bench/bench_configs.py --cols local --only SDDMM > $OUT/configs_local_sddmm_nnzbal.jsonl 2>/dev/null
+ls -la $OUT
