@@ -14,6 +14,15 @@ namespace dgs {
 // kernel's stale-variable behaviour).  Same schedule as the forward; the E pointer carries the saved arg ids (input).
 constexpr int kOpMaskSum = 4;
 
+// Dynamic LDS of the column-panel kernels.  (The only two hooks for tests/emu - the host-side wave64 emulation the CPU test
+// suite runs the kernels' control logic on: this declaration and store_vec_hidden below.  DGS_HOST_EMU is never defined in a
+// product build.)
+#ifndef DGS_HOST_EMU
+#define DGS_DYN_SHARED(name) extern __shared__ __align__(16) char name[]
+#else
+#define DGS_DYN_SHARED(name) extern char name[]
+#endif
+
 constexpr int kWave = 64;    // CDNA wavefront
 constexpr int kBlock = 256;  // 4 waves per workgroup, one per SIMD
 
@@ -230,6 +239,7 @@ __device__ __forceinline__ void store_vec_stream(int *p, const int (&o)[V]) {
   store_vec<V>(p, o);
 #endif
 }
+#ifndef DGS_HOST_EMU
 template <int V>
 __device__ __forceinline__ void store_vec_hidden(float *p, const float (&o)[V]) {
   if constexpr (V == 4) {
@@ -248,6 +258,12 @@ __device__ __forceinline__ void store_vec_hidden(int *p, const int (&o)[V]) {
     asm volatile("global_store_dword %0, %1, off" DGS_NT_SUFFIX "\n\ts_nop 1" ::"v"(p), "v"(o[0]) : "memory");
   }
 }
+#else  // host emulation (tests/emu): a store is a store
+template <int V>
+__device__ __forceinline__ void store_vec_hidden(float *p, const float (&o)[V]) { store_vec<V>(p, o); }
+template <int V>
+__device__ __forceinline__ void store_vec_hidden(int *p, const int (&o)[V]) { store_vec<V>(p, o); }
+#endif
 
 // Feature-dimension mapping shared by all row-group kernels: a row is covered by G lanes x V floats.
 struct FeatMap {

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kPanelBlock) void sddmm_panel(int M, int F, int ld,
   __shared__ unsigned short s_par[kSdVMax];
   __shared__ int s_wsum[kPW];
   __shared__ int s_ctr, s_nv;
-  extern __shared__ __align__(16) char sd_dyn[];
+  DGS_DYN_SHARED(sd_dyn);
   float *d1 = reinterpret_cast<float *>(sd_dyn);           // [R][F]
   int *em = reinterpret_cast<int *>(d1 + (size_t)R * F);    // [R][F] (MASK only)
 

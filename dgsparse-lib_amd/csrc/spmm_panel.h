@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kPanelBlock) void spmm_panel(int M, int N, int ld, 
   constexpr int V = 4;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
   __shared__ int s_ctr;
-  extern __shared__ __align__(16) char panel_dyn[];
+  DGS_DYN_SHARED(panel_dyn);
   float *acc = reinterpret_cast<float *>(panel_dyn);        // [R][N]
   unsigned short *acce = reinterpret_cast<unsigned short *>(acc + (size_t)R * N);  // [R][N] arg positions (max/min)
   // per-row state behind the accumulators (the whole 160 KiB is one budget: every row slot more is a row less to sweep

@@ -1,0 +1,125 @@
+"""TEST INFRASTRUCTURE ONLY: builds (once per source change) and loads tests/emu/_build/libdgs_emu.so - the kernels of
+dgsparse-lib_amd/csrc compiled as host code over the wave64 emulation of tests/emu/hip/hip_runtime.h - and wraps the C ABI
+for numpy arrays (host memory IS device memory here)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SUM, MAX, MIN, MEAN = 0, 1, 2, 3
+ALG_STRICT_SUM, ALG_STRICT_NOFMA = 0x200, 0x400
+_lib = None
+
+
+class PlanInfo(ctypes.Structure):
+    _fields_ = [('n_units', ctypes.c_int32), ('n_long', ctypes.c_int32), ('n_pslots', ctypes.c_int32), ('n_hub', ctypes.c_int32),
+                ('tslice', ctypes.c_int32), ('xcd_start', ctypes.c_int32 * 9), ('off_long', ctypes.c_int32),
+                ('off_hub', ctypes.c_int32)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        r = subprocess.run(['make', '-C', HERE, '-j8'], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('emu build failed:\n' + r.stdout[-3000:] + r.stderr[-3000:])
+        _lib = ctypes.CDLL(os.path.join(HERE, '_build', 'libdgs_emu.so'))
+        for f in ('dgs_spmm_csr_workspace_bytes', 'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes',
+                  'dgs_spmm_csr_plan_workspace_bytes', 'dgs_spmm_plan_compact_bytes'):
+            getattr(_lib, f).restype = ctypes.c_size_t
+    return _lib
+
+
+def _p(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+def _buf(nbytes):
+    return np.zeros(max(int(nbytes), 16) + 64, np.uint8)  # numpy's allocations are 64-byte aligned
+
+
+def set_env(**kw):
+    for k, v in kw.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+    lib().dgs_reload_tuning()
+
+
+def spmm(op, rp, col, val, X, algorithm=0, plan=None):
+    L = lib()
+    M, nnz, (K, N) = rp.size - 1, col.size, X.shape
+    C = np.full((M, N), np.nan, np.float32)
+    E = np.full((M, N), -7, np.int32) if op in (MAX, MIN) else None
+    i64 = ctypes.c_int64
+    if plan is not None:
+        pbuf, info = plan
+        wsb = L.dgs_spmm_csr_plan_workspace_bytes(op, i64(M), i64(N), i64(nnz), ctypes.byref(info))
+        ws = _buf(wsb)
+        rc = L.dgs_spmm_csr_plan_f32(op, i64(M), i64(K), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C), _p(E), _p(pbuf),
+                                     ctypes.byref(info), _p(ws), ctypes.c_size_t(wsb), None)
+    else:
+        wsb = L.dgs_spmm_csr_workspace_bytes(op, i64(M), i64(N), i64(nnz))
+        ws = _buf(wsb) if wsb else None
+        rc = L.dgs_spmm_csr_f32(op, i64(M), i64(K), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C), _p(E), int(algorithm),
+                                _p(ws), ctypes.c_size_t(wsb), None)
+    assert rc == 0, f'emu spmm rc={rc}'
+    return C, E
+
+
+def spmm_plan(rp, col, K, compact=True):
+    L = lib()
+    M, nnz = rp.size - 1, col.size
+    i64 = ctypes.c_int64
+    pb = L.dgs_spmm_plan_bytes(i64(M), i64(K), i64(nnz))
+    wb = L.dgs_spmm_plan_workspace_bytes(i64(M), i64(K), i64(nnz))
+    buf, ws = _buf(pb), _buf(wb)
+    info = PlanInfo()
+    rc = L.dgs_spmm_plan_build(i64(M), i64(K), i64(nnz), _p(rp), _p(col), _p(buf), ctypes.c_size_t(pb), _p(ws), ctypes.c_size_t(wb),
+                               ctypes.byref(info), None)
+    assert rc == 0, f'emu plan build rc={rc}'
+    if not compact:
+        return buf, info
+    cb = L.dgs_spmm_plan_compact_bytes(ctypes.byref(info))
+    small = _buf(cb)
+    rc = L.dgs_spmm_plan_compact(_p(buf), ctypes.byref(info), _p(small), ctypes.c_size_t(cb), i64(nnz), None)
+    assert rc == 0, f'emu plan compact rc={rc}'
+    return small, info
+
+
+def spmm_ex(op, rp, col, val, X, bias=None, row_scale=None, relu=False, plan=None, algorithm=0):
+    """dgs_spmm_csr_ex_f32: plan / info optional, fused epilogue."""
+    L = lib()
+    M, nnz, (K, N) = rp.size - 1, col.size, X.shape
+    C = np.full((M, N), np.nan, np.float32)
+    i64 = ctypes.c_int64
+    pbuf, info = plan if plan is not None else (None, None)
+    if plan is not None:
+        wsb = L.dgs_spmm_csr_plan_workspace_bytes(op, i64(M), i64(N), i64(nnz), ctypes.byref(info))
+    else:
+        wsb = L.dgs_spmm_csr_workspace_bytes(op, i64(M), i64(N), i64(nnz))
+    ws = _buf(wsb)
+    rc = L.dgs_spmm_csr_ex_f32(op, i64(M), i64(K), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C), None, int(algorithm),
+                               _p(bias), _p(row_scale), int(bool(relu)), _p(pbuf), ctypes.byref(info) if info is not None else None,
+                               _p(ws), ctypes.c_size_t(wsb), None)
+    assert rc == 0, f'emu spmm_ex rc={rc}'
+    return C
+
+
+def provisional_info(rp, t1=64, tslice=256):
+    L = lib()
+    deg = np.diff(rp).astype(np.int64)
+    info = PlanInfo()
+    i64 = ctypes.c_int64
+    rc = L.dgs_spmm_plan_provisional_info(i64(int(deg.sum())), i64(int((deg > t1).sum())), i64(int(deg[deg > t1].sum())),
+                                          i64(int((deg > tslice).sum())), i64(int(deg[deg > tslice].sum())), ctypes.byref(info))
+    assert rc == 0
+    return info
+
+
+def schedule(op, M, K, N, nnz):
+    i64 = ctypes.c_int64
+    return {0: 'small', 1: 'rows', 2: 'panel'}[lib().dgs_spmm_csr_schedule(op, i64(M), i64(K), i64(N), i64(nnz))]

@@ -1,0 +1,146 @@
+"""The kernels' CONTROL LOGIC on the CPU (no GPU needed): dgsparse-lib_amd/csrc compiled as host code over a wave64 emulation
+(tests/emu: every work-item a fiber, shuffles / ballots / barriers as rendezvous points, one workgroup at a time) and driven
+through the same C ABI as the HIP library, against the oracle.  What this catches: wrong unit / hub tables, wrong deals, index
+arithmetic, barrier protocols that do not match between role-specialised waves (reported as a deadlock with the waiting lanes),
+LDS hand-offs that rely on lockstep instead of a barrier.  What it cannot say: anything about speed, memory ordering on the real
+memory system, or compiler behaviour for gfx950 - the `-m gpu` tests remain the parity tests proper.
+
+The emulated library is test infrastructure: only this file loads it."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from util import assert_bitexact
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+import emu_lib as E  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not os.path.exists('/opt/rocm/lib/llvm/bin/clang++'), reason='the emulation builds with ROCm\'s clang')
+
+
+@pytest.fixture(scope='module')
+def graph():
+    """66 000 rows (the general schedule starts above 2^16 rows), almost all of them empty or tiny, plus every row class of the
+    schedules: 65 .. 256 nnz, cut rows, hub rows above the (lowered) hub threshold - one of them exactly one nnz above it."""
+    rng = np.random.default_rng(1)
+    M, K = 66000, 5000
+    deg = rng.integers(0, 3, M)
+    for r, d in ((100, 3000), (7000, 1500), (65000, 1100), (50000, 1025), (300, 200), (301, 70), (40000, 600), (12, 1024), (13, 65)):
+        deg[r] = d
+    rp = np.zeros(M + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    col = np.concatenate([np.sort(rng.choice(K, d, replace=False)) for d in deg]).astype(np.int32)
+    val = rng.random(col.size, dtype=np.float32)
+    return rp, col, val, K, deg
+
+
+@pytest.fixture(autouse=True)
+def tuning():
+    E.set_env(DGS_HUB_CHAIN=1024, DGS_NBU=8, DGS_STRICT_NBU=16, DGS_PANEL=None, DGS_PANEL_TLONG=None, DGS_PANEL_KB=None)
+    yield
+    E.set_env(DGS_HUB_CHAIN=None, DGS_NBU=None, DGS_STRICT_NBU=None, DGS_PANEL=None, DGS_PANEL_TLONG=None, DGS_PANEL_KB=None)
+
+
+def feats(K, N, seed=4):
+    return np.random.default_rng(seed).random((K, N), dtype=np.float32)
+
+
+@pytest.mark.parametrize('N', [64, 16, 48, 256])
+def test_default_sum_hub_rows_are_chains_plan_free_and_planned(graph, N):
+    rp, col, val, K, deg = graph
+    X = feats(K, N)
+    ref, _ = oracle.spmm('sum', rp, col, val, X, fma=True)
+    hub, short = deg > 1024, deg <= 64
+    assert E.schedule(E.SUM, rp.size - 1, K, N, col.size) == 'rows'
+    plan = E.spmm_plan(rp, col, K)
+    assert plan[1].n_hub == int(hub.sum()) == 4
+    for name, kw in (('plan-free', {}), ('planned', dict(plan=plan)), ('build buffer + provisional counts', None)):
+        if kw is None:
+            big, real = E.spmm_plan(rp, col, K, compact=False)
+            prov = E.provisional_info(rp)
+            assert prov.n_units >= real.n_units and prov.n_hub >= real.n_hub and prov.n_pslots >= real.n_pslots
+            kw = dict(plan=(big, prov))
+        C, _ = E.spmm(E.SUM, rp, col, val, X, **kw)
+        assert not np.isnan(C).any(), name + ': every output element is written'
+        assert_bitexact(C[hub], ref[hub], f'{name}: hub rows N={N}')
+        assert_bitexact(C[short], ref[short], f'{name}: rows up to 64 nnz N={N}')
+        assert (np.abs(C - ref) <= 1e-5 * np.abs(ref) + 1e-6).all(), name
+
+
+def test_hub_switch_off_and_mean_with_unit_weights(graph):
+    rp, col, val, K, deg = graph
+    X = feats(K, 64)
+    hub = deg > 1024
+    ref, _ = oracle.spmm('mean', rp, col, None, X, fma=True)
+    plan = E.spmm_plan(rp, col, K)
+    for kw in ({}, dict(plan=plan)):
+        C, _ = E.spmm(E.MEAN, rp, col, None, X, **kw)
+        assert_bitexact(C[hub], ref[hub], 'mean, unit weights: hub rows')
+        assert (np.abs(C - ref) <= 1e-5 * np.abs(ref) + 1e-6).all()
+    E.set_env(DGS_HUB_CHAIN=0)
+    refs, _ = oracle.spmm('sum', rp, col, val, X, fma=True)
+    for kw in ({}, dict(plan=plan)):  # the plan was built WITH hub rows: their units are walked again
+        C, _ = E.spmm(E.SUM, rp, col, val, X, **kw)
+        assert not np.array_equal(C[hub].view(np.int32), refs[hub].view(np.int32)), 'the tree is back'
+        assert (np.abs(C - refs) <= 1e-5 * np.abs(refs) + 1e-6).all()
+
+
+@pytest.mark.parametrize('N', [64, 48, 3])
+def test_strict_every_row_bit_exact(graph, N):
+    rp, col, val, K, deg = graph
+    X = feats(K, N) - 0.3
+    sval = val - 0.5
+    for alg, fma in ((E.ALG_STRICT_SUM, True), (E.ALG_STRICT_NOFMA, False)):
+        C, _ = E.spmm(E.SUM, rp, col, sval, X, algorithm=alg)
+        ref, _ = oracle.spmm('sum', rp, col, sval, X, fma=fma)
+        assert_bitexact(C, ref, f'strict N={N} fma={fma}')
+
+
+@pytest.mark.parametrize('red', ['max', 'min'])
+def test_max_min_over_a_plan_with_hub_rows(graph, red):
+    rp, col, val, K, deg = graph
+    X = (np.random.default_rng(9).integers(-2, 3, (K, 32)) / 4).astype(np.float32)  # ties and signs
+    tval = (np.random.default_rng(8).integers(0, 3, col.size) / 10).astype(np.float32)
+    plan = E.spmm_plan(rp, col, K)
+    Co, Eo = oracle.spmm(red, rp, col, tval, X, fma=True)
+    for kw in ({}, dict(plan=plan)):
+        C, Ee = E.spmm(getattr(E, red.upper()), rp, col, tval, X, **kw)
+        assert_bitexact(C, Co, red + ' values')
+        assert_bitexact(Ee, Eo, red + ' arg ids')
+
+
+def test_fused_epilogue_leaves_with_the_hub_rows(graph):
+    rp, col, val, K, deg = graph
+    X = feats(K, 64)
+    rng = np.random.default_rng(3)
+    bias = (rng.random(64, dtype=np.float32) - 0.5)
+    rs = rng.random(rp.size - 1, dtype=np.float32) + 0.5
+    plan = E.spmm_plan(rp, col, K)
+    for kw in ({}, dict(plan=plan)):
+        base, _ = E.spmm(E.SUM, rp, col, val, X, **kw)
+        got = E.spmm_ex(E.SUM, rp, col, val, X, bias=bias, row_scale=rs, relu=True, **kw)
+        want = np.maximum(base * rs[:, None] + bias[None, :], np.float32(0))
+        assert_bitexact(got, want, 'fused == unfused')
+
+
+def test_panel_schedule_chains_its_hub_rows():
+    rng = np.random.default_rng(5)
+    M, K, N = 600, 3000, 64
+    deg = rng.integers(350, 560, M)  # > 2^18 nnz in all: past the single-launch path
+    deg[17], deg[400] = 2800, 1900
+    rp = np.zeros(M + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    col = np.concatenate([np.sort(rng.choice(K, d, replace=False)) for d in deg]).astype(np.int32)
+    val = rng.random(col.size, dtype=np.float32)
+    X = feats(K, N)
+    E.set_env(DGS_PANEL=1, DGS_PANEL_TLONG=1200, DGS_PANEL_KB=64, DGS_HUB_CHAIN=1500)
+    if E.schedule(E.SUM, M, K, N, col.size) != 'panel':
+        pytest.skip('inputs this small take one launch whatever DGS_PANEL says')
+    C, _ = E.spmm(E.SUM, rp, col, val, X)
+    ref, _ = oracle.spmm('sum', rp, col, val, X, fma=True)
+    assert_bitexact(C[deg > 1500], ref[deg > 1500], 'panel schedule: hub rows')
+    assert_bitexact(C[deg <= 1200], ref[deg <= 1200], 'panel schedule: swept rows')
+    assert (np.abs(C - ref) <= 1e-5 * np.abs(ref) + 1e-6).all()
