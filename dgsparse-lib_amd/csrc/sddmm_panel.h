@@ -26,7 +26,11 @@ constexpr int kSdVMax = kPanelRMax;            // row slots per workgroup
 constexpr int kSdPanelBytes = 128 * 1024;      // LDS for the D1 (+E) rows (+ 22 KB of row tables = 150 KB)
 constexpr int kSdPU = 8;                       // D2-row gathers in flight per lane (fixed by the 8-way butterfly)
 
-__device__ int g_sddmm_arrivals;  // soft-barrier counter (zeroed by a memset node before every launch)
+__device__ int g_sddmm_arrivals;  // soft-barrier counter (zeroed by a memset node before every launch).  The one piece of
+// device-global state in the library (the SDDMM entry points have no workspace argument, like the reference's sddmm_cuda_csr):
+// two panel sweeps running CONCURRENTLY on different streams share it.  It is a speed hint only - the spin on it is bounded and
+// no result depends on it - and the sweep assumes the whole GPU to itself anyway (spmm_panel.h), so concurrent sweeps lose
+// lockstep, never correctness.
 
 template <int G, bool MEAN, bool MASK>
 __global__ __launch_bounds__(kPanelBlock) void sddmm_panel(int M, int F, int ld, int pass, int R, int tlong, int pcols,

@@ -40,7 +40,13 @@ def one_case(rng, it):
     kind = [None, 'tied', 'signed', 'uniform'][int(rng.integers(0, 4))]
     val = graphgen.weights(col.shape[0], kind, it) if kind else None
     X = (rng.integers(-3, 4, (K, N)) / 8).astype(np.float32)
-    tag = f'it={it} M={M} K={K} N={N} nnz={col.shape[0]} maxdeg={st["max_deg"]} val={kind}'
+    hubth = rng.choice(['', '1024', '2048', '0'])  # round 4: hub rows of the default sum / mean are chained above this length
+    if hubth:
+        os.environ['DGS_HUB_CHAIN'] = str(hubth)
+    else:
+        os.environ.pop('DGS_HUB_CHAIN', None)
+    capi.reload_tuning()
+    tag = f'it={it} M={M} K={K} N={N} nnz={col.shape[0]} maxdeg={st["max_deg"]} val={kind} hub={hubth or "default"}'
     if os.environ.get('FUZZ_VERBOSE'):
         print('case', tag, flush=True)
     drp, dcol, dval, dX = dev(rp), dev(col), (None if val is None else dev(val)), dev(X)
