@@ -15,6 +15,17 @@
 
 #include "hip/hip_runtime.h"
 
+// AddressSanitizer build (make ASAN=1): the fibers switch stacks behind the sanitizer's back, so every switch is announced
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#include <sanitizer/common_interface_defs.h>
+#define EMU_ASAN 1
+#endif
+#endif
+#ifndef EMU_ASAN
+#define EMU_ASAN 0
+#endif
+
 extern "C" void emu_switch(void **save_sp, void *load_sp);
 asm(R"(
 .text
@@ -56,9 +67,13 @@ struct Fiber {
   Item item;
   void *sp = nullptr;
   char *stack = nullptr;
+  void *fake = nullptr;  // ASAN: this fiber's fake-stack handle while it is switched out
   State st = DONE;
   int wave = 0, lane = 0;
 };
+void *sched_fake = nullptr;
+const void *sched_bottom = nullptr;
+size_t sched_size = 0;
 struct Wave {
   unsigned char buf[64][16], snap[64][16];
   unsigned long long live = 0, arrived = 0, snap_live = 0;
@@ -72,7 +87,16 @@ void (*k_fn)(void *) = nullptr;
 void *k_ctx = nullptr;
 int block_live = 0, block_arrived = 0;
 
-void yield() { emu_switch(&me->sp, sched_sp); }
+void yield() {
+  Fiber *f = me;
+#if EMU_ASAN
+  __sanitizer_start_switch_fiber(&f->fake, sched_bottom, sched_size);
+#endif
+  emu_switch(&f->sp, sched_sp);
+#if EMU_ASAN
+  __sanitizer_finish_switch_fiber(f->fake, nullptr, nullptr);
+#endif
+}
 
 void release_wave(Wave &w, int wi, State from) {
   for (int l = 0; l < 64; l++)
@@ -107,6 +131,9 @@ void try_release_block() {
 }
 
 extern "C" void emu_fiber_entry() {
+#if EMU_ASAN
+  __sanitizer_finish_switch_fiber(nullptr, &sched_bottom, &sched_size);
+#endif
   k_fn(k_ctx);
   Fiber *f = me;
   f->st = DONE;
@@ -115,6 +142,9 @@ extern "C" void emu_fiber_entry() {
   block_live--;
   try_release_wave(f->wave);
   try_release_block();
+#if EMU_ASAN
+  __sanitizer_start_switch_fiber(nullptr, sched_bottom, sched_size);  // this fiber ends here
+#endif
   emu_switch(&f->sp, sched_sp);
   abort();  // never resumed
 }
@@ -222,7 +252,13 @@ void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx) {
             ran = true;
             me = &f;
             cur = &f.item;
+#if EMU_ASAN
+            __sanitizer_start_switch_fiber(&sched_fake, f.stack, kStack);
+#endif
             emu_switch(&sched_sp, f.sp);
+#if EMU_ASAN
+            __sanitizer_finish_switch_fiber(sched_fake, nullptr, nullptr);
+#endif
             if (f.st == DONE) remaining--;
           }
           if (!ran) deadlock(dim3(bx, by, bz));
