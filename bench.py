@@ -338,6 +338,8 @@ def main():
         if a.reduce in ('sum', 'mean') and not strict_alg:
             th = _capi.hub_threshold()
             dg = (rp[1:] - rp[:-1]).long()
+            if th and N % 4 == 0 and N >= 16 and int((dg > th).sum()) > 0 and extra['schedule'].split('+')[0] != 'small':
+                extra['schedule'] += '+hub'
             extra['hub_chain'] = dict(threshold=th, rows=int((dg > th).sum()) if th else 0,
                                       nnz=int(dg[dg > th].sum()) if th else 0,
                                       note='rows above the threshold are one sequential fmaf chain per feature (like rows <= 64 '
@@ -420,11 +422,19 @@ def main():
     if os.path.exists(tf) and not use_dist:
         try:
             tj = json.load(open(tf))
-            key = f'{a.reduce}_feat{N}_{a.cols}' + ('_plan' if res.get('schedule', '').endswith('+plan') else '') + \
-                (f'_strict_{a.strict}' if a.strict else '')
+            sched_s = res.get('schedule', '')
+            key = f'{a.reduce}_feat{N}_{a.cols}' + ('_plan' if '+plan' in sched_s else '') + \
+                ('_hub' if '+hub' in sched_s else '') + (f'_strict_{a.strict}' if a.strict else '')
             if key in tj:
                 res['roofline']['traffic'] = tj[key]
                 res['roofline']['traffic_source'] = f"profiles/hbm_traffic.json[{key}] <- {tj.get('_source', {}).get(key, 'see profiles/README.md')}"
+                # the counters were collected in another process: say so when this run's call time is not the one they belong to
+                us0 = tj.get('_call_us', {}).get(key)
+                if us0:
+                    res['roofline']['traffic_call_us_at_collection'] = us0
+                    res['roofline']['traffic_stale'] = bool(abs(kern_s * 1e6 - us0) > 0.07 * us0)
+            else:
+                res['roofline']['traffic_source'] = f'no counter pass committed for this schedule yet (profiles/hbm_traffic.json has no key {key})' 
         except Exception:
             pass
 
