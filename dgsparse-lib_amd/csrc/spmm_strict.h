@@ -129,47 +129,40 @@ __device__ __forceinline__ void strict_row(const int p0, const int len, const in
       __builtin_amdgcn_wave_barrier();
       const int nh = (DGS_STRICT_DBG == 1 || DGS_STRICT_DBG == 3) ? 0 : min(NH, cnt - h * NH);
       if (CL == kWave || lane < CL) {
-        // the chain: one LDS read (x, and w beside it) + one fma per nnz.  Batches of CB steps, the reads of the next batch
-        // issued before the fmas of the current one, so the LDS latency is paid once per half round, not once per batch
+        // the chain: one LDS read (x, and w beside it) + one fma per nnz, through a rolling window of CB links: every read is
+        // issued (index clamped into the half round) and pinned where it is written, so the waits are counted.  (Round 3 kept
+        // two batches and prefetched the next one conditionally: the wait in front of the first fma, merged over both paths,
+        // then covered the prefetch as well - no overlap, ~20 clocks per link by the ISA.)
         constexpr int CB = 8;
         const float *xr = xb + lane * VP;
         auto rd = [&](int i, float (&xv)[VP], float &wv) {
           load_vec<VP>(xr + i * RS, xv);
           wv = WI ? xr[i * RS + W] : (HAS_VAL ? wb[i] : 1.0f);
         };
-        float xa[CB][VP], wa[CB], xn[CB][VP], wn2[CB];
-        auto rdb = [&](int i0, float (&xx)[CB][VP], float (&ww)[CB]) {
+        float xw[CB][VP], ww[CB];
 #pragma unroll
-          for (int u = 0; u < CB; u++) rd(i0 + u, xx[u], ww[u]);
-        };
-        auto fmab = [&](const float (&xx)[CB][VP], const float (&ww)[CB]) {
+        for (int u = 0; u < CB; u++) {
+          rd(min(u, NH - 1), xw[u], ww[u]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        int i = 0;
+        for (; i + CB <= nh; i += CB) {
 #pragma unroll
           for (int u = 0; u < CB; u++) {
 #pragma unroll
-            for (int v = 0; v < VP; v++) acc[v] = chain_step<FMA>(ww[u], xx[u][v], acc[v]);
-          }
-        };
-        int i = 0;
-        if (nh >= CB) {
-          // ping-pong between two register batches (no copies): per nnz one ds_read(2) and one fma
-          rdb(0, xa, wa);
-          while (true) {
-            if (i + 2 * CB <= nh) rdb(i + CB, xn, wn2);
-            fmab(xa, wa);
-            i += CB;
-            if (i + CB > nh) break;
-            if (i + 2 * CB <= nh) rdb(i + CB, xa, wa);
-            fmab(xn, wn2);
-            i += CB;
-            if (i + CB > nh) break;
+            for (int v = 0; v < VP; v++) acc[v] = chain_step<FMA>(ww[u], xw[u][v], acc[v]);
+            __builtin_amdgcn_sched_barrier(0);
+            rd(min(i + CB + u, NH - 1), xw[u], ww[u]);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
-        for (; i < nh; i++) {
-          float xv[VP], wv;
-          rd(i, xv, wv);
+        // the window holds links i .. i + CB - 1 already
 #pragma unroll
-          for (int v = 0; v < VP; v++) acc[v] = chain_step<FMA>(wv, xv[v], acc[v]);
-        }
+        for (int u = 0; u < CB; u++)
+          if (i + u < nh) {
+#pragma unroll
+            for (int v = 0; v < VP; v++) acc[v] = chain_step<FMA>(ww[u], xw[u][v], acc[v]);
+          }
       }
     }
   }
