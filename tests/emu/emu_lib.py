@@ -124,3 +124,51 @@ def provisional_info(rp, t1=64, tslice=256):
 def schedule(op, M, K, N, nnz):
     i64 = ctypes.c_int64
     return {0: 'small', 1: 'rows', 2: 'panel'}[lib().dgs_spmm_csr_schedule(op, i64(M), i64(K), i64(N), i64(nnz))]
+
+
+def sddmm(rp, col, D1, D2, mean=False, plan=None):
+    L = lib()
+    M, nnz, F, K = rp.size - 1, col.size, D1.shape[1], D2.shape[0]
+    out = np.full(nnz, np.nan, np.float32)
+    i64 = ctypes.c_int64
+    if plan is not None:
+        rc = L.dgs_sddmm_csr_plan_f32(MEAN if mean else SUM, i64(M), i64(K), i64(F), i64(nnz), _p(rp), _p(col), _p(D1), _p(D2), _p(out),
+                                      _p(plan[0]), ctypes.byref(plan[1]), None)
+    else:
+        rc = L.dgs_sddmm_csr_f32(MEAN if mean else SUM, i64(M), i64(K), i64(F), i64(nnz), _p(rp), _p(col), _p(D1), _p(D2), _p(out), None)
+    assert rc == 0, f'emu sddmm rc={rc}'
+    return out
+
+
+def csr2csc(rp, col, val, K):
+    L = lib()
+    L.dgs_csr2csc_workspace_bytes.restype = ctypes.c_size_t
+    M, nnz = rp.size - 1, col.size
+    i64 = ctypes.c_int64
+    wsb = L.dgs_csr2csc_workspace_bytes(i64(M), i64(K), i64(nnz))
+    ws = _buf(wsb)
+    colptr = np.full(K + 1, -1, np.int32)
+    row = np.full(nnz, -1, np.int32)
+    cval = np.full(nnz, np.nan, np.float32)
+    perm = np.full(nnz, -1, np.int32)
+    rc = L.dgs_csr2csc_i32(i64(M), i64(K), i64(nnz), _p(rp), _p(col), _p(val), _p(colptr), _p(row), _p(cval), _p(perm), _p(ws),
+                           ctypes.c_size_t(wsb), None)
+    assert rc == 0, f'emu csr2csc rc={rc}'
+    return colptr, row, cval, perm
+
+
+def spmm_acc(rp, col, val, X, C, rowmap=None, plan=None):
+    """C[rowmap[r]] += row r of A . X, in place."""
+    L = lib()
+    M, nnz, (K, N) = rp.size - 1, col.size, X.shape
+    i64 = ctypes.c_int64
+    if plan is not None:
+        wsb = L.dgs_spmm_csr_plan_workspace_bytes(SUM, i64(M), i64(N), i64(nnz), ctypes.byref(plan[1]))
+    else:
+        wsb = L.dgs_spmm_csr_workspace_bytes(SUM, i64(M), i64(N), i64(nnz))
+    ws = _buf(wsb)
+    rc = L.dgs_spmm_csr_acc_f32(i64(M), i64(K), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C), _p(rowmap),
+                                _p(plan[0]) if plan is not None else None, ctypes.byref(plan[1]) if plan is not None else None,
+                                _p(ws), ctypes.c_size_t(wsb), None)
+    assert rc == 0, f'emu spmm_acc rc={rc}'
+    return C

@@ -166,6 +166,28 @@ void start_fiber(Fiber &f) {
   f.st = RUN;
 }
 
+// Nothing can run.  Before calling it a deadlock: a wave in which SOME lanes wait at a collective while every other live lane
+// sits at a barrier is what divergence looks like on the hardware - e.g. lane groups with group-uniform loop bounds, the groups
+// that have more iterations shuffling among themselves while the others (exec-masked) are already past the loop.  Release the
+// collective for the lanes that arrived: the others count as inactive for it (ballot bit 0, undefined as a shuffle source).
+bool release_partial_collectives() {
+  bool any = false;
+  for (size_t wi = 0; wi < waves.size(); wi++) {
+    Wave &w = waves[wi];
+    unsigned long long at = 0;
+    for (int l = 0; l < 64 && wi * 64 + l < fibers.size(); l++)
+      if (fibers[wi * 64 + l].st == WAIT_WAVE) at |= 1ull << l;
+    if (!at) continue;
+    memcpy(w.snap, w.buf, sizeof(w.snap));
+    w.snap_live = at;
+    for (int l = 0; l < 64; l++)
+      if ((at >> l) & 1ull) fibers[wi * 64 + l].st = RUN;
+    w.arrived &= ~at;
+    any = true;
+  }
+  return any;
+}
+
 [[noreturn]] void deadlock(const dim3 &b) {
   fprintf(stderr, "emu: DEADLOCK in block (%u, %u): no work-item can run\n", b.x, b.y);
   const char *nm[] = {"run", "wave collective", "wave barrier", "workgroup barrier", "done"};
@@ -261,7 +283,7 @@ void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx) {
 #endif
             if (f.st == DONE) remaining--;
           }
-          if (!ran) deadlock(dim3(bx, by, bz));
+          if (!ran && !release_partial_collectives()) deadlock(dim3(bx, by, bz));
         }
       }
   cur = saved_cur;

@@ -144,3 +144,55 @@ def test_panel_schedule_chains_its_hub_rows():
     assert_bitexact(C[deg > 1500], ref[deg > 1500], 'panel schedule: hub rows')
     assert_bitexact(C[deg <= 1200], ref[deg <= 1200], 'panel schedule: swept rows')
     assert (np.abs(C - ref) <= 1e-5 * np.abs(ref) + 1e-6).all()
+
+
+def test_sddmm_plan_free_and_over_the_plan(graph):
+    """The nnz-balanced SDDMM and the fused row-block / unit SDDMM over the SpMM plan (forced: the dispatch rule would keep a
+    graph this sparse on the first) - hub-row units included: they are sorted behind each XCD's share and the SDDMM walks all."""
+    rp, col, val, K, deg = graph
+    F = 64
+    rng = np.random.default_rng(11)
+    D1 = (rng.integers(-3, 4, (rp.size - 1, F)) / 8).astype(np.float32)
+    D2 = (rng.integers(-3, 4, (K, F)) / 8).astype(np.float32)
+    plan = E.spmm_plan(rp, col, K)
+    for mean in (False, True):
+        want = oracle.sddmm(rp, col, D1, D2, reduce='mean' if mean else 'sum', fma=True)
+        got = E.sddmm(rp, col, D1, D2, mean=mean)
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-6), 'nnz-balanced'
+        E.set_env(DGS_SDDMM_FUSED=1)
+        got = E.sddmm(rp, col, D1, D2, mean=mean, plan=plan)
+        E.set_env(DGS_SDDMM_FUSED=None)
+        assert not np.isnan(got).any(), 'every nnz is written exactly once'
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-6), 'fused over the plan'
+
+
+def test_csr2csc_exact(graph):
+    rp, col, val, K, deg = graph
+    colptr, row, cval, perm = E.csr2csc(rp, col, val, K)
+    cp, r, cv, pm = oracle.csr2csc(rp, col, val, K)
+    assert_bitexact(colptr, cp)
+    assert_bitexact(row, r)
+    assert_bitexact(cval, cv)
+    assert_bitexact(perm, pm)
+
+
+def test_accumulating_sum_over_a_compact_row_subset(graph):
+    """dgs_spmm_csr_acc_f32 (the multi-GPU halo product): C[rowmap[r]] += row r; hub rows go through the tree there (no hub
+    chains in accumulating calls), plan-free and over a plan built WITH hub rows."""
+    rp, col, val, K, deg = graph
+    N = 32
+    X = feats(K, N)
+    M = rp.size - 1
+    rowmap = np.random.default_rng(2).permutation(M).astype(np.int32)
+    base = np.random.default_rng(3).random((M, N), dtype=np.float32)
+    ref64 = oracle.spmm_sum_f64(rp, col, val, X)
+    plan = E.spmm_plan(rp, col, K)
+    for kw in ({}, dict(plan=plan)):
+        C = base.copy()
+        E.spmm_acc(rp, col, val, X, C, rowmap=rowmap, **kw)
+        want = base.astype(np.float64)
+        want[rowmap] += ref64
+        touched = np.zeros(M, bool)
+        touched[rowmap[deg > 0]] = True
+        assert np.array_equal(C[~touched], base[~touched]), 'rows without entries are left alone'
+        assert (np.abs(C - want) <= 2e-6 * np.maximum(np.abs(want), 1.0) * 4).all()
