@@ -324,6 +324,23 @@ def main():
                 if a.reduce == 'mean':
                     ref = ref / (e0 - s0)
                 worst = max(worst, ((C[r].double() - ref).abs() / ref.abs().clamp_min(1e-6)).max().item())
+            if worst >= 1e-5 and _capi.hub_threshold() and not strict_alg:
+                # the hub chains (round 4) were verified on the CPU emulation only when this was written: if they misbehave on
+                # this box, say so in the line and time the schedule without them rather than lose the measurement
+                extra['hub_chain_fallback'] = f'self-check with hub chains on: rel err {worst:.3e}; DGS_HUB_CHAIN=0 for this run'
+                os.environ['DGS_HUB_CHAIN'] = '0'
+                _capi.reload_tuning()
+                step, planned = make_step(rp, col, val, X)
+                C, _ = step()
+                worst = 0.0
+                for r in sel.tolist()[-64:] + sel.tolist()[:256]:
+                    s0, e0 = int(rp[r]), int(rp[r + 1])
+                    if e0 == s0:
+                        continue
+                    ref = (val[s0:e0].double()[:, None] * X[col[s0:e0].long()].double()).sum(0)
+                    if a.reduce == 'mean':
+                        ref = ref / (e0 - s0)
+                    worst = max(worst, ((C[r].double() - ref).abs() / ref.abs().clamp_min(1e-6)).max().item())
             assert worst < 1e-5, f'bench self-check failed: rel err {worst}'
             extra['self_check_max_rel_err_vs_fp64'] = worst
         if a.reduce == 'sum' and not a.no_cpu_baseline:
