@@ -38,6 +38,8 @@ g.manual_seed(1)
 val = torch.rand(st['nnz'], generator=g, device='cuda')
 X = torch.rand((st['K'], N), generator=g, device='cuda')
 deg = (rp[1:] - rp[:-1]).long()
+# part 1: hub chains OFF, rows above `nocut` leave the column-slice order but keep the tree: the pure locality price
+os.environ['DGS_HUB_CHAIN'] = '0'
 for nocut in (0, 32768, 16384, 8192, 4096, 2048, 1024):
     if nocut:
         os.environ['DGS_PLAN_NOCUT'] = str(nocut)
@@ -48,3 +50,15 @@ for nocut in (0, 32768, 16384, 8192, 4096, 2048, 1024):
     ms = t(lambda: _capi.spmm(_capi.SUM, rp, col, val, X, plan=plan))
     m = deg > (nocut if nocut else 1 << 30)
     print(f'feat {N} nocut {nocut or "off"}: rows above {int(m.sum())}, nnz above {int(deg[m].sum())}: planned sum {ms:.4f} ms', flush=True)
+
+# part 2: hub chains at several thresholds (plan built per threshold; plan-free call beside it): what the chains cost in all
+os.environ.pop('DGS_PLAN_NOCUT', None)
+for th in (0, 32768, 16384, 8192, 4096, 2048):
+    os.environ['DGS_HUB_CHAIN'] = str(th)
+    _capi.reload_tuning()
+    plan = _capi.spmm_plan(rp, col, st['K'], N)
+    ms = t(lambda: _capi.spmm(_capi.SUM, rp, col, val, X, plan=plan))
+    ms0 = t(lambda: _capi.spmm(_capi.SUM, rp, col, val, X), n=50)
+    m = deg > (th if th else 1 << 30)
+    print(f'feat {N} hub chains above {th or "off"}: rows {int(m.sum())}, nnz {int(deg[m].sum())}, longest {int(deg.max())}: '
+          f'planned sum {ms:.4f} ms, plan-free {ms0:.4f} ms', flush=True)
