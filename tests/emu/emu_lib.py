@@ -172,3 +172,33 @@ def spmm_acc(rp, col, val, X, C, rowmap=None, plan=None):
                                 _p(ws), ctypes.c_size_t(wsb), None)
     assert rc == 0, f'emu spmm_acc rc={rc}'
     return C
+
+
+def spmm_acc_max(rp, col, val, X, C, Ei, rowmap, col_off, n_local, h_lo, plan=None):
+    L = lib()
+    M, nnz, (K, N) = rp.size - 1, col.size, X.shape
+    i64, i32 = ctypes.c_int64, ctypes.c_int32
+    if plan is not None:
+        wsb = L.dgs_spmm_csr_plan_workspace_bytes(MAX, i64(M), i64(N), i64(nnz), ctypes.byref(plan[1]))
+    else:
+        wsb = L.dgs_spmm_csr_workspace_bytes(MAX, i64(M), i64(N), i64(nnz))
+    ws = _buf(wsb)
+    rc = L.dgs_spmm_csr_acc_max_f32(i64(M), i64(K), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C), _p(Ei), _p(rowmap),
+                                    i32(col_off), i32(n_local), i32(h_lo), _p(plan[0]) if plan is not None else None,
+                                    ctypes.byref(plan[1]) if plan is not None else None, _p(ws), ctypes.c_size_t(wsb), None)
+    assert rc == 0, f'emu spmm_acc_max rc={rc}'
+
+
+def spmm_acc_min(rp, col, val, X, C, Ei, rowmap, col_off, precedes, plan=None):
+    L = lib()
+    M, nnz, (K, N) = rp.size - 1, col.size, X.shape
+    i64, i32 = ctypes.c_int64, ctypes.c_int32
+    if plan is not None:
+        wsb = L.dgs_spmm_csr_plan_workspace_bytes(MIN, i64(M), i64(N), i64(nnz), ctypes.byref(plan[1]))
+    else:
+        wsb = L.dgs_spmm_csr_workspace_bytes(MIN, i64(M), i64(N), i64(nnz))
+    ws = _buf(wsb)
+    rc = L.dgs_spmm_csr_acc_min_f32(i64(M), i64(K), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C), _p(Ei), _p(rowmap),
+                                    i32(col_off), i32(1 if precedes else 0), _p(plan[0]) if plan is not None else None,
+                                    ctypes.byref(plan[1]) if plan is not None else None, _p(ws), ctypes.c_size_t(wsb), None)
+    assert rc == 0, f'emu spmm_acc_min rc={rc}'

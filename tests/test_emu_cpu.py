@@ -196,3 +196,47 @@ def test_accumulating_sum_over_a_compact_row_subset(graph):
         touched[rowmap[deg > 0]] = True
         assert np.array_equal(C[~touched], base[~touched]), 'rows without entries are left alone'
         assert (np.abs(C - want) <= 2e-6 * np.maximum(np.abs(want), 1.0) * 4).all()
+
+
+@pytest.mark.parametrize('planned', [False, True], ids=['plan-free', 'plan'])
+def test_accumulating_max_and_min_merge_column_subsets_exactly(graph, planned):
+    """The multi-GPU merges (dgs_spmm_csr_acc_max_f32 / _acc_min_f32): columns split into "local" [a, b) and "halo" (slots in
+    global order, h_lo = a of them before the local ones); local product first, halo product(s) merged into (C, E); equal to
+    algorithm 0 on the undivided rows bit for bit, ties everywhere.  Min folds the lower-rank slots in FRONT of the local result
+    and the higher-rank ones BEHIND it (two calls)."""
+    rp, col, _, K, deg = graph
+    M, N = rp.size - 1, 16
+    a, b = K // 3, K // 3 + K // 4
+    nl, h_lo = b - a, a
+    val = (np.random.default_rng(3).integers(0, 3, col.size) / 10).astype(np.float32)
+    X = (np.random.default_rng(9).integers(-2, 3, (K, N)) / 4).astype(np.float32)
+    ext = np.where((col >= a) & (col < b), col - a, np.where(col < a, nl + col, col)).astype(np.int32)
+    Xe = np.ascontiguousarray(np.concatenate([X[a:b], X[:a], X[b:]]))
+    rows = np.repeat(np.arange(M), deg)
+
+    def sub(mask, shift, compact):
+        cnt = np.bincount(rows[mask], minlength=M)
+        keep = np.nonzero(cnt)[0] if compact else np.arange(M)
+        rpp = np.concatenate([[0], np.cumsum(cnt[keep])]).astype(np.int32)
+        return rpp, np.ascontiguousarray((ext[mask] - shift).astype(np.int32)), np.ascontiguousarray(val[mask]), keep.astype(np.int32)
+
+    is_loc = (col >= a) & (col < b)
+    lrp, lcol, lval, _ = sub(is_loc, 0, False)
+    Xl, Xh = np.ascontiguousarray(Xe[:nl]), np.ascontiguousarray(Xe[nl:])
+    # max: one merge of the whole halo
+    Co, Eo = oracle.spmm('max', rp, ext, val, Xe)
+    C, Ei = E.spmm(E.MAX, lrp, lcol, lval, Xl)
+    rrp, rcol, rval, rrows = sub(~is_loc, nl, True)
+    plan = E.spmm_plan(rrp, rcol, K - nl) if (planned and E.schedule(E.MAX, rrp.size - 1, K - nl, N, rcol.size) == 'rows') else None
+    E.spmm_acc_max(rrp, rcol, rval, Xh, C, Ei, rrows, nl, nl, h_lo, plan=plan)
+    assert_bitexact(C, Co, 'merged max values')
+    assert_bitexact(Ei, Eo, 'merged max arg ids')
+    # min: lower-rank slots (global columns < a) first, then the higher-rank ones
+    Co, Eo = oracle.spmm('min', rp, ext, val, Xe)
+    C, Ei = E.spmm(E.MIN, lrp, lcol, lval, Xl)
+    for mask, first in ((col < a, True), (col >= b, False)):
+        prp, pcol, pval, prow = sub(mask, nl, True)
+        if pcol.size:
+            E.spmm_acc_min(prp, pcol, pval, Xh, C, Ei, prow, nl, first)
+    assert_bitexact(C, Co, 'merged min values')
+    assert_bitexact(Ei, Eo, 'merged min arg ids')
