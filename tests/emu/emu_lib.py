@@ -23,6 +23,13 @@ def lib():
     global _lib
     if _lib is None:
         asan = os.environ.get('DGS_EMU_ASAN') == '1'  # tests/emu/run_asan.sh: the sanitizer's runtime must be preloaded
+        alt = os.environ.get('DGS_EMU_LIB')  # tests/emu/mutation_check.py: a library built from deliberately broken sources
+        if alt:
+            _lib = ctypes.CDLL(alt)
+            for f in ('dgs_spmm_csr_workspace_bytes', 'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes',
+                      'dgs_spmm_csr_plan_workspace_bytes', 'dgs_spmm_plan_compact_bytes'):
+                getattr(_lib, f).restype = ctypes.c_size_t
+            return _lib
         r = subprocess.run(['make', '-C', HERE, '-j8'] + (['ASAN=1'] if asan else []), capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('emu build failed:\n' + r.stdout[-3000:] + r.stderr[-3000:])

@@ -11,6 +11,7 @@
 #include <string.h>
 #include <sys/mman.h>
 
+#include <utility>
 #include <vector>
 
 #include "hip/hip_runtime.h"
@@ -86,6 +87,60 @@ Fiber *me = nullptr;
 void (*k_fn)(void *) = nullptr;
 void *k_ctx = nullptr;
 int block_live = 0, block_arrived = 0;
+
+// The order in which the runnable work-items of a workgroup get their turn.  Between two rendezvous points a fiber runs
+// undisturbed, so a missing barrier BETWEEN waves only shows when the reader happens to run before the writer (RAW) or the
+// over-writer before the reader (WAR): one fixed order hides one of the two.  DGS_EMU_ORDER = fwd (default: ascending
+// work-item id) | rev | rand:<seed> (a fresh permutation of the waves and of the lanes in each wave for every sweep).
+enum Order { FWD, REV, RAND };
+Order order_mode = FWD;
+unsigned long long order_state = 1;
+bool order_read = false;
+std::vector<unsigned> order_buf;
+unsigned order_next(unsigned n) {  // xorshift64*: deterministic for a seed
+  order_state ^= order_state >> 12;
+  order_state ^= order_state << 25;
+  order_state ^= order_state >> 27;
+  return (unsigned)(((order_state * 2685821657736338717ull) >> 33) % n);
+}
+void order_init() {
+  if (order_read) return;
+  order_read = true;
+  const char *e = getenv("DGS_EMU_ORDER");
+  if (!e || !*e || !strcmp(e, "fwd")) return;
+  if (!strcmp(e, "rev")) order_mode = REV;
+  else if (!strncmp(e, "rand:", 5)) {
+    order_mode = RAND;
+    order_state = strtoull(e + 5, nullptr, 10) * 0x9e3779b97f4a7c15ull + 0x1234567ull;
+    if (!order_state) order_state = 1;
+  } else {
+    fprintf(stderr, "emu: DGS_EMU_ORDER=%s (fwd | rev | rand:<seed>)\n", e);
+    abort();
+  }
+}
+const std::vector<unsigned> &sweep_order(unsigned nthr) {
+  if (order_buf.size() != nthr || order_mode == RAND) {
+    order_buf.resize(nthr);
+    for (unsigned t = 0; t < nthr; t++) order_buf[t] = order_mode == REV ? nthr - 1 - t : t;
+  }
+  if (order_mode == RAND) {
+    const unsigned nw = (nthr + 63) / 64;
+    // waves first (Fisher-Yates over whole waves), then the lanes inside each wave
+    for (unsigned w = nw; w > 1; w--) {
+      const unsigned o = order_next(w);
+      if (o != w - 1)
+        for (unsigned l = 0; l < 64; l++) {
+          const unsigned a = (w - 1) * 64 + l, b = o * 64 + l;
+          if (a < nthr && b < nthr) std::swap(order_buf[a], order_buf[b]);
+        }
+    }
+    for (unsigned w = 0; w < nw; w++) {
+      const unsigned n = min(64u, nthr - w * 64);
+      for (unsigned l = n; l > 1; l--) std::swap(order_buf[w * 64 + l - 1], order_buf[w * 64 + order_next(l)]);
+    }
+  }
+  return order_buf;
+}
 
 void yield() {
   Fiber *f = me;
@@ -241,6 +296,7 @@ void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx) {
     fprintf(stderr, "emu: block shape %u x %u x %u\n", block.x, block.y, block.z);
     abort();
   }
+  order_init();
   if (fibers.size() < nthr) fibers.resize(nthr);
   const unsigned nw = (nthr + 63) / 64;
   k_fn = fn;
@@ -268,8 +324,9 @@ void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx) {
         int remaining = (int)nthr;
         while (remaining > 0) {
           bool ran = false;
-          for (unsigned t = 0; t < nthr; t++) {
-            Fiber &f = fibers[t];
+          const std::vector<unsigned> &ord = sweep_order(nthr);
+          for (unsigned i = 0; i < nthr; i++) {
+            Fiber &f = fibers[ord[i]];
             if (f.st != RUN) continue;
             ran = true;
             me = &f;

@@ -240,3 +240,19 @@ def test_accumulating_max_and_min_merge_column_subsets_exactly(graph, planned):
             E.spmm_acc_min(prp, pcol, pval, Xh, C, Ei, prow, nl, first)
     assert_bitexact(C, Co, 'merged min values')
     assert_bitexact(Ei, Eo, 'merged min arg ids')
+
+
+@pytest.mark.parametrize('order', ['rev', 'rand:7'])
+def test_hub_rows_under_other_fiber_schedules(order):
+    """Between two barriers a fiber runs undisturbed, so ONE fixed fiber order can hide a missing barrier between waves (the
+    reader always before the over-writer, say).  The hub workgroup's tile hand-off again with the work-items taking their turns
+    in reverse and in a random order (tests/emu/emu_rt.cpp: DGS_EMU_ORDER, read once per process: hence the subprocess);
+    tests/emu/mutation_check.py shows that every barrier pair of that workgroup, when removed, is noticed."""
+    import subprocess
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    import mutation_check as MC
+    E.lib()  # built
+    env = dict(os.environ, DGS_EMU_ORDER=order)
+    p = subprocess.run([sys.executable, '-c', MC.RUN % dict(root=MC.ROOT, here=MC.HERE)], capture_output=True, text=True, env=env,
+                       timeout=1200)
+    assert p.returncode == 0 and 'BAD 0' in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
