@@ -783,7 +783,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
       int2 cv[kU1];
       float x[kU1][V];
       int mk[kU1][V];
-      const int *El = E + (fl ? f0 : 0);
+      const int *El = OP == kOpMaskSum ? E + (fl ? f0 : 0) : nullptr;
 #pragma unroll
       for (int u = 0; u < kU1; u++) {
         cv[u] = tile[min(ps + u, last)];

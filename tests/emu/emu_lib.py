@@ -30,10 +30,12 @@ def lib():
                       'dgs_spmm_csr_plan_workspace_bytes', 'dgs_spmm_plan_compact_bytes'):
                 getattr(_lib, f).restype = ctypes.c_size_t
             return _lib
-        r = subprocess.run(['make', '-C', HERE, '-j8'] + (['ASAN=1'] if asan else []), capture_output=True, text=True)
+        ubsan = os.environ.get('DGS_EMU_UBSAN') == '1'
+        r = subprocess.run(['make', '-C', HERE, '-j8'] + (['ASAN=1'] if asan else ['UBSAN=1'] if ubsan else []), capture_output=True,
+                           text=True)
         if r.returncode != 0:
             raise RuntimeError('emu build failed:\n' + r.stdout[-3000:] + r.stderr[-3000:])
-        _lib = ctypes.CDLL(os.path.join(HERE, '_build_asan' if asan else '_build', 'libdgs_emu.so'))
+        _lib = ctypes.CDLL(os.path.join(HERE, '_build_asan' if asan else '_build_ubsan' if ubsan else '_build', 'libdgs_emu.so'))
         for f in ('dgs_spmm_csr_workspace_bytes', 'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes',
                   'dgs_spmm_csr_plan_workspace_bytes', 'dgs_spmm_plan_compact_bytes'):
             getattr(_lib, f).restype = ctypes.c_size_t
