@@ -54,8 +54,11 @@ struct StrictLds {
 constexpr int strict_smid(int G) { return G < 4 ? G : 4; }
 // hub rows: feature tiles of >= 16 floats with 16-byte lanes are cut into slices of >= 16 floats (4 slices from 64 floats on), each worked by a whole workgroup
 // (strict_hub_coop: four waves gather, one chains); narrower tiles into up to 16 wave-level slices
-constexpr bool strict_coop(int G, int V) { return V == 4 && G >= 4; }
-constexpr int strict_shub(int G, int V) { return strict_coop(G, V) ? (G >= 16 ? 4 : G / 4) : (G < 16 ? G : 16); }
+constexpr bool strict_coop(int G, int V) { return DGS_HUB_COOP_V2 ? true : (V == 4 && G >= 4); }  // (the round-3 workgroup: 16-byte lanes only)
+// lanes of a feature slice: 16 floats per slice where the tile has them (one ds_read_b128 of x feeds four links of 16 chains),
+// a quarter of the tile for the wide ones
+constexpr int strict_hub_gp(int G, int V) { return V == 4 ? (G >= 16 ? G / 4 : (G >= 4 ? 4 : G)) : (G >= 16 ? 16 : G); }
+constexpr int strict_shub(int G, int V) { return strict_coop(G, V) ? G / strict_hub_gp(G, V) : (G < 16 ? G : 16); }
 
 // One wave, one feature slice [fbase, fbase + GP*V) of one row [p0, p0+len): returns the chain results in the CHAIN
 // layout: lane c < CL holds features fbase + c*VP .. + VP-1 (VP = 1 unless the slice is wider than 64 floats).
@@ -207,14 +210,20 @@ __device__ __forceinline__ void strict_unit(const int row, const int p0, const i
 // ~11 clocks per link.  The window below is straight-line - every read is issued, its index clamped into the tile - and
 // rolls four b128 pairs (16 links) ahead of the fmas.
 constexpr int kHubBlockFloats = 7008;  // what strict_hub_coop needs at most (16 x 388 + 2 x 384 + 16): 28 KB, 5 workgroups per CU
-template <int GP, bool MEAN, bool HAS_VAL, bool FMA, int LDSF = kStrictBlockFloats>
+constexpr int strict_hub_lds(int V, int GP, int us) {  // floats of LDS of one workgroup phase with `us` gathers per lane and set
+  return GP * V * (3 * us * (kWave / GP) + 4) + 2 * 3 * us * (kWave / GP) + 16;
+}
+template <int V, int GP, bool MEAN, bool HAS_VAL, bool FMA, int LDSF = kStrictBlockFloats>
 __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, const int len, const int tbase, const int sl,
                                                 const int N, const int *__restrict__ col, const float *__restrict__ val,
                                                 const float *__restrict__ B, float *__restrict__ C, float *lds,
                                                 const Epi &epi = Epi{}) {
-  constexpr int V = 4, NWG = kBlock / kWave - 1;  // gather waves (wave 0 chains and does nothing else)
+  constexpr int NWG = kBlock / kWave - 1;       // gather waves (wave 0 chains and does nothing else)
   constexpr int NGP = kWave / GP, W = GP * V;   // nnz per load instruction; floats (= chain lanes) of the slice
-  constexpr int NWV = kUS * NGP;                // nnz per gather wave and phase
+  // gathers per lane and set: kUS where the tile then fits the launch's LDS (every shape the headline runs), half of it for the
+  // narrow tiles whose 64 / GP rows per instruction make the phase long (N = 4, 8)
+  constexpr int US = strict_hub_lds(V, GP, kUS) <= LDSF ? kUS : kUS / 2;
+  constexpr int NWV = US * NGP;                 // nnz per gather wave and phase
   constexpr int NRB = NWG * NWV;                // nnz per workgroup phase
   constexpr int LD = NRB + 4;                   // row pitch of the feature-major tile: conflict-free ds_read_b128 across lanes
   static_assert(W * LD + 2 * NRB + 16 <= LDSF && W <= kWave && NRB % 16 == 0, "strict_hub_coop LDS");
@@ -289,7 +298,7 @@ __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, con
   constexpr int NGT = NWG * kWave;           // CPT entries per gather thread, and handed round through LDS (ct / wt)
   constexpr int CPT = (NRB + NGT - 1) / NGT;
   constexpr bool CFULL = NRB % NGT == 0;     // (256-float tiles: 96 nnz per phase, half of the gather threads carry an entry)
-  float xa[kUS][V], xb[kUS][V];  // the two gather sets (even / odd phases)
+  float xa[US][V], xb[US][V];  // the two gather sets (even / odd phases)
   int cv[CPT];                   // columns of the phase whose gathers are issued NEXT (two phases ahead of the chain)
   float wv[CPT];                 // weights of the phase written NEXT
   // slots past the end of the row repeat its last nnz (never chained)
@@ -306,18 +315,18 @@ __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, con
     for (int k = 0; k < CPT; k++)
       if (CFULL || k * NGT + gt < NRB) ct[k * NGT + gt] = cv[k];
   };
-  auto issue = [&](float (&x)[kUS][V]) {
-    int c[kUS];
+  auto issue = [&](float (&x)[US][V]) {
+    int c[US];
 #pragma unroll
-    for (int q = 0; q < kUS; q++) c[q] = ct[mine + q * NGP];
+    for (int q = 0; q < US; q++) c[q] = ct[mine + q * NGP];
 #pragma unroll
-    for (int q = 0; q < kUS; q++) load_vec_gather<V>(Bl + (int64_t)c[q] * N, x[q]);
+    for (int q = 0; q < US; q++) load_vec_gather<V>(Bl + (int64_t)c[q] * N, x[q]);
   };
   // Loads return in order, so whatever a phase waits for must be OLDER than the gathers it wants to keep in flight: the
   // (col, val) entries a phase needs were requested one phase earlier, BEFORE that phase's gathers.
-  auto phase = [&](const int ph, float (&x)[kUS][V]) {
+  auto phase = [&](const int ph, float (&x)[US][V]) {
 #pragma unroll
-    for (int q = 0; q < kUS; q++) {
+    for (int q = 0; q < US; q++) {
       const int i = mine + q * NGP;
 #pragma unroll
       for (int v = 0; v < V; v++) xt[(lp * V + v) * LD + i] = x[q][v];
@@ -513,7 +522,7 @@ __device__ __forceinline__ int spmm_hub_body(int bid, int nblocks, float *ldsf, 
       strict_deal(ha.cnt[c], SH, x, nx, sb, SPB, rotb, [&](int g, int j) {
         const int4 d = ha.rows[ha.ht.base[c] + g];
 #if DGS_HUB_COOP_V2
-        strict_hub_coop<G / SH, MEAN, HAS_VAL, FMA, LDSF>(d.x, d.y, d.z, tbase, j, N, col, val, B, C, ldsf, epi);
+        strict_hub_coop<V, G / SH, MEAN, HAS_VAL, FMA, LDSF>(d.x, d.y, d.z, tbase, j, N, col, val, B, C, ldsf, epi);
 #else
         static_assert(LDSF >= kStrictBlockFloats, "the round-3 hub workgroup needs the strict launch's LDS");
         strict_hub_coop_v1<G / SH, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, j, N, col, val, B, C, ldsf, epi);

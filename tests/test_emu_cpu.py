@@ -48,7 +48,7 @@ def feats(K, N, seed=4):
     return np.random.default_rng(seed).random((K, N), dtype=np.float32)
 
 
-@pytest.mark.parametrize('N', [64, 16, 48, 256])
+@pytest.mark.parametrize('N', [64, 16, 48, 256, 41, 8, 7, 1])  # 16-byte lanes (N % 4 == 0) and scalar ones, down to one feature
 def test_default_sum_hub_rows_are_chains_plan_free_and_planned(graph, N):
     rp, col, val, K, deg = graph
     X = feats(K, N)

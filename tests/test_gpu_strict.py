@@ -155,13 +155,14 @@ def _default(capi, op, rp, col, val, X, plan=False, **kw):
     return C.cpu().numpy(), pl
 
 
-@pytest.mark.parametrize('N', [16, 32, 64, 128, 256, 48, 384])
+@pytest.mark.parametrize('N', [16, 32, 64, 128, 256, 48, 384, 41, 100, 8, 4, 7, 1])
 @pytest.mark.parametrize('plan', [False, True], ids=['plan-free', 'plan'])
 def test_default_sum_chains_the_hub_rows(capi, monkeypatch, N, plan):
     """Rows above the hub threshold are ONE fmaf chain per feature in the default schedule too - bit for bit the oracle's
     sequential chain, like the rows up to 64 nnz; the rows in between keep the fixed tree (1e-5).  Plan-free (hub table from
     the classify pass) and planned (hub table of the plan, the hub rows' units skipped), every 16-byte feature mapping,
-    widths that leave a slice partly or wholly empty (48) and several feature tiles (384)."""
+    widths that leave a slice partly or wholly empty (48), several feature tiles (384), scalar lanes (41, 7, 1) and the narrow
+    tiles whose hub workgroup runs the shorter gather sets (4, 8)."""
     monkeypatch.setenv('DGS_HUB_CHAIN', '1024')
     rp, col, st = graphgen.powerlaw_csr(70000, 900000, alpha=1.9, dmax=20000, seed=21)
     lens = np.diff(rp)
