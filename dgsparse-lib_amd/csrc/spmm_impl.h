@@ -625,14 +625,16 @@ __device__ __forceinline__ void acc_commit(float *__restrict__ C, int *__restric
 // halo product of dgsparse.dist adds into the rows that have remote entries); rows without entries are left alone.
 // STRICT (spmm_strict.h; sum / mean only): 0 = default; 1 = every row one sequential fmaf chain; 2 = the same without
 // contraction.  Here it only changes the arithmetic of the (already sequential) short rows and, in the single-launch
-// kernel, sends the long rows through strict_unit instead of the wave-cooperative tree.
+// kernel, sends the long rows through strict_unit instead of the wave-cooperative tree.  3 = the default arithmetic, the single-launch
+// kernel's rows above `thub` nnz skipped and reported in `hubmask` (two words per wave; spmm_small_hub chains them).
 template <int G, int V, int OP, bool HAS_VAL, bool INLINE, bool ACC = false, int STRICT = 0>
 __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, int M, int N,
                                                const int *__restrict__ rowptr,
                                                const int *__restrict__ col, const float *__restrict__ val,
                                                const float *__restrict__ B, float *__restrict__ C,
                                                int *__restrict__ E, const AccArg aa = AccArg{},
-                                               float *strict_xb = nullptr) {
+                                               float *strict_xb = nullptr, const int thub = INT_MAX,
+                                               unsigned *hubmask = nullptr) {
   static_assert(!ACC || OP == DGS_SUM || OP == DGS_MAX || OP == DGS_MIN, "accumulation exists for sum, max and min");
   static_assert(STRICT == 0 || ((OP == DGS_SUM || OP == DGS_MEAN) && !ACC), "strict order exists for plain sum and mean");
   const int *rowmap = aa.rowmap;
@@ -852,10 +854,16 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
     const int r = __ffsll((long long)med) - 1;
     med &= med - 1;
     const int rs = __shfl(s_i, r, 64), re = __shfl(e_i, r, 64);
-    if constexpr (STRICT != 0) {
+    if constexpr (STRICT == 1 || STRICT == 2) {
       strict_unit<V, G, OP == DGS_MEAN, HAS_VAL, STRICT != 2>(r0 + r, rs, re - rs, blockIdx.y * G * V, 0, lane, N, col, val, B,
                                                              C, strict_xb);
       continue;
+    }
+    if constexpr (STRICT == 3) {
+      if (re - rs > thub) {  // wave-uniform: left to the workgroup (spmm_small_hub), bit = row inside this wave's range
+        if (lane == 0) hubmask[wave * 2 + (r >> 5)] = hubmask[wave * 2 + (r >> 5)] | (1u << (r & 31));
+        continue;
+      }
     }
     float acc[V];
     int ei[V], ep[V], el[V];
@@ -1078,6 +1086,43 @@ __global__ __launch_bounds__(kBlock, 4) void spmm_fused_strict(int M, int N, int
     if (rb < per * 8) rb = (rb % 8) * per + rb / 8;
 #endif
     spmm_rows_body<G, V, OP, HAS_VAL, false, false, STRICT>(rb, rpw, lds.r, M, N, rowptr, col, val, B, C, nullptr);
+  }
+}
+
+// The single-launch kernel for inputs that CAN hold a row above the hub threshold (nnz > threshold; sum / mean).  The row waves
+// skip such rows and leave their positions in a mask; when all four waves are through, the workgroup chains each of them
+// - slice after slice of the feature tile - as the hub workgroup of the general schedule does (strict_hub_coop: three waves
+// gather, one chains), in the LDS the row stream no longer needs.  28 KB and the fused HUB kernel's register budget instead
+// of 20.5 KB: the inputs below the threshold keep spmm_small as it was.
+template <int G, int V, int OP, bool HAS_VAL>
+__global__ __launch_bounds__(kBlock) void spmm_small_hub(int M, int N, int rpw, int thub, const int *__restrict__ rowptr,
+                                                         const int *__restrict__ col, const float *__restrict__ val,
+                                                         const float *__restrict__ B, float *__restrict__ C, const AccArg aa) {
+  __shared__ union U {
+    RowsLds r;
+    HubLds h;
+    __device__ U() {}
+  } lds;
+  __shared__ unsigned hubmask[2 * (kBlock / kWave)];
+  if (threadIdx.x < 2 * (kBlock / kWave)) hubmask[threadIdx.x] = 0u;
+  __syncthreads();
+  spmm_rows_body<G, V, OP, HAS_VAL, true, false, 3>(blockIdx.x, rpw, lds.r, M, N, rowptr, col, val, B, C, nullptr, aa, nullptr, thub,
+                                                    hubmask);
+  __syncthreads();  // every wave has left the row stream's LDS; the mask is complete
+  constexpr int SH = strict_shub(G, V);
+#pragma unroll 1
+  for (int w = 0; w < 2 * (kBlock / kWave); w++) {
+    unsigned m = hubmask[w];  // (block-uniform)
+    while (m) {
+      const int b = __ffs((int)m) - 1;
+      m &= m - 1;
+      const int row = (blockIdx.x * (kBlock / kWave) + (w >> 1)) * rpw + (w & 1) * 32 + b;
+      const int rs = rowptr[row], len = rowptr[row + 1] - rs;
+#pragma unroll 1
+      for (int j = 0; j < SH; j++)
+        strict_hub_coop<V, G / SH, OP == DGS_MEAN, HAS_VAL, true, kHubBlockFloats>(row, rs, len, blockIdx.y * G * V, j, N, col, val, B,
+                                                                               C, lds.h.f, aa.epi);
+    }
   }
 }
 
@@ -1382,6 +1427,14 @@ static int launch_impl(const SpmmArgs &a) {
     while (rpw > NGc && rpw > 4 && (a.M + rpw - 1) / rpw < 2048) rpw >>= 1;
     const int rpb = (kBlock / kWave) * rpw;
     const dim3 grid((unsigned)((a.M + rpb - 1) / rpb), (unsigned)a.tiles);
+    if constexpr (hub_ok<OP, V, G, ACC>()) {
+      const int thub = hub_threshold();
+      if (a.nnz > thub) {  // (a row above the threshold needs that many nnz to begin with)
+        hipLaunchKernelGGL((spmm_small_hub<G, V, OP, HAS_VAL>), grid, dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, rpw, thub,
+                           a.rowptr, a.col, a.val, a.B, a.C, a.acc);
+        return check_launch();
+      }
+    }
     hipLaunchKernelGGL((spmm_small<G, V, OP, HAS_VAL, ACC>), grid, dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, rpw,
                        a.rowptr, a.col, a.val, a.B, a.C, a.E, a.acc);
     return check_launch();

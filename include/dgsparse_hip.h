@@ -98,8 +98,7 @@ int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_
  * include/cuda/spmm_cuda.cuh:27-47, host twin example/util/sp_util.hpp:73-83):
  *   rows of <= 64 nnz            that chain (fmaf), bit for bit
  *   rows of > hub threshold nnz  that chain (fmaf), bit for bit - the HUB rows, each worked by its own workgroups, chained by
- *                                one wave (every feature width; the one exception: inputs of <= 2^18 nnz and <= 2^16 rows
- *                                run as ONE launch and fold such a row - >= 6 % of the matrix - like the rows in between)
+ *                                one wave (every feature width and every schedule: general, column-panel, single-launch)
  *   rows in between              a fixed reduction tree (deterministic, closer to the exact sum than the chain; within ~7e-6
  *                                of the chain on non-negative data at the default threshold)
  * The threshold is DGS_HUB_CHAIN (default 16384, clamped to >= 1024, 0 = no hub chains: every row above 64 nnz takes the

@@ -256,3 +256,40 @@ def test_hub_rows_under_other_fiber_schedules(order):
     p = subprocess.run([sys.executable, '-c', MC.RUN % dict(root=MC.ROOT, here=MC.HERE)], capture_output=True, text=True, env=env,
                        timeout=1200)
     assert p.returncode == 0 and 'BAD 0' in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
+
+
+@pytest.mark.parametrize('N', [64, 8, 41])
+def test_single_launch_inputs_chain_their_hub_rows(N):
+    """Inputs of <= 2^18 nnz run as ONE launch; above the hub threshold's worth of nnz it is spmm_small_hub: the row waves skip
+    the rows above the threshold, the workgroup chains them afterwards (the general schedule's hub workgroup in the row
+    stream's LDS).  At the DEFAULT threshold: rows of 20000 and 16385 nnz are chains, 16384 is not; mean, unit weights and the
+    fused epilogue go the same way."""
+    E.set_env(DGS_HUB_CHAIN=None)
+    rng = np.random.default_rng(2)
+    M, K = 3000, 30000
+    deg = rng.integers(0, 12, M)
+    deg[5], deg[2999], deg[77], deg[100] = 20000, 16385, 16384, 700
+    rp = np.zeros(M + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    col = np.concatenate([np.sort(rng.choice(K, d, replace=False)) for d in deg]).astype(np.int32)
+    val = rng.random(col.size, dtype=np.float32)
+    X = feats(K, N)
+    assert E.schedule(E.SUM, M, K, N, col.size) == 'small'
+    ref, _ = oracle.spmm('sum', rp, col, val, X, fma=True)
+    hub, short = deg > 16384, deg <= 64
+    C, _ = E.spmm(E.SUM, rp, col, val, X)
+    assert not np.isnan(C).any()
+    assert_bitexact(C[hub], ref[hub], 'hub rows of a single-launch input')
+    assert_bitexact(C[short], ref[short], 'short rows')
+    assert (np.abs(C - ref) <= 1e-5 * np.abs(ref) + 1e-6).all()
+    refm, _ = oracle.spmm('mean', rp, col, None, X, fma=True)
+    Cm, _ = E.spmm(E.MEAN, rp, col, None, X)
+    assert_bitexact(Cm[hub], refm[hub], 'mean, unit weights')
+    bias, sc = rng.random(N, dtype=np.float32), rng.random(M, dtype=np.float32)
+    Ce = E.spmm_ex(E.SUM, rp, col, val, X, bias=bias, row_scale=sc, relu=True)
+    assert_bitexact(Ce[hub], np.maximum(sc[:, None] * ref + bias[None, :], 0).astype(np.float32)[hub], 'epilogue')
+    if N == 64:  # the switch: the wave-cooperative tree again (not the chain: 20000 roundings in another order)
+        E.set_env(DGS_HUB_CHAIN=0)
+        C0, _ = E.spmm(E.SUM, rp, col, val, X)
+        assert (C0[hub].view(np.int32) != ref[hub].view(np.int32)).any()
+        assert (np.abs(C0 - ref) <= 1e-5 * np.abs(ref) + 1e-6).all()

@@ -252,3 +252,36 @@ def test_hub_chain_with_the_fused_epilogue_and_the_panel_schedule(capi, monkeypa
     assert_bitexact(C2[l2 > 3000], ref2[l2 > 3000], 'panel schedule: hub rows')
     assert_bitexact(C2[l2 <= 2500], ref2[l2 <= 2500], 'panel schedule: swept rows are chains already')
     assert (np.abs(C2 - ref2) <= 1e-5 * np.abs(ref2) + 2e-6).all()
+
+
+@pytest.mark.parametrize('N', [64, 128, 8, 41])
+def test_single_launch_inputs_chain_their_hub_rows(capi, N):
+    """Inputs of <= 2^18 nnz / 2^16 rows are ONE launch; with more nnz than the hub threshold that launch is spmm_small_hub: rows
+    above the threshold skipped by the row waves and chained by the workgroup afterwards.  Default threshold (16384): rows of
+    20000 and 16385 nnz bit for bit the oracle's chain, everything else as before (1e-5; rows <= 64 nnz bit-exact); mean with
+    unit weights and the fused epilogue through the same kernel."""
+    assert capi.hub_threshold() == 16384
+    rng = np.random.default_rng(2)
+    M, K = 3000, 30000
+    deg = rng.integers(0, 12, M)
+    deg[5], deg[2999], deg[77], deg[100] = 20000, 16385, 16384, 700
+    rp = np.zeros(M + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    col = np.concatenate([np.sort(rng.choice(K, d, replace=False)) for d in deg]).astype(np.int32)
+    val = rng.random(col.size, dtype=np.float32)
+    X = rng.random((K, N), dtype=np.float32)
+    assert capi.spmm_schedule(capi.SUM, M, K, N, col.size) == 'small'
+    ref, _ = oracle.spmm('sum', rp, col, val, X, fma=True, threads=oracle.max_threads())
+    hub, short = deg > 16384, deg <= 64
+    C, _ = _default(capi, 'sum', rp, col, val, X)
+    assert_bitexact(C[hub], ref[hub], 'hub rows of a single-launch input')
+    assert_bitexact(C[short], ref[short], 'short rows')
+    assert (np.abs(C - ref) <= 1e-5 * np.abs(ref) + 1e-6).all()
+    Cm, _ = _default(capi, 'mean', rp, col, None, X)
+    refm, _ = oracle.spmm('mean', rp, col, None, X, fma=True, threads=oracle.max_threads())
+    assert_bitexact(Cm[hub], refm[hub], 'mean, unit weights')
+    d = 'cuda'
+    drp, dcol, dval, dX = (torch.from_numpy(a).to(d) for a in (rp, col, val, X))
+    bias, rs = torch.linspace(-1, 1, N, device=d), torch.rand(M, device=d) + 0.5
+    got, _ = capi.spmm(capi.SUM, drp, dcol, dval, dX, bias=bias, row_scale=rs, relu=True)
+    assert torch.equal(got, torch.relu(torch.from_numpy(C).to(d) * rs[:, None] + bias)), 'fused == unfused bit for bit'
