@@ -35,6 +35,7 @@ static void tuning_read(Tuning &t) {
   t.plan_ch = rd("DGS_PLAN_CH");
   t.plan_nocut = rd("DGS_PLAN_NOCUT");
   t.hub_chain = rd("DGS_HUB_CHAIN");
+  t.hub_xcd = rd("DGS_HUB_XCD");
 }
 static void tuning_publish() {
   std::lock_guard<std::mutex> lk(g_tuning_mu);

@@ -59,6 +59,9 @@ def set_env(**kw):
     lib().dgs_reload_tuning()
 
 
+last_ws = None  # the workspace of the last spmm() call (tests look at what a launch left in it)
+
+
 def spmm(op, rp, col, val, X, algorithm=0, plan=None):
     L = lib()
     M, nnz, (K, N) = rp.size - 1, col.size, X.shape
@@ -77,6 +80,8 @@ def spmm(op, rp, col, val, X, algorithm=0, plan=None):
         rc = L.dgs_spmm_csr_f32(op, i64(M), i64(K), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C), _p(E), int(algorithm),
                                 _p(ws), ctypes.c_size_t(wsb), None)
     assert rc == 0, f'emu spmm rc={rc}'
+    global last_ws
+    last_ws = ws
     return C, E
 
 

@@ -32,11 +32,12 @@ def one_case(rng, it):
     if rng.integers(0, 2):  # half of the cases: the general schedule with hub rows (what round 4 added)
         M, per, alpha = int(rng.choice([66000, 70000])), float(rng.choice([0.5, 3])), 1.5
         K, dmax = int(rng.choice([1000, 20000])), int(rng.choice([3000, 9000]))
-        N = int(rng.choice([16, 20, 32, 48, 64, 100, 128, 256]))
+        N = int(rng.choice([16, 20, 32, 48, 64, 100, 128, 256, 41, 7, 8, 4, 1, 33]))
         nnz = int(M * per)
     rp, col, st = graphgen.powerlaw_csr(M, max(nnz, 1), K=K, alpha=alpha, dmax=max(1, min(K * 3, dmax)), seed=it,
                                         dedup=bool(rng.integers(0, 2)), cols=str(rng.choice(['uniform', 'powerlaw'])))
-    if M >= 66000 and K >= 33:  # the generator rescales its degrees to the nnz budget: put real hub rows in by hand
+    tiny_hub = M in (1000, 4096, 4097, 30000) and K >= 1000 and rng.integers(0, 2)  # single-launch inputs with hub rows
+    if (M >= 66000 and K >= 33) or tiny_hub:  # the generator rescales its degrees to the nnz budget: put real hub rows in by hand
         lens0 = np.diff(rp).astype(np.int64)
         rows = rng.choice(M, int(rng.integers(2, 7)), replace=False)
         parts = np.split(col, rp[1:-1])
@@ -65,7 +66,7 @@ def one_case(rng, it):
     S64 = oracle.spmm_sum_f64(rp, col, val, X, absval=True)
     sched = E.schedule(E.SUM, M, K, N, max(col.shape[0], 0)) if col.shape[0] else 'small'
     plan = E.spmm_plan(rp, col, K) if (sched == 'rows' and rng.integers(0, 2)) else None
-    hub_ok = N % 4 == 0 and N >= 16 and hubth > 0 and sched != 'small'  # 16-byte lanes, >= 16 features (X is 64-byte aligned)
+    hub_ok = hubth > 0 and sched != 'panel'  # every feature width, general and single-launch schedules (panel: its own long-row bound)
     for reduce in ('sum', 'mean', 'max', 'min'):
         Co, Eo = oracle.spmm(reduce, rp, col, val, X, fma=True)
         for kw in ([{}] + ([dict(plan=plan)] if plan is not None else [])):

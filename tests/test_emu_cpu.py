@@ -293,3 +293,44 @@ def test_single_launch_inputs_chain_their_hub_rows(N):
         C0, _ = E.spmm(E.SUM, rp, col, val, X)
         assert (C0[hub].view(np.int32) != ref[hub].view(np.int32)).any()
         assert (np.abs(C0 - ref) <= 1e-5 * np.abs(ref) + 1e-6).all()
+
+
+@pytest.mark.parametrize('N', [64, 41, 128])
+def test_hub_rows_slice_by_slice_across_the_xcds(graph, N):
+    """DGS_HUB_XCD=1 (planned sum / mean): the workgroups of XCD s chain segment s (column slice s) of every hub row and hand
+    the accumulators on through the workspace - same sequence of fmaf, so the same bits as the one-workgroup chain and the
+    oracle.  Covered: compact plan / build buffer / provisional counts, a hub row with unsorted columns (all of it in "slice
+    0"), one whose columns end in the second slice (empty segments that only pass the accumulators on), mean with unit
+    weights, the fused epilogue; max over the same plan is untouched.  The hand-over area of the workspace is really used."""
+    rp, col, val, K, deg = graph
+    rng = np.random.default_rng(8)
+    col = col.copy()
+    rng.shuffle(col[rp[100]:rp[101]])
+    col[rp[7000]:rp[7001]] = np.sort(rng.choice(K // 3, 1500, replace=False))
+    X = feats(K, N)
+    hub = deg > 1024
+    ref, _ = oracle.spmm('sum', rp, col, val, X, fma=True)
+    refm, _ = oracle.spmm('mean', rp, col, None, X, fma=True)
+    E.set_env(DGS_HUB_XCD=1)
+    try:
+        plan = E.spmm_plan(rp, col, K)
+        big, real = E.spmm_plan(rp, col, K, compact=False)
+        for name, pl in (('compact', plan), ('build buffer', (big, real)), ('provisional counts', (big, E.provisional_info(rp)))):
+            C, _ = E.spmm(E.SUM, rp, col, val, X, plan=pl)
+            assert not np.isnan(C).any(), name
+            assert_bitexact(C[hub], ref[hub], f'{name}: hub rows N={N}')
+            assert (np.abs(C - ref) <= 1e-5 * np.abs(ref) + 1e-6).all(), name
+            xpitch = (N + 255) // 256 * 256
+            area = E.last_ws[-(int(pl[1].n_hub) * 8 * xpitch * 8 + 256 + 64):]
+            assert (area != 0).any(), 'the accumulators went through the workspace'
+            Cm, _ = E.spmm(E.MEAN, rp, col, None, X, plan=pl)
+            assert_bitexact(Cm[hub], refm[hub], f'{name}: mean, unit weights N={N}')
+        bias, sc = rng.random(N, dtype=np.float32), rng.random(rp.size - 1, dtype=np.float32)
+        Ce = E.spmm_ex(E.SUM, rp, col, val, X, bias=bias, row_scale=sc, relu=True, plan=plan)
+        assert_bitexact(Ce[hub], np.maximum(sc[:, None] * ref + bias[None, :], 0).astype(np.float32)[hub], 'epilogue')
+        Cx, Ex = E.spmm(E.MAX, rp, col, val, X, plan=plan)
+        rx, ex = oracle.spmm('max', rp, col, val, X)
+        assert_bitexact(Cx, rx, 'max over the same plan')
+        assert_bitexact(Ex, ex, 'max arg ids')
+    finally:
+        E.set_env(DGS_HUB_XCD=None)
