@@ -45,8 +45,10 @@ def one_case(rng, it):
         os.environ['DGS_HUB_CHAIN'] = str(hubth)
     else:
         os.environ.pop('DGS_HUB_CHAIN', None)
+    xcd = str(int(rng.integers(0, 2)))  # planned sum / mean: hub rows slice by slice across the XCDs
+    os.environ['DGS_HUB_XCD'] = xcd
     capi.reload_tuning()
-    tag = f'it={it} M={M} K={K} N={N} nnz={col.shape[0]} maxdeg={st["max_deg"]} val={kind} hub={hubth or "default"}'
+    tag = f'it={it} M={M} K={K} N={N} nnz={col.shape[0]} maxdeg={st["max_deg"]} val={kind} hub={hubth or "default"} xcd={xcd}'
     if os.environ.get('FUZZ_VERBOSE'):
         print('case', tag, flush=True)
     drp, dcol, dval, dX = dev(rp), dev(col), (None if val is None else dev(val)), dev(X)
