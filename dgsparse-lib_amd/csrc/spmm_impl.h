@@ -1485,8 +1485,12 @@ static int launch_impl(const SpmmArgs &a) {
     HubTab ht{};
     const char *hubp = pb + (a.plan_off_hub ? (size_t)a.plan_off_hub : PL.off_hub);
     HubArg ha{&ph->n_hub, reinterpret_cast<const int4 *>(hubp), ht, 1};
-    const int nbh = use_hub ? hub_blocks((int64_t)a.plan_hub * strict_shub(G, V)) : 0;
+    int nbh = use_hub ? hub_blocks((int64_t)a.plan_hub * strict_shub(G, V)) : 0;
     if (use_hub && tune(tuning().hub_xcd, DGS_HUB_XCD) != 0 && (nbh & 7) == 0 && L.xacc_bytes) {
+      // (workgroups that wait for one another: all of them, over all feature tiles, fit the chip twice over - whatever order
+      // the dispatcher takes them in, a waiting one can never keep its producer from starting)
+      const int cap = ((2 * cu_count() / (int)a.tiles) & ~7) < 8 ? 8 : ((2 * cu_count() / (int)a.tiles) & ~7);
+      if (nbh > cap) nbh = cap;
       // slice by slice (spmm_strict.h HubLink): the cut table sits behind the hub rows - max_hub of them in a build buffer,
       // n_hub in a compact plan
       ha.cuts = reinterpret_cast<const int *>(hubp + (size_t)(a.plan_off_hub ? a.plan_hub : PL.max_hub) * sizeof(int4));
