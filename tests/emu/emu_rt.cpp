@@ -51,11 +51,14 @@ emu_switch:
 .size emu_switch,.-emu_switch
 )");
 
-// dynamic LDS of the column-panel kernels (DGS_DYN_SHARED in dgs_common.h)
+// LDS: every __shared__ object of the emulated kernels is a static in the link section "emu_lds" (hip/hip_runtime.h), and so is the
+// dynamic LDS of the column-panel kernels (DGS_DYN_SHARED in dgs_common.h).  One workgroup at a time owns the section; when
+// several are resident (DGS_EMU_BLOCKS > 1) the scheduler saves and restores it around every workgroup switch.
 namespace dgs {
-alignas(16) char panel_dyn[160 * 1024];
-alignas(16) char sd_dyn[160 * 1024];
+alignas(16) __attribute__((section("emu_lds"))) char panel_dyn[160 * 1024];
+alignas(16) __attribute__((section("emu_lds"))) char sd_dyn[160 * 1024];
 }  // namespace dgs
+extern "C" char __start_emu_lds[], __stop_emu_lds[];
 
 namespace emu {
 
@@ -71,52 +74,72 @@ struct Fiber {
   void *fake = nullptr;  // ASAN: this fiber's fake-stack handle while it is switched out
   State st = DONE;
   int wave = 0, lane = 0;
+  bool relaxed = false;  // gave its turn away in a spin-wait (s_sleep): no progress of its own
 };
-void *sched_fake = nullptr;
-const void *sched_bottom = nullptr;
-size_t sched_size = 0;
 struct Wave {
   unsigned char buf[64][16], snap[64][16];
   unsigned long long live = 0, arrived = 0, snap_live = 0;
   unsigned bytes = 0;
 };
-std::vector<Fiber> fibers;
-std::vector<Wave> waves;
+// One resident workgroup.  DGS_EMU_BLOCKS = 1 (default): workgroups run one after the other, each to completion, in dispatch
+// order - enough for kernels whose workgroups do not wait for one another.  DGS_EMU_BLOCKS = n: up to n workgroups are resident
+// and take turns (a workgroup gives its turn away when all it did in a sweep was spin: `s_sleep` is the yield point), which is
+// what a kernel with hand-overs BETWEEN workgroups needs - the soft barrier of the column-panel sweep, the slice-by-slice hub
+// chains - and DGS_EMU_BLOCK_ORDER = fwd | rev | rand:<seed> is the order in which they are dispatched (a consumer resident
+// before its producer has to wait, not fail).
+struct Block {
+  std::vector<Fiber> fibers;
+  std::vector<Wave> waves;
+  std::vector<char> lds;  // the section's contents while another workgroup owns it
+  dim3 bid;
+  int live = 0, arrived = 0, remaining = 0;
+  bool fresh = true;      // has not run yet: its LDS is whatever the previous owner left (as on the hardware)
+};
+void *sched_fake = nullptr;
+const void *sched_bottom = nullptr;
+size_t sched_size = 0;
 void *sched_sp = nullptr;
 Fiber *me = nullptr;
+Block *blk = nullptr;
 void (*k_fn)(void *) = nullptr;
 void *k_ctx = nullptr;
-int block_live = 0, block_arrived = 0;
+std::vector<char *> stack_pool;
 
 // The order in which the runnable work-items of a workgroup get their turn.  Between two rendezvous points a fiber runs
 // undisturbed, so a missing barrier BETWEEN waves only shows when the reader happens to run before the writer (RAW) or the
 // over-writer before the reader (WAR): one fixed order hides one of the two.  DGS_EMU_ORDER = fwd (default: ascending
 // work-item id) | rev | rand:<seed> (a fresh permutation of the waves and of the lanes in each wave for every sweep).
 enum Order { FWD, REV, RAND };
-Order order_mode = FWD;
-unsigned long long order_state = 1;
+Order order_mode = FWD, block_order = FWD;
+unsigned long long order_state = 1, block_state = 1;
+int max_resident = 1;
 bool order_read = false;
 std::vector<unsigned> order_buf;
-unsigned order_next(unsigned n) {  // xorshift64*: deterministic for a seed
-  order_state ^= order_state >> 12;
-  order_state ^= order_state << 25;
-  order_state ^= order_state >> 27;
-  return (unsigned)(((order_state * 2685821657736338717ull) >> 33) % n);
+unsigned xs_next(unsigned long long &st, unsigned n) {  // xorshift64*: deterministic for a seed
+  st ^= st >> 12;
+  st ^= st << 25;
+  st ^= st >> 27;
+  return (unsigned)(((st * 2685821657736338717ull) >> 33) % n);
+}
+void parse_order(const char *name, Order &mode, unsigned long long &state) {
+  const char *e = getenv(name);
+  if (!e || !*e || !strcmp(e, "fwd")) return;
+  if (!strcmp(e, "rev")) mode = REV;
+  else if (!strncmp(e, "rand:", 5)) {
+    mode = RAND;
+    state = strtoull(e + 5, nullptr, 10) * 0x9e3779b97f4a7c15ull + 0x1234567ull;
+    if (!state) state = 1;
+  } else {
+    fprintf(stderr, "emu: %s=%s (fwd | rev | rand:<seed>)\n", name, e);
+    abort();
+  }
 }
 void order_init() {
   if (order_read) return;
   order_read = true;
-  const char *e = getenv("DGS_EMU_ORDER");
-  if (!e || !*e || !strcmp(e, "fwd")) return;
-  if (!strcmp(e, "rev")) order_mode = REV;
-  else if (!strncmp(e, "rand:", 5)) {
-    order_mode = RAND;
-    order_state = strtoull(e + 5, nullptr, 10) * 0x9e3779b97f4a7c15ull + 0x1234567ull;
-    if (!order_state) order_state = 1;
-  } else {
-    fprintf(stderr, "emu: DGS_EMU_ORDER=%s (fwd | rev | rand:<seed>)\n", e);
-    abort();
-  }
+  parse_order("DGS_EMU_ORDER", order_mode, order_state);
+  parse_order("DGS_EMU_BLOCK_ORDER", block_order, block_state);
+  if (const char *e = getenv("DGS_EMU_BLOCKS")) max_resident = atoi(e) > 1 ? atoi(e) : 1;
 }
 const std::vector<unsigned> &sweep_order(unsigned nthr) {
   if (order_buf.size() != nthr || order_mode == RAND) {
@@ -127,7 +150,7 @@ const std::vector<unsigned> &sweep_order(unsigned nthr) {
     const unsigned nw = (nthr + 63) / 64;
     // waves first (Fisher-Yates over whole waves), then the lanes inside each wave
     for (unsigned w = nw; w > 1; w--) {
-      const unsigned o = order_next(w);
+      const unsigned o = xs_next(order_state, w);
       if (o != w - 1)
         for (unsigned l = 0; l < 64; l++) {
           const unsigned a = (w - 1) * 64 + l, b = o * 64 + l;
@@ -136,7 +159,7 @@ const std::vector<unsigned> &sweep_order(unsigned nthr) {
     }
     for (unsigned w = 0; w < nw; w++) {
       const unsigned n = min(64u, nthr - w * 64);
-      for (unsigned l = n; l > 1; l--) std::swap(order_buf[w * 64 + l - 1], order_buf[w * 64 + order_next(l)]);
+      for (unsigned l = n; l > 1; l--) std::swap(order_buf[w * 64 + l - 1], order_buf[w * 64 + xs_next(order_state, l)]);
     }
   }
   return order_buf;
@@ -155,17 +178,17 @@ void yield() {
 
 void release_wave(Wave &w, int wi, State from) {
   for (int l = 0; l < 64; l++)
-    if ((size_t)(wi * 64 + l) < fibers.size() && fibers[wi * 64 + l].st == from) fibers[wi * 64 + l].st = RUN;
+    if ((size_t)(wi * 64 + l) < blk->fibers.size() && blk->fibers[wi * 64 + l].st == from) blk->fibers[wi * 64 + l].st = RUN;
   w.arrived = 0;
 }
 void try_release_wave(int wi) {
-  Wave &w = waves[wi];
+  Wave &w = blk->waves[wi];
   if (!w.arrived || (w.arrived & w.live) != w.live) return;
   // every live lane waits: they must all wait for the same kind of rendezvous
   State kind = DONE;
   for (int l = 0; l < 64; l++)
     if ((w.live >> l) & 1ull) {
-      const State s = fibers[wi * 64 + l].st;
+      const State s = blk->fibers[wi * 64 + l].st;
       if (kind == DONE) kind = s;
       else if (kind != s) return;  // mixed: left to the deadlock report
     }
@@ -178,10 +201,10 @@ void try_release_wave(int wi) {
   }
 }
 void try_release_block() {
-  if (block_live > 0 && block_arrived == block_live) {
-    for (auto &f : fibers)
+  if (blk->live > 0 && blk->arrived == blk->live) {
+    for (auto &f : blk->fibers)
       if (f.st == WAIT_BLOCK) f.st = RUN;
-    block_arrived = 0;
+    blk->arrived = 0;
   }
 }
 
@@ -192,9 +215,9 @@ extern "C" void emu_fiber_entry() {
   k_fn(k_ctx);
   Fiber *f = me;
   f->st = DONE;
-  Wave &w = waves[f->wave];
+  Wave &w = blk->waves[f->wave];
   w.live &= ~(1ull << f->lane);
-  block_live--;
+  blk->live--;
   try_release_wave(f->wave);
   try_release_block();
 #if EMU_ASAN
@@ -204,14 +227,22 @@ extern "C" void emu_fiber_entry() {
   abort();  // never resumed
 }
 
-void start_fiber(Fiber &f) {
-  if (!f.stack) {
-    f.stack = static_cast<char *>(mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0));
-    if (f.stack == MAP_FAILED) {
-      perror("emu: mmap");
-      abort();
-    }
+char *get_stack() {
+  if (!stack_pool.empty()) {
+    char *s = stack_pool.back();
+    stack_pool.pop_back();
+    return s;
   }
+  char *s = static_cast<char *>(mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0));
+  if (s == MAP_FAILED) {
+    perror("emu: mmap");
+    abort();
+  }
+  return s;
+}
+
+void start_fiber(Fiber &f) {
+  if (!f.stack) f.stack = get_stack();
   // stack image emu_switch pops: r15 r14 r13 r12 rbx rbp, then `ret` into the entry with rsp = 16 n + 8
   uintptr_t top = (reinterpret_cast<uintptr_t>(f.stack) + kStack) & ~uintptr_t(15);
   void **sp = reinterpret_cast<void **>(top - 8);  // the slot `ret` would have left behind: keeps the ABI's alignment at entry
@@ -219,6 +250,7 @@ void start_fiber(Fiber &f) {
   for (int i = 0; i < 6; i++) *--sp = nullptr;
   f.sp = sp;
   f.st = RUN;
+  f.relaxed = false;
 }
 
 // Nothing can run.  Before calling it a deadlock: a wave in which SOME lanes wait at a collective while every other live lane
@@ -227,43 +259,107 @@ void start_fiber(Fiber &f) {
 // collective for the lanes that arrived: the others count as inactive for it (ballot bit 0, undefined as a shuffle source).
 bool release_partial_collectives() {
   bool any = false;
-  for (size_t wi = 0; wi < waves.size(); wi++) {
-    Wave &w = waves[wi];
+  for (size_t wi = 0; wi < blk->waves.size(); wi++) {
+    Wave &w = blk->waves[wi];
     unsigned long long at = 0;
-    for (int l = 0; l < 64 && wi * 64 + l < fibers.size(); l++)
-      if (fibers[wi * 64 + l].st == WAIT_WAVE) at |= 1ull << l;
+    for (int l = 0; l < 64 && wi * 64 + l < blk->fibers.size(); l++)
+      if (blk->fibers[wi * 64 + l].st == WAIT_WAVE) at |= 1ull << l;
     if (!at) continue;
     memcpy(w.snap, w.buf, sizeof(w.snap));
     w.snap_live = at;
     for (int l = 0; l < 64; l++)
-      if ((at >> l) & 1ull) fibers[wi * 64 + l].st = RUN;
+      if ((at >> l) & 1ull) blk->fibers[wi * 64 + l].st = RUN;
     w.arrived &= ~at;
     any = true;
   }
   return any;
 }
 
-[[noreturn]] void deadlock(const dim3 &b) {
-  fprintf(stderr, "emu: DEADLOCK in block (%u, %u): no work-item can run\n", b.x, b.y);
+[[noreturn]] void deadlock(const char *why) {
+  fprintf(stderr, "emu: DEADLOCK in block (%u, %u): %s\n", blk->bid.x, blk->bid.y, why);
   const char *nm[] = {"run", "wave collective", "wave barrier", "workgroup barrier", "done"};
-  for (size_t w = 0; w < waves.size(); w++) {
-    fprintf(stderr, "  wave %zu live %016llx:", w, waves[w].live);
+  for (size_t w = 0; w < blk->waves.size(); w++) {
+    fprintf(stderr, "  wave %zu live %016llx:", w, blk->waves[w].live);
     int cnt[5] = {0, 0, 0, 0, 0};
-    for (int l = 0; l < 64 && w * 64 + l < fibers.size(); l++) cnt[fibers[w * 64 + l].st]++;
+    for (int l = 0; l < 64 && w * 64 + l < blk->fibers.size(); l++) cnt[blk->fibers[w * 64 + l].st]++;
     for (int s = 0; s < 5; s++)
       if (cnt[s]) fprintf(stderr, " %d x %s", cnt[s], nm[s]);
     fprintf(stderr, "\n");
   }
   abort();
 }
+
+void init_block(Block &b, dim3 bid, dim3 block, dim3 grid, unsigned nthr) {
+  b.bid = bid;
+  b.fibers.resize(nthr);
+  b.waves.assign((nthr + 63) / 64, Wave{});
+  b.live = b.remaining = (int)nthr;
+  b.arrived = 0;
+  b.fresh = true;
+  for (unsigned t = 0; t < nthr; t++) {
+    Fiber &f = b.fibers[t];
+    f.item.tid = uint3{t, 0, 0};
+    f.item.bid = uint3{bid.x, bid.y, bid.z};
+    f.item.bdim = uint3{block.x, 1, 1};
+    f.item.gdim = uint3{grid.x, grid.y, grid.z};
+    f.wave = (int)(t / 64);
+    f.lane = (int)(t % 64);
+    b.waves[f.wave].live |= 1ull << f.lane;
+    start_fiber(f);
+  }
+}
+
+// Runs the current workgroup until it is finished or until a whole sweep over its work-items was nothing but spinning.
+// Returns true when it made progress of its own (so the caller's no-progress count restarts).
+bool run_block() {
+  bool progress = false;
+  int spins = 0;
+  const unsigned nthr = (unsigned)blk->fibers.size();
+  while (blk->remaining > 0) {
+    bool ran = false, worked = false;
+    const std::vector<unsigned> &ord = sweep_order(nthr);
+    for (unsigned i = 0; i < nthr; i++) {
+      Fiber &f = blk->fibers[ord[i]];
+      if (f.st != RUN) continue;
+      ran = true;
+      f.relaxed = false;
+      me = &f;
+      cur = &f.item;
+#if EMU_ASAN
+      __sanitizer_start_switch_fiber(&sched_fake, f.stack, kStack);
+#endif
+      emu_switch(&sched_sp, f.sp);
+#if EMU_ASAN
+      __sanitizer_finish_switch_fiber(sched_fake, nullptr, nullptr);
+#endif
+      if (f.st == DONE) blk->remaining--;
+      if (!f.relaxed) worked = true;
+    }
+    if (!ran && !release_partial_collectives()) deadlock("no work-item can run");
+    if (worked || !ran) {
+      progress = true;
+      spins = 0;
+    } else if (max_resident > 1) {
+      return progress;  // every runnable work-item only spun: somebody else's turn
+    } else if (++spins > 1000000) {
+      return false;     // alone and spinning for good (a bounded spin - the panel sweep's soft barrier - runs out long before)
+    }
+  }
+  return true;
+}
 }  // namespace
+
+void relax() {  // s_sleep inside a spin-wait: give the turn away (to the other work-items, then to the other workgroups)
+  me->relaxed = true;
+  yield();
+}
 
 void wave_collective(const void *in, unsigned bytes, void *all, unsigned long long *live) {
   if (bytes > 16) {
     fprintf(stderr, "emu: collective of %u bytes\n", bytes);
     abort();
   }
-  Wave &w = waves[me->wave];
+  Wave &w = blk->waves[me->wave];
   memcpy(w.buf[me->lane], in, bytes);
   w.bytes = bytes;
   w.arrived |= 1ull << me->lane;
@@ -276,7 +372,7 @@ void wave_collective(const void *in, unsigned bytes, void *all, unsigned long lo
 }
 
 void wave_sync() {
-  Wave &w = waves[me->wave];
+  Wave &w = blk->waves[me->wave];
   w.arrived |= 1ull << me->lane;
   me->st = WAIT_WSYNC;
   try_release_wave(me->wave);
@@ -284,7 +380,7 @@ void wave_sync() {
 }
 
 void block_sync() {
-  block_arrived++;
+  blk->arrived++;
   me->st = WAIT_BLOCK;
   try_release_block();
   while (me->st != RUN) yield();
@@ -297,54 +393,75 @@ void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx) {
     abort();
   }
   order_init();
-  if (fibers.size() < nthr) fibers.resize(nthr);
-  const unsigned nw = (nthr + 63) / 64;
-  k_fn = fn;
-  k_ctx = ctx;
+  // saved across a nested launch (none today) and restored at the end
+  void (*const saved_fn)(void *) = k_fn;
+  void *const saved_ctx = k_ctx;
   Item *const saved_cur = cur;
   Fiber *const saved_me = me;
-  for (unsigned bz = 0; bz < grid.z; bz++)
-    for (unsigned by = 0; by < grid.y; by++)
-      for (unsigned bx = 0; bx < grid.x; bx++) {
-        waves.assign(nw, Wave{});
-        block_live = (int)nthr;
-        block_arrived = 0;
-        for (unsigned t = 0; t < nthr; t++) {
-          Fiber &f = fibers[t];
-          f.item.tid = uint3{t, 0, 0};
-          f.item.bid = uint3{bx, by, bz};
-          f.item.bdim = uint3{block.x, 1, 1};
-          f.item.gdim = uint3{grid.x, grid.y, grid.z};
-          f.wave = (int)(t / 64);
-          f.lane = (int)(t % 64);
-          waves[f.wave].live |= 1ull << f.lane;
-          start_fiber(f);
-        }
-        for (unsigned t = nthr; t < fibers.size(); t++) fibers[t].st = DONE;
-        int remaining = (int)nthr;
-        while (remaining > 0) {
-          bool ran = false;
-          const std::vector<unsigned> &ord = sweep_order(nthr);
-          for (unsigned i = 0; i < nthr; i++) {
-            Fiber &f = fibers[ord[i]];
-            if (f.st != RUN) continue;
-            ran = true;
-            me = &f;
-            cur = &f.item;
-#if EMU_ASAN
-            __sanitizer_start_switch_fiber(&sched_fake, f.stack, kStack);
-#endif
-            emu_switch(&sched_sp, f.sp);
-#if EMU_ASAN
-            __sanitizer_finish_switch_fiber(sched_fake, nullptr, nullptr);
-#endif
-            if (f.st == DONE) remaining--;
-          }
-          if (!ran && !release_partial_collectives()) deadlock(dim3(bx, by, bz));
-        }
+  Block *const saved_blk = blk;
+  k_fn = fn;
+  k_ctx = ctx;
+  // dispatch order: x fastest, then y, then z (the hardware's), permuted as a whole on request
+  const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+  std::vector<size_t> order(nblocks);
+  for (size_t i = 0; i < nblocks; i++) order[i] = block_order == REV ? nblocks - 1 - i : i;
+  if (block_order == RAND)
+    for (size_t i = nblocks; i > 1; i--) std::swap(order[i - 1], order[xs_next(block_state, (unsigned)(i < 0xffffffffu ? i : 0xffffffffu))]);
+  auto bid_of = [&](size_t i) { return dim3((unsigned)(i % grid.x), (unsigned)((i / grid.x) % grid.y), (unsigned)(i / ((size_t)grid.x * grid.y))); };
+  const size_t lds_bytes = (size_t)(__stop_emu_lds - __start_emu_lds);
+  if (max_resident <= 1) {
+    Block b;
+    blk = &b;
+    for (size_t i = 0; i < nblocks; i++) {
+      init_block(b, bid_of(order[i]), block, grid, nthr);
+      if (!run_block()) deadlock("its work-items wait for another workgroup, and workgroups run one at a time (DGS_EMU_BLOCKS)");
+    }
+    for (auto &f : b.fibers) stack_pool.push_back(f.stack);
+  } else {
+    std::vector<Block *> res;
+    size_t next = 0, turn = 0;
+    Block *owner = nullptr;  // whose LDS is in the section
+    int idle_rounds = 0;
+    while (next < nblocks || !res.empty()) {
+      while (next < nblocks && (int)res.size() < max_resident) {
+        Block *b = new Block;
+        blk = b;
+        init_block(*b, bid_of(order[next++]), block, grid, nthr);
+        res.push_back(b);
       }
+      if (turn >= res.size()) turn = 0;
+      Block *b = res[turn];
+      if (owner != b) {
+        if (owner) {
+          owner->lds.resize(lds_bytes);
+          memcpy(owner->lds.data(), __start_emu_lds, lds_bytes);
+        }
+        if (!b->fresh) memcpy(__start_emu_lds, b->lds.data(), lds_bytes);
+        owner = b;
+      }
+      b->fresh = false;
+      blk = b;
+      const bool progress = run_block();
+      if (b->remaining == 0) {
+        for (auto &f : b->fibers) stack_pool.push_back(f.stack);
+        res.erase(res.begin() + (long)turn);
+        if (owner == b) owner = nullptr;
+        delete b;
+        idle_rounds = 0;
+        continue;  // (the next one slid into this turn)
+      }
+      idle_rounds = progress ? 0 : idle_rounds + 1;
+      if (idle_rounds > 4 * (int)res.size() + 8 && next >= nblocks) deadlock("every resident workgroup spins and none is left to dispatch");
+      if (idle_rounds > 4 * (int)res.size() + 8 && (int)res.size() >= max_resident)
+        deadlock("every resident workgroup spins and there is no room to dispatch the one they wait for (DGS_EMU_BLOCKS)");
+      turn++;
+    }
+  }
+  k_fn = saved_fn;
+  k_ctx = saved_ctx;
   cur = saved_cur;
   me = saved_me;
+  blk = saved_blk;
 }
 
 }  // namespace emu

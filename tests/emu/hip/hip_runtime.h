@@ -28,7 +28,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static __attribute__((section("emu_lds")))  // one link section: saved / restored when workgroups take turns
 #define __align__(n) alignas(n)
 
 // ---- vector types -----------------------------------------------------------------------------------------------------------
@@ -57,6 +57,7 @@ extern Item *cur;
 void wave_collective(const void *in, unsigned bytes, void *all /* 64 x bytes */, unsigned long long *live);
 void wave_sync();
 void block_sync();
+void relax();
 void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx);
 template <typename F>
 inline void launch(dim3 grid, dim3 block, F &&f) {
@@ -170,7 +171,7 @@ static inline T emu_readfirstlane(T v) {
 #define __builtin_amdgcn_s_barrier() ::emu::block_sync()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
-#define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ::emu::relax()  // the yield point of a spin-wait
 
 // atomics: one fiber runs at a time, so plain read-modify-write is atomic
 template <typename T>

@@ -334,3 +334,22 @@ def test_hub_rows_slice_by_slice_across_the_xcds(graph, N):
         assert_bitexact(Ex, ex, 'max arg ids')
     finally:
         E.set_env(DGS_HUB_XCD=None)
+
+
+@pytest.mark.parametrize('order', ['rev', 'rand:3'])
+def test_slice_by_slice_hub_chains_with_consumers_dispatched_before_their_producers(order):
+    """The slice-by-slice hub chains are workgroups that WAIT for one another.  With DGS_EMU_BLOCKS = 64 the emulation keeps
+    that many workgroups resident and lets them take turns (a workgroup gives its turn away when all it did was spin), and
+    DGS_EMU_BLOCK_ORDER dispatches them in reverse / random order: every consumer is resident before its producer and has to
+    wait for the hand-over word, not fail.  (With 4 resident workgroups and reverse dispatch the same case ends in the
+    emulator's deadlock report - the situation the in-order dispatch of the hub blocks at the head of the grid rules out.)"""
+    import subprocess
+    E.lib()
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu', 'xcd_case.py')
+    env = dict(os.environ, DGS_EMU_BLOCKS='64', DGS_EMU_BLOCK_ORDER=order)
+    p = subprocess.run([sys.executable, script], capture_output=True, text=True, env=env, timeout=1500)
+    assert p.returncode == 0 and 'hub mismatches 0 all within 1e-5 True' in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
+    if order == 'rev':
+        env = dict(os.environ, DGS_EMU_BLOCKS='4', DGS_EMU_BLOCK_ORDER='rev')
+        p = subprocess.run([sys.executable, script], capture_output=True, text=True, env=env, timeout=1500)
+        assert p.returncode != 0 and 'DEADLOCK' in p.stderr and 'no room to dispatch' in p.stderr
