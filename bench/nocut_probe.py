@@ -68,12 +68,12 @@ for th in (0, 32768, 16384, 8192, 4096, 2048):
 for th in (16384, 8192, 4096):
     os.environ['DGS_HUB_CHAIN'] = str(th)
     res = {}
-    for xcd in (0, 1):
+    for xcd in (0, 1, 2):  # 1: every XCD works a fixed task sequence; 2: its workgroups claim whatever task is ready
         os.environ['DGS_HUB_XCD'] = str(xcd)
         _capi.reload_tuning()
         plan = _capi.spmm_plan(rp, col, st['K'], N)
         res[xcd] = _capi.spmm(_capi.SUM, rp, col, val, X, plan=plan)[0].clone()
         ms = t(lambda: _capi.spmm(_capi.SUM, rp, col, val, X, plan=plan))
         print(f'feat {N} hub chains above {th}, DGS_HUB_XCD={xcd}: planned sum {ms:.4f} ms', flush=True)
-    print(f'   slice-by-slice result == one-workgroup result, bit for bit: {bool(torch.equal(res[0], res[1]))}', flush=True)
+    print(f'   slice-by-slice results == one-workgroup result, bit for bit: {bool(torch.equal(res[0], res[1]) and torch.equal(res[0], res[2]))}', flush=True)
 os.environ.pop('DGS_HUB_XCD', None)

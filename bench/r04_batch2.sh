@@ -18,5 +18,6 @@ timeout 300 python -m pytest tests/test_gpu_strict.py -x -q -m gpu -k "slice_by_
 tail -n 5 $O/pytest_hub_xcd.txt
 timeout 900 python bench/nocut_probe.py 64 > $O/nocut_probe.txt 2>&1
 DGS_HUB_XCD=1 timeout 900 python bench.py --no-dense > $O/bench_line_hub_xcd.json 2> $O/bench_err_hub_xcd.txt
+DGS_HUB_XCD=2 timeout 900 python bench.py --no-dense > $O/bench_line_hub_xcd2.json 2> $O/bench_err_hub_xcd2.txt
 timeout 1800 python -m pytest tests -x -q -m gpu > $O/pytest_all.txt 2>&1
 tail -n 12 $O/strict_parts.txt $O/nocut_probe.txt $O/pytest_all.txt

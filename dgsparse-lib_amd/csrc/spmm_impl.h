@@ -162,7 +162,8 @@ static inline WsLayout ws_layout_plan(int reduce_op, int64_t N, int64_t pslots, 
   L.off_parte = prow;
   const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
   L.off_xacc = prow + (arg ? prow : 0);
-  L.xacc_bytes = (reduce_op == DGS_SUM || reduce_op == DGS_MEAN) ? up((size_t)n_hub * 8 * hub_xpitch(N) * 8) : 0;
+  // (8 bytes per hand-over word + 4 per claim word of the work-conserving deal)
+  L.xacc_bytes = (reduce_op == DGS_SUM || reduce_op == DGS_MEAN) ? up((size_t)n_hub * 8 * hub_xpitch(N) * 12) : 0;
   L.total = L.off_xacc + L.xacc_bytes + 256;
   return L;
 }
@@ -353,6 +354,7 @@ struct HubArg {
   // first) of its 8 column slices, the hand-over words [row][slice][xpitch floats of the padded width], zeroed by the launch
   const int *cuts = nullptr;
   unsigned long long *xacc = nullptr;
+  int *claim = nullptr;  // DGS_HUB_XCD=2: one claim word per hand-over slab (same indexing as xacc), zeroed with it
   int xpitch = 0;
 };
 
@@ -1496,6 +1498,8 @@ static int launch_impl(const SpmmArgs &a) {
       ha.cuts = reinterpret_cast<const int *>(hubp + (size_t)(a.plan_off_hub ? a.plan_hub : PL.max_hub) * sizeof(int4));
       ha.xacc = reinterpret_cast<unsigned long long *>(w + L.off_xacc);
       ha.xpitch = (int)hub_xpitch(a.N);
+      if (tune(tuning().hub_xcd, DGS_HUB_XCD) == 2)
+        ha.claim = reinterpret_cast<int *>(ha.xacc + (size_t)a.plan_hub * 8 * ha.xpitch);
       if (hipMemsetAsync(ha.xacc, 0, L.xacc_bytes, a.st) != hipSuccess) return DGS_ELAUNCH;
     }
     if (use_hub) ut.xcd_end = ph->xcd_hub;  // the hub rows' units (behind the others of each share) are not walked

@@ -566,19 +566,71 @@ __device__ __forceinline__ int spmm_hub_body(int bid, int nblocks, float *ldsf, 
       // and never waiting for it (no cycle; the hub blocks are the first of the grid)
       const int sb = bid / nx, SPB = nblocks / nx;
       const int ntask = ha.cnt[0] * SH;
-      for (int k = sb; k < ntask; k += SPB) {
+      constexpr int W = (G / SH) * V;
+      auto work = [&](int k) {
         const int g = k / SH, j = k - g * SH;
         const int4 d = ha.rows[g];
         const int c0 = ha.cuts[g * 8 + x], c1 = x == 7 ? d.z : ha.cuts[g * 8 + x + 1];
-        constexpr int W = (G / SH) * V;
         unsigned long long *slab = ha.xacc + ((int64_t)g * 8 + x) * ha.xpitch + tbase + j * W;
         HubLink lk;
         lk.in = x == 0 ? nullptr : slab - ha.xpitch;
         lk.out = x == 7 ? nullptr : slab;
         lk.full_len = d.z;
         strict_hub_coop<V, G / SH, MEAN, HAS_VAL, FMA, LDSF>(d.x, d.y + c0, c1 - c0, tbase, j, N, col, val, B, C, ldsf, epi, lk);
+      };
+      if (!ha.claim) {
+        for (int k = sb; k < ntask; k += SPB) work(k);
+        __syncthreads();
+        return 0;
       }
-      __syncthreads();
+      // DGS_HUB_XCD=2, work-conserving: instead of owning a fixed task sequence (whose 8-stage pipeline leaves a workgroup idle
+      // most of the time - experiments/hub_xcd_pipeline.py), a workgroup of XCD x CLAIMS any task whose segment x - 1 has been
+      // handed over (segment 0: any task).  Even slots look from the front of the table (longest rows: the critical paths),
+      // odd slots from the back (short rows: they reach the later XCDs soonest and end their idle start).  One claim word per
+      // (task, XCD), taken with a compare-and-swap by wave 0; nothing to claim but tasks left = sleep and look again.
+      __shared__ int s_pick;
+      const bool back = (sb & 1) != 0;
+      while (true) {
+        if (wave == 0) {
+          int pick = -1;
+          bool open = false;
+          for (int base = 0; base < ntask && pick < 0; base += kWave) {
+            const int i = base + lane, k = back ? ntask - 1 - i : i;
+            bool cand = false;
+            if (i < ntask) {
+              const int g = k / SH, j = k - g * SH;
+              const int64_t at = ((int64_t)g * 8 + x) * ha.xpitch + tbase + j * W;
+              if (__hip_atomic_load(ha.claim + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                open = true;
+                cand = x == 0 || (__hip_atomic_load(ha.xacc + at - ha.xpitch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != 0;
+              }
+            }
+            unsigned long long m = __ballot(cand);
+            while (m && pick < 0) {  // first candidate in scan order that nobody else takes in the meantime
+              const int l = __ffsll((long long)m) - 1;
+              m &= m - 1;
+              int got = 0;
+              if (lane == l) {
+                const int g = k / SH, j = k - g * SH;
+                got = atomicCAS(ha.claim + ((int64_t)g * 8 + x) * ha.xpitch + tbase + j * W, 0, 1) == 0 ? k + 1 : 0;
+              }
+              got = __shfl(got, l, kWave);
+              if (got) pick = got - 1;
+            }
+          }
+          const bool any_open = __ballot(open) != 0ull;
+          if (lane == 0) s_pick = pick >= 0 ? pick : (any_open ? -1 : -2);
+        }
+        __syncthreads();
+        const int k = s_pick;
+        __syncthreads();
+        if (k == -2) break;
+        if (k == -1) {
+          __builtin_amdgcn_s_sleep(32);
+          continue;
+        }
+        work(k);
+      }
       return 0;
     }
   }

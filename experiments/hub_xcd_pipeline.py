@@ -6,6 +6,7 @@ Inputs that ARE measured (profiles/r04_lds_dma_gather.txt part 2, fabric saturat
 chains a link in ~4 ns when its gathers miss; ASSUMED: 3 ns when two thirds of them hit the slice's L2, 3 us per hand-over
 (device-scope store -> poll on another XCD), 4 feature slices per row, the launch's hub grid (one workgroup per task up to
 4 per CU, a multiple of 8).  Output: finish time of the last hub task and the idle share of the hub workgroups, both modes."""
+import heapq
 import os
 import sys
 
@@ -59,3 +60,32 @@ for nb in (nbh, 104, 64, 32):
     print(f'slice by slice across the XCDs, {nb:4d} hub workgroups: last hub task done at {last:.0f} us; busy share until then '
           f'{busy / (last * nb):.2f}; workgroup-microseconds held {last * nb / 1000:.0f} k; the longest row alone: {done[7, :SH].max():.0f} us')
 print(f'(one workgroup per task holds {t_whole.sum() / 1000:.0f} k workgroup-microseconds, all of them busy)')
+
+# work-conserving: a workgroup of XCD s claims any unclaimed task whose segment s-1 is done; even slots scan longest-first, odd slots shortest-first
+def sim_claim(nb, mixed=True):
+    per = nb // 8
+    done = np.full((8, ntask), np.inf); claimed = np.zeros((8, ntask), bool)
+    ev = [(0.0, s, p) for s in range(8) for p in range(per)]  # (time a workgroup becomes free, xcd, slot)
+    heapq.heapify(ev); busy = 0.0; held_until = np.zeros((8, per)); last = 0.0
+    pending = 8 * ntask
+    while ev and pending:
+        t, s, p = heapq.heappop(ev)
+        order = range(ntask) if (not mixed or p % 2 == 0) else range(ntask - 1, -1, -1)
+        pick = None
+        for k in order:
+            if not claimed[s, k] and (s == 0 or done[s - 1, k] + HANDOVER_US <= t):
+                pick = k; break
+        if pick is None:
+            if claimed[s].all():
+                held_until[s, p] = t; continue
+            # sleep until the next producer finishes
+            nxt = min((done[s - 1, k] + HANDOVER_US for k in range(ntask) if not claimed[s, k] and np.isfinite(done[s - 1, k])), default=t + 1.0)
+            heapq.heappush(ev, (max(nxt, t + 0.5), s, p)); continue
+        claimed[s, pick] = True; pending -= 1
+        dur = seg[pick // SH, s] * NS_HIT * 1e-3
+        done[s, pick] = t + dur; busy += dur; last = max(last, t + dur); held_until[s, p] = t + dur
+        heapq.heappush(ev, (t + dur, s, p))
+    return last, busy / held_until.sum(), held_until.sum() / 1000
+for nb in (nbh, 104, 64):
+    for mixed in (False, True):
+        print('claim', 'front/back' if mixed else 'longest first', nb, 'last %.0f us, busy %.2f, held %.0f k' % sim_claim(nb, mixed))

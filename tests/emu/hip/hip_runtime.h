@@ -178,6 +178,8 @@ template <typename T>
 static inline T atomicAdd(T *p, T v) { const T o = *p; *p = o + v; return o; }
 static inline float unsafeAtomicAdd(float *p, float v) { const float o = *p; *p = o + v; return o; }
 template <typename T>
+static inline T atomicCAS(T *p, T cmp, T v) { const T o = *p; if (o == cmp) *p = v; return o; }
+template <typename T>
 static inline T atomicOr(T *p, T v) { const T o = *p; *p = o | v; return o; }
 template <typename T>
 static inline T atomicMax(T *p, T v) { const T o = *p; *p = o > v ? o : v; return o; }

@@ -17,7 +17,7 @@ val = rng.random(col.size, dtype=np.float32)
 X = rng.random((K, N), dtype=np.float32)
 ref, _ = oracle.spmm('sum', rp, col, val, X, fma=True)
 hub = deg > 1024
-E.set_env(DGS_HUB_CHAIN=1024, DGS_NBU=8, DGS_HUB_XCD=1)
+E.set_env(DGS_HUB_CHAIN=1024, DGS_NBU=8, DGS_HUB_XCD=int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 plan = E.spmm_plan(rp, col, K)
 t0 = time.time()
 C, _ = E.spmm(E.SUM, rp, col, val, X, plan=plan)

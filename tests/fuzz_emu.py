@@ -57,7 +57,7 @@ def one_case(rng, it):
     val = graphgen.weights(col.shape[0], kind, it) if kind else None
     X = (rng.integers(-3, 4, (K, N)) / 8).astype(np.float32)
     hubth = int(rng.choice([0, 1024, 1024, 2048, 16384]))
-    xcd = int(rng.integers(0, 2))  # planned sum / mean: hub rows slice by slice across the XCDs
+    xcd = int(rng.integers(0, 3))  # planned sum / mean: hub rows slice by slice across the XCDs (1 fixed deal, 2 claimed tasks)
     E.set_env(DGS_HUB_CHAIN=hubth, DGS_NBU=int(rng.choice([8, 16, 64])), DGS_STRICT_NBU=int(rng.choice([8, 16, 64])), DGS_HUB_XCD=xcd)
     tag = f'it={it} M={M} K={K} N={N} nnz={col.shape[0]} maxdeg={st["max_deg"]} val={kind} hub={hubth} xcd={xcd}'
     if os.environ.get('FUZZ_VERBOSE'):

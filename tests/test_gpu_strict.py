@@ -287,8 +287,9 @@ def test_single_launch_inputs_chain_their_hub_rows(capi, N):
     assert torch.equal(got, torch.relu(torch.from_numpy(C).to(d) * rs[:, None] + bias)), 'fused == unfused bit for bit'
 
 
+@pytest.mark.parametrize('mode', ['1', '2'], ids=['fixed deal', 'claimed tasks'])
 @pytest.mark.parametrize('N', [64, 128, 41])
-def test_hub_rows_slice_by_slice_across_the_xcds(capi, monkeypatch, N):
+def test_hub_rows_slice_by_slice_across_the_xcds(capi, monkeypatch, N, mode):
     """DGS_HUB_XCD=1: XCD s chains segment s (column slice s) of every hub row of the plan and hands the accumulators to XCD
     s + 1 through device-scope words in the workspace.  The chain is the same sequence of fmaf, so the result must equal the
     one-workgroup chain - and the oracle - bit for bit; repeated calls on one workspace (the hand-over area is zeroed per
@@ -305,7 +306,7 @@ def test_hub_rows_slice_by_slice_across_the_xcds(capi, monkeypatch, N):
     ref, _ = oracle.spmm('sum', rp, col, val, X, fma=True, threads=oracle.max_threads())
     monkeypatch.setenv('DGS_HUB_XCD', '0')
     C0, _ = _default(capi, 'sum', rp, col, val, X, True)
-    monkeypatch.setenv('DGS_HUB_XCD', '1')
+    monkeypatch.setenv('DGS_HUB_XCD', mode)  # 2: the workgroups claim ready tasks instead of owning a fixed sequence
     d = 'cuda'
     drp, dcol, dval, dX = (torch.from_numpy(a).to(d) for a in (rp, col, val, X))
     capi.reload_tuning()
