@@ -75,6 +75,7 @@ struct Fiber {
   State st = DONE;
   int wave = 0, lane = 0;
   bool relaxed = false;  // gave its turn away in a spin-wait (s_sleep): no progress of its own
+  int relaxes = 0;       // ... how often during the workgroup's current turn
 };
 struct Wave {
   unsigned char buf[64][16], snap[64][16];
@@ -309,14 +310,17 @@ void init_block(Block &b, dim3 bid, dim3 block, dim3 grid, unsigned nthr) {
   }
 }
 
-// Runs the current workgroup until it is finished or until a whole sweep over its work-items was nothing but spinning.
-// Returns true when it made progress of its own (so the caller's no-progress count restarts).
+// Runs the current workgroup until it is finished or until it has nothing to do but spin.  "Nothing but spin" = a sweep in which
+// every work-item that ran ended in a spin-wait, or - the work-items of a spinning workgroup need not be in step: the one that
+// released a barrier runs ahead of the others by a loop iteration for good - every runnable work-item has spun at least twice
+// during this turn.  Returns true when the turn looked like progress (a work-item finished, or nobody spun at all).
 bool run_block() {
-  bool progress = false;
+  bool finished_any = false, relaxed_any = false;
   int spins = 0;
   const unsigned nthr = (unsigned)blk->fibers.size();
+  for (auto &f : blk->fibers) f.relaxes = 0;
   while (blk->remaining > 0) {
-    bool ran = false, worked = false;
+    bool ran = false, worked = false, relaxed_now = false;
     const std::vector<unsigned> &ord = sweep_order(nthr);
     for (unsigned i = 0; i < nthr; i++) {
       Fiber &f = blk->fibers[ord[i]];
@@ -332,20 +336,34 @@ bool run_block() {
 #if EMU_ASAN
       __sanitizer_finish_switch_fiber(sched_fake, nullptr, nullptr);
 #endif
-      if (f.st == DONE) blk->remaining--;
-      if (!f.relaxed) worked = true;
+      if (f.st == DONE) {
+        blk->remaining--;
+        finished_any = true;
+      }
+      if (f.relaxed) {
+        f.relaxes++;
+        relaxed_now = relaxed_any = true;
+      } else {
+        worked = true;
+      }
     }
     if (!ran && !release_partial_collectives()) deadlock("no work-item can run");
-    if (worked || !ran) {
-      progress = true;
-      spins = 0;
-    } else if (max_resident > 1) {
-      return progress;  // every runnable work-item only spun: somebody else's turn
-    } else if (++spins > 1000000) {
-      return false;     // alone and spinning for good (a bounded spin - the panel sweep's soft barrier - runs out long before)
+    if (!ran) continue;
+    bool all_spun = relaxed_now;
+    if (all_spun && worked)
+      for (auto &f : blk->fibers)
+        if (f.st == RUN && f.relaxes < 2) {
+          all_spun = false;
+          break;
+        }
+    if (!all_spun) {
+      if (worked) spins = 0;
+      continue;
     }
+    if (max_resident > 1) return finished_any;  // somebody else's turn
+    if (++spins > 1000000) return false;  // alone and spinning for good (a bounded spin - the panel sweep's soft barrier - runs out long before)
   }
-  return true;
+  return finished_any || !relaxed_any;
 }
 }  // namespace
 
@@ -414,7 +432,8 @@ void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx) {
     blk = &b;
     for (size_t i = 0; i < nblocks; i++) {
       init_block(b, bid_of(order[i]), block, grid, nthr);
-      if (!run_block()) deadlock("its work-items wait for another workgroup, and workgroups run one at a time (DGS_EMU_BLOCKS)");
+      run_block();
+      if (b.remaining > 0) deadlock("its work-items wait for another workgroup, and workgroups run one at a time (DGS_EMU_BLOCKS)");
     }
     for (auto &f : b.fibers) stack_pool.push_back(f.stack);
   } else {
@@ -442,6 +461,7 @@ void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx) {
       b->fresh = false;
       blk = b;
       const bool progress = run_block();
+      if (getenv("DGS_EMU_TRACE")) fprintf(stderr, "turn %zu block %u,%u progress %d remaining %d resident %zu\n", turn, b->bid.x, b->bid.y, (int)progress, b->remaining, res.size());
       if (b->remaining == 0) {
         for (auto &f : b->fibers) stack_pool.push_back(f.stack);
         res.erase(res.begin() + (long)turn);
@@ -451,8 +471,10 @@ void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx) {
         continue;  // (the next one slid into this turn)
       }
       idle_rounds = progress ? 0 : idle_rounds + 1;
-      if (idle_rounds > 4 * (int)res.size() + 8 && next >= nblocks) deadlock("every resident workgroup spins and none is left to dispatch");
-      if (idle_rounds > 4 * (int)res.size() + 8 && (int)res.size() >= max_resident)
+      // (a turn that ends in a spin counts as idle even when the workgroup did real work before it: hence the generous limit)
+      const int idle_limit = 200 * (int)res.size() + 8;
+      if (idle_rounds > idle_limit && next >= nblocks) deadlock("every resident workgroup spins and none is left to dispatch");
+      if (idle_rounds > idle_limit && (int)res.size() >= max_resident)
         deadlock("every resident workgroup spins and there is no room to dispatch the one they wait for (DGS_EMU_BLOCKS)");
       turn++;
     }

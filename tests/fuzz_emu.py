@@ -62,6 +62,8 @@ def one_case(rng, it):
     tag = f'it={it} M={M} K={K} N={N} nnz={col.shape[0]} maxdeg={st["max_deg"]} val={kind} hub={hubth} xcd={xcd}'
     if os.environ.get('FUZZ_VERBOSE'):
         print('case', tag, flush=True)
+    if os.environ.get('FUZZ_DUMP'):  # the inputs of the case that is about to run (to replay a hang or a crash outside the campaign)
+        np.savez(os.environ['FUZZ_DUMP'], rp=rp, col=col, val=np.zeros(0, np.float32) if val is None else val, X=X, K=K, hubth=hubth, xcd=xcd)
     lens = np.diff(rp)
     C64 = oracle.spmm_sum_f64(rp, col, val, X)
     S64 = oracle.spmm_sum_f64(rp, col, val, X, absval=True)
