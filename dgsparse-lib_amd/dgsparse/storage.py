@@ -63,7 +63,7 @@ class _SharedPlan:
     from the device header, the host only sizes grids and the workspace with them); once the build's event has completed, a
     later use swaps in the compacted plan with the real counts and drops the worst-case build buffer (same tables, same bits).
     Which use is the first planned one depends on the use count alone, never on what has or has not completed yet."""
-    __slots__ = ('ptr', 'idx', 'K', 'prefix', 'calls', 'ready', 'prov', '__weakref__')
+    __slots__ = ('ptr', 'idx', 'K', 'prefix', 'calls', 'ready', 'prov', 'stats', '__weakref__')
 
     def __init__(self, ptr, idx, K, prefix=None):
         self.ptr, self.idx, self.K = ptr, idx, K
@@ -71,13 +71,16 @@ class _SharedPlan:
         self.calls = 0
         self.ready = None   # (compact plan buffer, plan info) once the build has been seen complete
         self.prov = None    # (build buffer, provisional info, pinned header copy, event, stream) in between
+        self.stats = None   # (pinned sums over the row lengths, event): what the provisional counts need; one copy for all sharers
 
-    def get(self, stats, wait=False):
+    def get(self, wait=False):
         if self.ready is not None:
             return self.ready
         cur = torch.cuda.current_stream(self.ptr.device)
         if self.prov is None:
-            host, ev = stats
+            if self.stats is None:
+                self.stats = _length_stats(self.ptr)
+            host, ev = self.stats
             ev.synchronize()  # four sums queued one use ago (or just now, DGS_PLAN_AFTER=0 / wait=True): never a poll
             buf, hdr = torch.ops.dgsparse_spmm.spmm_plan_start(self.ptr, self.idx, self.K, self.prefix)  # queued on `cur`
             done = torch.cuda.Event()
@@ -196,7 +199,6 @@ class Storage(object):
         self._plans = {}       # 'csr' / 'csc' -> _SharedPlan (shared with every Storage over the same buffers)
         self._sched = {}       # ('csr' | 'csc', feature width) -> does that shape take the planned schedule?
         self._tvalues = None   # (weakref to values, version, values in CSC order)
-        self._len_stats = {}   # 'csr' / 'csc' -> (pinned sums over the row lengths, event): what a provisional plan needs
         self.csr2csc_convert()
 
     @classmethod
@@ -275,12 +277,10 @@ class Storage(object):
                     # a matrix used once (sampled mini-batches) pays nothing; its SECOND use (or the last plan-free one) queues
                     # the row-length sums the build needs on a side stream (they used to be queued at construction,
                     # for every Storage, used or not)
-                    if (sp.calls == 2 or sp.calls == after) and which not in self._len_stats:
-                        self._len_stats[which] = _length_stats(ptr)
+                    if (sp.calls == 2 or sp.calls == after) and sp.stats is None:
+                        sp.stats = _length_stats(ptr)
                     return (None, None)
-            if which not in self._len_stats:
-                self._len_stats[which] = _length_stats(ptr)
-        return sp.get(self._len_stats[which], wait)
+        return sp.get(wait)
 
     def csc_values(self) -> torch.Tensor:
         """Edge values in CSC order (``values[csr2csc]``), recomputed only when ``values`` was replaced or updated in

@@ -488,6 +488,43 @@ def test_plan_lifecycle_lazy_async_shared(monkeypatch):
     assert torch.allclose(y, ref, rtol=1e-5, atol=1e-6)
 
 
+def test_second_tensor_over_the_same_arrays_while_the_plan_is_provisional(monkeypatch):
+    """a new SparseTensor per layer / iteration over the same graph lands inside the ~1.5 ms window in which
+    the shared plan is still provisional; it must get the build buffer (same stream) like the first one, never a KeyError."""
+    import dgsparse
+    from bench import graphgen
+    from dgsparse import storage as dst
+    monkeypatch.delenv('DGS_PLAN_AFTER', raising=False)
+    rp, col, st = graphgen.powerlaw_csr(70000, 900000, alpha=1.9, dmax=20000, seed=14, device='cuda', as_torch=True)
+    N = 64
+    X = torch.rand((st['K'], N), device='cuda')
+    A = dgsparse.SparseTensor(rowptr=rp, col=col, values=None, has_value=False)
+    ref = dgsparse.spmm_sum(A, X, 0)
+    torch.cuda.synchronize()
+    for k in range(dst._plan_after()):
+        dgsparse.spmm_sum(A, X, 0)  # the last of these queues the build: no synchronisation from here on
+    sp = A.storage._plans['csr']
+    outs = []
+    for k in range(4):
+        B = dgsparse.SparseTensor(rowptr=rp, col=col, values=None, has_value=False)
+        outs.append(dgsparse.spmm_sum(B, X, 0))
+        assert B.storage._plans['csr'] is sp
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.allclose(o, ref, rtol=1e-5, atol=1e-6)
+    # and a sharer on ANOTHER stream while provisional: plan-free there (None), not an error
+    C = dgsparse.SparseTensor(rowptr=rp.clone(), col=col.clone(), values=None, has_value=False)
+    for k in range(dst._plan_after() + 1):
+        dgsparse.spmm_sum(C, X, 0)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        D = dgsparse.SparseTensor(rowptr=C.storage.rowptr(), col=C.storage.col(), values=None, has_value=False)
+        out = dgsparse.spmm_sum(D, X, 0)
+    torch.cuda.synchronize()
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
+
+
 def test_schedule_switch_is_a_function_of_the_use_count_and_reproducible_mode(monkeypatch):
     """the plan-free and the planned schedule fold rows of 65 .. 8192 nnz with different trees, so WHEN a matrix
     switches must not depend on timing.  (i) Two fresh tensors over clones of the same arrays, one driven in a tight loop and
