@@ -361,7 +361,7 @@ def main():
             th = _capi.hub_threshold()
             dg = (rp[1:] - rp[:-1]).long()
             if th and int((dg > th).sum()) > 0:
-                extra['schedule'] += '+hub' + ('-xcd' + os.environ['DGS_HUB_XCD'] if planned and os.environ.get('DGS_HUB_XCD', '0') not in ('', '0') else '')
+                extra['schedule'] += '+hub'
             extra['hub_chain'] = dict(threshold=th, rows=int((dg > th).sum()) if th else 0,
                                       nnz=int(dg[dg > th].sum()) if th else 0,
                                       note='rows above the threshold are one sequential fmaf chain per feature (like rows <= 64 '

@@ -39,9 +39,8 @@ def main():
                ' - one sequential chain per (row, feature)', emulation='tests/emu (wave64 emulation of dgsparse-lib_amd/csrc, same C ABI)',
                rows_gt_16384=int((lens > 16384).sum()), rows_gt_8192=int((lens > 8192).sum()), runs={})
     for name, env, planned in (('hub chains on (default), plan-free', {}, False), ('hub chains on (default), planned', {}, True),
-                               ('hub chains on, slice by slice across the XCDs (DGS_HUB_XCD=1), planned', dict(DGS_HUB_XCD=1), True),
                                ('hub chains off (round-3 schedule), planned', dict(DGS_HUB_CHAIN=0), True)):
-        E.set_env(DGS_HUB_CHAIN=None, DGS_NBU=64, DGS_HUB_XCD=None)
+        E.set_env(DGS_HUB_CHAIN=None, DGS_NBU=64)
         E.set_env(**env)
         plan = E.spmm_plan(rp, col, st['K']) if planned else None
         t0 = time.time()
@@ -60,7 +59,7 @@ def main():
             hub_rows_bit_exact_vs_fmaf_chain=bool(np.array_equal(C[hub].view(np.int32), Cfma[hub].view(np.int32))) if hub.any() else None,
             max_rel_err_vs_fp64=float(e_gpu.max()), max_rel_err_vs_fp64_of_the_reference_itself=float(e_seq.max()),
             n_hub_in_plan=(int(plan[1].n_hub) if plan is not None else None), emulation_seconds=round(dt, 1))
-    E.set_env(DGS_HUB_CHAIN=None, DGS_NBU=None, DGS_HUB_XCD=None)
+    E.set_env(DGS_HUB_CHAIN=None, DGS_NBU=None)
     print(json.dumps(out, indent=1))
 
 

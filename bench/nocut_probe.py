@@ -62,18 +62,3 @@ for th in (0, 32768, 16384, 8192, 4096, 2048):
     m = deg > (th if th else 1 << 30)
     print(f'feat {N} hub chains above {th or "off"}: rows {int(m.sum())}, nnz {int(deg[m].sum())}, longest {int(deg.max())}: '
           f'planned sum {ms:.4f} ms, plan-free {ms0:.4f} ms', flush=True)
-
-# part 3: the same chains slice by slice across the XCDs (DGS_HUB_XCD=1: segment s of every hub row on XCD s, accumulators handed
-# on through the workspace): the locality of part 1's "off" line with the chains of part 2 - and the same bits
-for th in (16384, 8192, 4096):
-    os.environ['DGS_HUB_CHAIN'] = str(th)
-    res = {}
-    for xcd in (0, 1, 2):  # 1: every XCD works a fixed task sequence; 2: its workgroups claim whatever task is ready
-        os.environ['DGS_HUB_XCD'] = str(xcd)
-        _capi.reload_tuning()
-        plan = _capi.spmm_plan(rp, col, st['K'], N)
-        res[xcd] = _capi.spmm(_capi.SUM, rp, col, val, X, plan=plan)[0].clone()
-        ms = t(lambda: _capi.spmm(_capi.SUM, rp, col, val, X, plan=plan))
-        print(f'feat {N} hub chains above {th}, DGS_HUB_XCD={xcd}: planned sum {ms:.4f} ms', flush=True)
-    print(f'   slice-by-slice results == one-workgroup result, bit for bit: {bool(torch.equal(res[0], res[1]) and torch.equal(res[0], res[2]))}', flush=True)
-os.environ.pop('DGS_HUB_XCD', None)

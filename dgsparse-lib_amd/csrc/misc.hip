@@ -11,7 +11,9 @@
 namespace dgs {
 
 // ---- process-wide tuning snapshot + per-device facts (the only global state of the library; see dgs_common.h) -------------
-static Tuning g_tuning[2];
+// Every publish is a fresh heap snapshot that is never written again and never freed (64 bytes per dgs_reload_tuning(), a
+// tests-only call): a launch that holds `const Tuning &` keeps valid, unchanging values however many reloads follow (ADVICE r4:
+// two alternating static buffers were overwritten in place by the second reload).
 static std::atomic<const Tuning *> g_tuning_cur{nullptr};
 static std::mutex g_tuning_mu;
 static std::once_flag g_tuning_once;
@@ -35,14 +37,12 @@ static void tuning_read(Tuning &t) {
   t.plan_ch = rd("DGS_PLAN_CH");
   t.plan_nocut = rd("DGS_PLAN_NOCUT");
   t.hub_chain = rd("DGS_HUB_CHAIN");
-  t.hub_xcd = rd("DGS_HUB_XCD");
 }
 static void tuning_publish() {
   std::lock_guard<std::mutex> lk(g_tuning_mu);
-  const Tuning *cur = g_tuning_cur.load(std::memory_order_relaxed);
-  Tuning &next = g_tuning[cur == &g_tuning[0] ? 1 : 0];
-  tuning_read(next);
-  g_tuning_cur.store(&next, std::memory_order_release);
+  Tuning *next = new Tuning;
+  tuning_read(*next);
+  g_tuning_cur.store(next, std::memory_order_release);
 }
 const Tuning &tuning() {
   std::call_once(g_tuning_once, tuning_publish);

@@ -117,7 +117,7 @@ struct UnitTab {
 };
 
 struct WsLayout {
-  size_t off_units, off_long, off_part, off_parte, total, off_xacc, xacc_bytes;
+  size_t off_units, off_long, off_part, off_parte, total;
   int64_t max_units, max_pslots, max_long;
   int ch;
 };
@@ -150,10 +150,7 @@ static inline WsLayout ws_layout(int reduce_op, int64_t N, int64_t nnz) {
 }
 
 // With a cached plan the workspace only holds the partial rows of the multi-unit rows.
-// (+ for sum / mean over a plan with hub rows: the hand-over words of the slice-by-slice hub chains, one 64-bit word per hub
-// row, column slice and float of the width padded to 256 - spmm_strict.h HubLink; 0.8 MB for the 51 hub rows of the headline)
-static inline int64_t hub_xpitch(int64_t N) { return (N + 255) & ~int64_t(255); }
-static inline WsLayout ws_layout_plan(int reduce_op, int64_t N, int64_t pslots, int64_t n_hub = 0) {
+static inline WsLayout ws_layout_plan(int reduce_op, int64_t N, int64_t pslots) {
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
   WsLayout L{};
   L.max_pslots = pslots;
@@ -161,10 +158,7 @@ static inline WsLayout ws_layout_plan(int reduce_op, int64_t N, int64_t pslots, 
   const size_t prow = up((size_t)(pslots > 0 ? pslots : 1) * N * sizeof(float));
   L.off_parte = prow;
   const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
-  L.off_xacc = prow + (arg ? prow : 0);
-  // (8 bytes per hand-over word + 4 per claim word of the work-conserving deal)
-  L.xacc_bytes = (reduce_op == DGS_SUM || reduce_op == DGS_MEAN) ? up((size_t)n_hub * 8 * hub_xpitch(N) * 12) : 0;
-  L.total = L.off_xacc + L.xacc_bytes + 256;
+  L.total = prow + (arg ? prow : 0) + 256;
   return L;
 }
 // plan buffer: [256-byte header][column grid: 129 ints][units: max_units int4][long rows: max_long int4]; the capacities
@@ -191,9 +185,8 @@ static inline PlanLayout plan_layout(int64_t nnz) {
   L.max_hub = nnz / kHubChainMin + 16;
   L.off_long = L.off_units + up((size_t)L.max_units * sizeof(int4));
   L.off_hub = L.off_long + up((size_t)L.max_long * sizeof(int4));
-  // hub region: max_hub entries {row, first nnz, nnz, -}, then (round 4, slice-by-slice hub chains) 8 ints per entry: the first
-  // nnz, relative to the row's, of each of the row's 8 column slices.  (A compact plan: the same two tables, n_hub entries.)
-  L.total = L.off_hub + up((size_t)L.max_hub * (sizeof(int4) + 8 * sizeof(int))) + 256;
+  // hub region: max_hub entries {row, first nnz, nnz, -}  (a compact plan: n_hub entries)
+  L.total = L.off_hub + up((size_t)L.max_hub * sizeof(int4)) + 256;
   return L;
 }
 
@@ -350,12 +343,6 @@ struct HubArg {
   const int4 *rows;   // table the class regions of `ht` index
   HubTab ht;
   int ncls;           // kHubClasses (tables of a classify pass), 1 (a plan's table: dense, sorted longest first), 0 = none
-  // slice-by-slice mode (a plan's table only, DGS_HUB_XCD=1; spmm_strict.h HubLink): per row the first nnz (relative to the row's
-  // first) of its 8 column slices, the hand-over words [row][slice][xpitch floats of the padded width], zeroed by the launch
-  const int *cuts = nullptr;
-  unsigned long long *xacc = nullptr;
-  int *claim = nullptr;  // DGS_HUB_XCD=2: one claim word per hand-over slab (same indexing as xacc), zeroed with it
-  int xpitch = 0;
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1269,9 +1256,6 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
 #ifndef DGS_NBU
 #define DGS_NBU 1024  // persistent unit blocks of the fused launch
 #endif
-#ifndef DGS_HUB_XCD
-#define DGS_HUB_XCD 0  // planned sum / mean: 1 = hub rows chained slice by slice across the XCDs (env DGS_HUB_XCD overrides)
-#endif
 struct SpmmArgs {
   int64_t M, K, N, nnz;
   const int *rowptr, *col;
@@ -1467,7 +1451,7 @@ static int launch_impl(const SpmmArgs &a) {
     // cached plan: the unit tables already exist (hub rows cut at column-slice boundaries, sorted by slice and first
     // column, one slice per XCD), so the call is fused + combine; the workspace only holds the partial rows
     const char *pb = reinterpret_cast<const char *>(a.plan);
-    const WsLayout L = ws_layout_plan(a.reduce_op, a.N, a.plan_pslots, a.plan_hub);
+    const WsLayout L = ws_layout_plan(a.reduce_op, a.N, a.plan_pslots);
     char *w = static_cast<char *>(a.ws);
     float *part = reinterpret_cast<float *>(w + L.off_part);
     int *parte = reinterpret_cast<int *>(w + L.off_parte);
@@ -1487,21 +1471,7 @@ static int launch_impl(const SpmmArgs &a) {
     HubTab ht{};
     const char *hubp = pb + (a.plan_off_hub ? (size_t)a.plan_off_hub : PL.off_hub);
     HubArg ha{&ph->n_hub, reinterpret_cast<const int4 *>(hubp), ht, 1};
-    int nbh = use_hub ? hub_blocks((int64_t)a.plan_hub * strict_shub(G, V)) : 0;
-    if (use_hub && tune(tuning().hub_xcd, DGS_HUB_XCD) != 0 && (nbh & 7) == 0 && L.xacc_bytes) {
-      // (workgroups that wait for one another: all of them, over all feature tiles, fit the chip twice over - whatever order
-      // the dispatcher takes them in, a waiting one can never keep its producer from starting)
-      const int cap = ((2 * cu_count() / (int)a.tiles) & ~7) < 8 ? 8 : ((2 * cu_count() / (int)a.tiles) & ~7);
-      if (nbh > cap) nbh = cap;
-      // slice by slice (spmm_strict.h HubLink): the cut table sits behind the hub rows - max_hub of them in a build buffer,
-      // n_hub in a compact plan
-      ha.cuts = reinterpret_cast<const int *>(hubp + (size_t)(a.plan_off_hub ? a.plan_hub : PL.max_hub) * sizeof(int4));
-      ha.xacc = reinterpret_cast<unsigned long long *>(w + L.off_xacc);
-      ha.xpitch = (int)hub_xpitch(a.N);
-      if (tune(tuning().hub_xcd, DGS_HUB_XCD) == 2)
-        ha.claim = reinterpret_cast<int *>(ha.xacc + (size_t)a.plan_hub * 8 * ha.xpitch);
-      if (hipMemsetAsync(ha.xacc, 0, L.xacc_bytes, a.st) != hipSuccess) return DGS_ELAUNCH;
-    }
+    const int nbh = use_hub ? hub_blocks((int64_t)a.plan_hub * strict_shub(G, V)) : 0;
     if (use_hub) ut.xcd_end = ph->xcd_hub;  // the hub rows' units (behind the others of each share) are not walked
     launch_fused<G, V, OP, HAS_VAL, ACC>(a, nbh, nbu, nbr, rpw, ut, part, parte, ha);
     if (a.plan_long > 0) {

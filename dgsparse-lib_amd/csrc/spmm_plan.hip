@@ -232,23 +232,6 @@ __global__ __launch_bounds__(kBlock) void plan_rowunits(int ch, int tslice, int 
   }
 }
 
-// Hub rows (sorted table): where each of the row's 8 column slices starts.  A row whose columns are not ascending has all its
-// nnz in "slice 0" (the slice-by-slice chain then runs on one XCD, in CSR order as ever).
-__global__ __launch_bounds__(kBlock) void plan_hubcuts(int max_hub, const PlanWs *__restrict__ pw, const int4 *__restrict__ hub_rows,
-                                                       const int *__restrict__ col, const PlanHdr *__restrict__ hdr,
-                                                       int *__restrict__ cuts) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n = min(pw->n_hub, max_hub);
-  for (int i = blockIdx.x * (kBlock / kWave) + wave; i < n; i += gridDim.x * (kBlock / kWave)) {
-    const int4 d = hub_rows[i];
-    const int rs = d.y, re = d.y + d.z;
-    bool ok = true;
-    for (int p = rs + lane; p + 1 < re; p += kWave) ok &= col[p] <= col[p + 1];
-    const bool sorted = __ballot(!ok) == 0ull;
-    if (lane < 8) cuts[i * 8 + lane] = lane == 0 ? 0 : (sorted ? seg_lower_bound(col, rs, re, hdr->slice_bound[lane]) - rs : d.z);
-  }
-}
-
 __global__ void plan_totals(const PlanWs *__restrict__ pw, const int4 *__restrict__ info, const int4 *__restrict__ scan,
                             PlanHdr *__restrict__ hdr) {
   const int n = pw->n_longlist;
@@ -424,8 +407,6 @@ extern "C" int dgs_spmm_plan_build2(int64_t M, int64_t K, int64_t nnz, const int
   if (rocprim::radix_sort_pairs(tmp, tb, hkeys_in, hkeys_out, hub_in, hub_rows, (size_t)PL.max_hub, 0, 32, st, false) !=
       hipSuccess)
     return DGS_ELAUNCH;
-  hipLaunchKernelGGL(plan_hubcuts, dim3(64), dim3(kBlock), 0, st, (int)PL.max_hub, pw, hub_rows, col, hdr,
-                     reinterpret_cast<int *>(pb + PL.off_hub + (size_t)PL.max_hub * sizeof(int4)));
   tb = WL.tmp_bytes;
   if (rocprim::exclusive_scan(tmp, tb, rinfo, rscan, make_int4(0, 0, 0, 0), (size_t)WL.cap_long, I4Plus(), st, false) !=
       hipSuccess)
@@ -500,9 +481,13 @@ extern "C" int dgs_spmm_plan_provisional_info(int64_t nnz, int64_t rows_gt_t1, i
   info->n_pslots = (int32_t)units;
   info->tslice = plan_tslice();
   info->off_long = 0;  // the build-time layout
-  {  // hub rows: at most every row longer than tslice, and no more than fit nnz (a bound: it only sizes the hub grid)
+  {  // hub rows, an UPPER bound (it sizes the hub grid, and 0 must mean "no hub row"): every row longer than the threshold is
+    // longer than tslice when thub >= tslice, and in any case longer than t1 (thub >= kHubChainMin > t1); no more than fit
+    // the nnz of those rows (with DGS_PLAN_TSLICE above DGS_HUB_CHAIN the tslice sums under-counted)
     const int thub = hub_threshold();
-    const int64_t hb = thub == INT_MAX ? 0 : (rows_gt_tslice < nnz_gt_tslice / thub ? rows_gt_tslice : nnz_gt_tslice / thub);
+    const bool above = thub >= info->tslice;
+    const int64_t rows = above ? rows_gt_tslice : rows_gt_t1, nz = above ? nnz_gt_tslice : nnz_gt_t1;
+    const int64_t hb = thub == INT_MAX ? 0 : (rows < nz / thub ? rows : nz / thub);
     info->n_hub = (int32_t)(hb < PL.max_hub ? hb : PL.max_hub);
   }
   info->off_hub = 0;
@@ -512,14 +497,14 @@ extern "C" int dgs_spmm_plan_provisional_info(int64_t nnz, int64_t rows_gt_t1, i
 extern "C" size_t dgs_spmm_csr_plan_workspace_bytes(int reduce_op, int64_t M, int64_t N, int64_t nnz,
                                                     const dgsSpmmPlanInfo *info) {
   if (M <= 0 || N <= 0 || nnz <= 0 || !info) return 0;
-  return ws_layout_plan(reduce_op, N, info->n_pslots, info->n_hub).total;
+  return ws_layout_plan(reduce_op, N, info->n_pslots).total;
 }
 
 extern "C" size_t dgs_spmm_plan_compact_bytes(const dgsSpmmPlanInfo *info) {
   if (!info) return 0;
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
   return 256 + 768 + up((size_t)info->n_units * sizeof(int4)) + up((size_t)info->n_long * sizeof(int4)) +
-         up((size_t)info->n_hub * (sizeof(int4) + 8 * sizeof(int))) + 256;
+         up((size_t)info->n_hub * sizeof(int4)) + 256;
 }
 
 extern "C" int dgs_spmm_plan_compact(const void *plan, dgsSpmmPlanInfo *info, void *compact, size_t compact_bytes,
@@ -532,16 +517,13 @@ extern "C" int dgs_spmm_plan_compact(const void *plan, dgsSpmmPlanInfo *info, vo
   const char *src = static_cast<const char *>(plan);
   char *dst = static_cast<char *>(compact);
   const size_t ub = (size_t)info->n_units * sizeof(int4), lb = (size_t)info->n_long * sizeof(int4);
-  const size_t hb = (size_t)info->n_hub * sizeof(int4), cb = (size_t)info->n_hub * 8 * sizeof(int);
+  const size_t hb = (size_t)info->n_hub * sizeof(int4);
   const size_t off_long = PL.off_units + up(ub), off_hub = off_long + up(lb);
-  if (off_hub + up(hb + cb) > (size_t)INT32_MAX) return DGS_ERANGE;  // the offsets are 32-bit (2^27 units: beyond any int32 nnz / 64)
+  if (off_hub + up(hb) > (size_t)INT32_MAX) return DGS_ERANGE;  // the offsets are 32-bit (2^27 units: beyond any int32 nnz / 64)
   if (hipMemcpyAsync(dst, src, PL.off_units + ub, hipMemcpyDeviceToDevice, st) != hipSuccess) return DGS_ELAUNCH;
   if (lb && hipMemcpyAsync(dst + off_long, src + PL.off_long, lb, hipMemcpyDeviceToDevice, st) != hipSuccess)
     return DGS_ELAUNCH;
   if (hb && hipMemcpyAsync(dst + off_hub, src + PL.off_hub, hb, hipMemcpyDeviceToDevice, st) != hipSuccess) return DGS_ELAUNCH;
-  if (cb && hipMemcpyAsync(dst + off_hub + hb, src + PL.off_hub + (size_t)PL.max_hub * sizeof(int4), cb, hipMemcpyDeviceToDevice,
-                           st) != hipSuccess)
-    return DGS_ELAUNCH;
   info->off_long = (int32_t)off_long;
   info->off_hub = (int32_t)off_hub;
   return DGS_OK;

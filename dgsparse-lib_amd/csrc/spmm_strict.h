@@ -210,40 +210,6 @@ __device__ __forceinline__ void strict_unit(const int row, const int p0, const i
 // ~11 clocks per link.  The window below is straight-line - every read is issued, its index clamped into the tile - and
 // rolls four b128 pairs (16 links) ahead of the fmas.
 constexpr int kHubBlockFloats = 7008;  // what strict_hub_coop needs at most (16 x 388 + 2 x 384 + 16): 28 KB, 5 workgroups per CU
-// A hub row worked SLICE BY SLICE of the column grid (planned sum / mean launches, DGS_HUB_XCD=1): the workgroups of XCD s chain
-// the row's nnz of column slice s - in the L2 that sees nothing but that slice of the dense operand - and hand the running
-// accumulators to XCD s + 1 through memory: one 64-bit word per chain lane, {tag 1, float bits}, written and polled with
-// device-scope atomics (a single word: no fence on either side; the area is zeroed by the launch).  The chain is the
-// same sequence of fmaf as on one workgroup - CSR order, rows with sorted columns only - so the result does not change by a bit.
-struct HubLink {
-  const unsigned long long *in = nullptr;  // accumulators of the previous segment (nullptr: this is the first one)
-  unsigned long long *out = nullptr;       // where the next segment reads them (nullptr: this is the last one: store the row)
-  int full_len = 0;                        // nnz of the whole row (mean); 0 = no link at all: a whole row on one workgroup
-};
-__device__ __forceinline__ float hub_link_in(const HubLink &lk, int lane) {
-  if (!lk.in) return 0.0f;
-  unsigned long long v;
-  while (true) {
-    v = __hip_atomic_load(lk.in + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (v >> 32) break;
-    __builtin_amdgcn_s_sleep(4);
-  }
-  return __uint_as_float((unsigned)v);
-}
-template <bool MEAN>
-__device__ __forceinline__ void hub_link_out(const HubLink &lk, float acc, int row, int f, int N, float *__restrict__ C,
-                                             const Epi &epi, int lane) {
-  if (lk.out) {
-    __hip_atomic_store(lk.out + lane, (1ull << 32) | (unsigned long long)__float_as_uint(acc), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  } else if (f < N) {
-    if constexpr (MEAN) acc /= (float)lk.full_len;
-    float o[1] = {acc};
-    epi_apply<1>(o, row, f, epi);
-    store_vec_stream<1>(C + (int64_t)row * N + f, o);
-  }
-}
-
 constexpr int strict_hub_lds(int V, int GP, int us) {  // floats of LDS of one workgroup phase with `us` gathers per lane and set
   return GP * V * (3 * us * (kWave / GP) + 4) + 2 * 3 * us * (kWave / GP) + 16;
 }
@@ -251,7 +217,7 @@ template <int V, int GP, bool MEAN, bool HAS_VAL, bool FMA, int LDSF = kStrictBl
 __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, const int len, const int tbase, const int sl,
                                                 const int N, const int *__restrict__ col, const float *__restrict__ val,
                                                 const float *__restrict__ B, float *__restrict__ C, float *lds,
-                                                const Epi &epi = Epi{}, const HubLink &lk = HubLink{}) {
+                                                const Epi &epi = Epi{}) {
   constexpr int NWG = kBlock / kWave - 1;       // gather waves (wave 0 chains and does nothing else)
   constexpr int NGP = kWave / GP, W = GP * V;   // nnz per load instruction; floats (= chain lanes) of the slice
   // gathers per lane and set: kUS where the tile then fits the launch's LDS (every shape the headline runs), half of it for the
@@ -266,10 +232,6 @@ __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, con
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int fbase = tbase + sl * W;
   const int nph = (len + NRB - 1) / NRB;
-  if (len == 0) {  // an empty segment of a hub row worked slice by slice (HubLink): hand the accumulators on, no barrier at all
-    if (wave == 0 && lane < W) hub_link_out<MEAN>(lk, hub_link_in(lk, lane), row, fbase + lane, N, C, epi, lane);
-    return;
-  }
   // Roles: the two kinds of waves share nothing but the tile and two barriers per phase (A: tile written, B: tile chained), so
   // the kernel's register budget is the larger of the two roles, not their sum (the first round-4 version, every wave with two
   // gather sets AND the chain window, spilled the chain's addresses to scratch and drained vmcnt inside the chain loop).
@@ -284,7 +246,6 @@ __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, con
     __syncthreads();
     __syncthreads();
     __syncthreads();
-    acc = hub_link_in(lk, lane < W ? lane : 0);  // (behind the prologue: the gathers of two phases fly while this wave waits)
     if (DGS_STRICT_PRIO) __builtin_amdgcn_s_setprio(3);
     for (int ph = 0; ph < nph; ph++) {
       const int cnt = min(NRB, len - ph * NRB);
@@ -321,15 +282,11 @@ __device__ __forceinline__ void strict_hub_coop(const int row, const int p0, con
       __syncthreads();  // B
     }
     if (DGS_STRICT_PRIO) __builtin_amdgcn_s_setprio(0);
-    if (lane < W) {
-      if (lk.full_len) {
-        hub_link_out<MEAN>(lk, acc, row, fbase + lane, N, C, epi, lane);
-      } else if (fbase + lane < N) {
-        if constexpr (MEAN) acc /= (float)len;
-        float o[1] = {acc};
-        epi_apply<1>(o, row, fbase + lane, epi);
-        store_vec_stream<1>(C + (int64_t)row * N + fbase + lane, o);
-      }
+    if (lane < W && fbase + lane < N) {
+      if constexpr (MEAN) acc /= (float)len;
+      float o[1] = {acc};
+      epi_apply<1>(o, row, fbase + lane, epi);
+      store_vec_stream<1>(C + (int64_t)row * N + fbase + lane, o);
     }
     return;
   }
@@ -558,82 +515,6 @@ __device__ __forceinline__ int spmm_hub_body(int bid, int nblocks, float *ldsf, 
   const int x = bid % nx;
   const int SP = (nblocks / nx) * (kBlock / kWave);  // wave slots of this XCD
   int rot = 0;
-  if constexpr (COOP && DGS_HUB_COOP_V2) {
-    if (ha.cuts && nx == 8) {
-      // slice by slice: XCD x chains segment x of every (row, feature slice) task, the tasks dealt to its workgroup slots in
-      // table order (longest rows first), the same deal on every XCD - so the producer of (task, x - 1) is workgroup slot
-      // bid / 8 of XCD x - 1: a LOWER block index working through the same task sequence, i.e. dispatched before this block
-      // and never waiting for it (no cycle; the hub blocks are the first of the grid)
-      const int sb = bid / nx, SPB = nblocks / nx;
-      const int ntask = ha.cnt[0] * SH;
-      constexpr int W = (G / SH) * V;
-      auto work = [&](int k) {
-        const int g = k / SH, j = k - g * SH;
-        const int4 d = ha.rows[g];
-        const int c0 = ha.cuts[g * 8 + x], c1 = x == 7 ? d.z : ha.cuts[g * 8 + x + 1];
-        unsigned long long *slab = ha.xacc + ((int64_t)g * 8 + x) * ha.xpitch + tbase + j * W;
-        HubLink lk;
-        lk.in = x == 0 ? nullptr : slab - ha.xpitch;
-        lk.out = x == 7 ? nullptr : slab;
-        lk.full_len = d.z;
-        strict_hub_coop<V, G / SH, MEAN, HAS_VAL, FMA, LDSF>(d.x, d.y + c0, c1 - c0, tbase, j, N, col, val, B, C, ldsf, epi, lk);
-      };
-      if (!ha.claim) {
-        for (int k = sb; k < ntask; k += SPB) work(k);
-        __syncthreads();
-        return 0;
-      }
-      // DGS_HUB_XCD=2, work-conserving: instead of owning a fixed task sequence (whose 8-stage pipeline leaves a workgroup idle
-      // most of the time - experiments/hub_xcd_pipeline.py), a workgroup of XCD x CLAIMS any task whose segment x - 1 has been
-      // handed over (segment 0: any task).  Even slots look from the front of the table (longest rows: the critical paths),
-      // odd slots from the back (short rows: they reach the later XCDs soonest and end their idle start).  One claim word per
-      // (task, XCD), taken with a compare-and-swap by wave 0; nothing to claim but tasks left = sleep and look again.
-      __shared__ int s_pick;
-      const bool back = (sb & 1) != 0;
-      while (true) {
-        if (wave == 0) {
-          int pick = -1;
-          bool open = false;
-          for (int base = 0; base < ntask && pick < 0; base += kWave) {
-            const int i = base + lane, k = back ? ntask - 1 - i : i;
-            bool cand = false;
-            if (i < ntask) {
-              const int g = k / SH, j = k - g * SH;
-              const int64_t at = ((int64_t)g * 8 + x) * ha.xpitch + tbase + j * W;
-              if (__hip_atomic_load(ha.claim + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                open = true;
-                cand = x == 0 || (__hip_atomic_load(ha.xacc + at - ha.xpitch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != 0;
-              }
-            }
-            unsigned long long m = __ballot(cand);
-            while (m && pick < 0) {  // first candidate in scan order that nobody else takes in the meantime
-              const int l = __ffsll((long long)m) - 1;
-              m &= m - 1;
-              int got = 0;
-              if (lane == l) {
-                const int g = k / SH, j = k - g * SH;
-                got = atomicCAS(ha.claim + ((int64_t)g * 8 + x) * ha.xpitch + tbase + j * W, 0, 1) == 0 ? k + 1 : 0;
-              }
-              got = __shfl(got, l, kWave);
-              if (got) pick = got - 1;
-            }
-          }
-          const bool any_open = __ballot(open) != 0ull;
-          if (lane == 0) s_pick = pick >= 0 ? pick : (any_open ? -1 : -2);
-        }
-        __syncthreads();
-        const int k = s_pick;
-        __syncthreads();
-        if (k == -2) break;
-        if (k == -1) {
-          __builtin_amdgcn_s_sleep(32);
-          continue;
-        }
-        work(k);
-      }
-      return 0;
-    }
-  }
   if constexpr (COOP) {
     const int sb = bid / nx, SPB = nblocks / nx;  // workgroup slots of this XCD
     int rotb = 0;

@@ -104,9 +104,6 @@ int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_
  * The threshold is DGS_HUB_CHAIN (default 16384, clamped to >= 1024, 0 = no hub chains: every row above 64 nnz takes the
  * tree); the chain's own rounding error grows like sqrt(nnz) and passes 1e-5 of the exact sum beyond ~3 10^4 nnz, which is
  * where a tree - however accurate - stops being within 1e-5 of the REFERENCE.  DGS_ALG_STRICT_SUM / _NOFMA chain every row.
- * DGS_HUB_XCD=1 | 2 (experimental, planned sum / mean only; 2 = work-conserving task claims): a hub row's chain moves from XCD to XCD with the column slices of the
- * plan instead of staying on one workgroup - same arithmetic, same bits; needs the workspace size this header's
- * dgs_spmm_csr_plan_workspace_bytes() reports (it includes the hand-over words).
  * dgs_spmm_hub_threshold() returns the threshold in force (0 = off).
  */
 int dgs_spmm_hub_threshold(void);

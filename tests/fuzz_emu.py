@@ -57,13 +57,12 @@ def one_case(rng, it):
     val = graphgen.weights(col.shape[0], kind, it) if kind else None
     X = (rng.integers(-3, 4, (K, N)) / 8).astype(np.float32)
     hubth = int(rng.choice([0, 1024, 1024, 2048, 16384]))
-    xcd = int(rng.integers(0, 3))  # planned sum / mean: hub rows slice by slice across the XCDs (1 fixed deal, 2 claimed tasks)
-    E.set_env(DGS_HUB_CHAIN=hubth, DGS_NBU=int(rng.choice([8, 16, 64])), DGS_STRICT_NBU=int(rng.choice([8, 16, 64])), DGS_HUB_XCD=xcd)
-    tag = f'it={it} M={M} K={K} N={N} nnz={col.shape[0]} maxdeg={st["max_deg"]} val={kind} hub={hubth} xcd={xcd}'
+    E.set_env(DGS_HUB_CHAIN=hubth, DGS_NBU=int(rng.choice([8, 16, 64])), DGS_STRICT_NBU=int(rng.choice([8, 16, 64])))
+    tag = f'it={it} M={M} K={K} N={N} nnz={col.shape[0]} maxdeg={st["max_deg"]} val={kind} hub={hubth}'
     if os.environ.get('FUZZ_VERBOSE'):
         print('case', tag, flush=True)
     if os.environ.get('FUZZ_DUMP'):  # the inputs of the case that is about to run (to replay a hang or a crash outside the campaign)
-        np.savez(os.environ['FUZZ_DUMP'], rp=rp, col=col, val=np.zeros(0, np.float32) if val is None else val, X=X, K=K, hubth=hubth, xcd=xcd)
+        np.savez(os.environ['FUZZ_DUMP'], rp=rp, col=col, val=np.zeros(0, np.float32) if val is None else val, X=X, K=K, hubth=hubth)
     lens = np.diff(rp)
     C64 = oracle.spmm_sum_f64(rp, col, val, X)
     S64 = oracle.spmm_sum_f64(rp, col, val, X, absval=True)

@@ -45,10 +45,8 @@ def one_case(rng, it):
         os.environ['DGS_HUB_CHAIN'] = str(hubth)
     else:
         os.environ.pop('DGS_HUB_CHAIN', None)
-    xcd = str(int(rng.integers(0, 3)))  # planned sum / mean: hub rows slice by slice across the XCDs (1 fixed deal, 2 claimed tasks)
-    os.environ['DGS_HUB_XCD'] = xcd
     capi.reload_tuning()
-    tag = f'it={it} M={M} K={K} N={N} nnz={col.shape[0]} maxdeg={st["max_deg"]} val={kind} hub={hubth or "default"} xcd={xcd}'
+    tag = f'it={it} M={M} K={K} N={N} nnz={col.shape[0]} maxdeg={st["max_deg"]} val={kind} hub={hubth or "default"}'
     if os.environ.get('FUZZ_VERBOSE'):
         print('case', tag, flush=True)
     drp, dcol, dval, dX = dev(rp), dev(col), (None if val is None else dev(val)), dev(X)

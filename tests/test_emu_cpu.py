@@ -295,64 +295,3 @@ def test_single_launch_inputs_chain_their_hub_rows(N):
         assert (np.abs(C0 - ref) <= 1e-5 * np.abs(ref) + 1e-6).all()
 
 
-@pytest.mark.parametrize('mode', [1, 2], ids=['fixed deal', 'claimed tasks'])
-@pytest.mark.parametrize('N', [64, 41, 128])
-def test_hub_rows_slice_by_slice_across_the_xcds(graph, N, mode):
-    """DGS_HUB_XCD=1 / 2 (planned sum / mean; 2 = the workgroups CLAIM ready tasks instead of owning a fixed sequence): the
-    workgroups of XCD s chain segment s (column slice s) of every hub row and hand
-    the accumulators on through the workspace - same sequence of fmaf, so the same bits as the one-workgroup chain and the
-    oracle.  Covered: compact plan / build buffer / provisional counts, a hub row with unsorted columns (all of it in "slice
-    0"), one whose columns end in the second slice (empty segments that only pass the accumulators on), mean with unit
-    weights, the fused epilogue; max over the same plan is untouched.  The hand-over area of the workspace is really used."""
-    rp, col, val, K, deg = graph
-    rng = np.random.default_rng(8)
-    col = col.copy()
-    rng.shuffle(col[rp[100]:rp[101]])
-    col[rp[7000]:rp[7001]] = np.sort(rng.choice(K // 3, 1500, replace=False))
-    X = feats(K, N)
-    hub = deg > 1024
-    ref, _ = oracle.spmm('sum', rp, col, val, X, fma=True)
-    refm, _ = oracle.spmm('mean', rp, col, None, X, fma=True)
-    E.set_env(DGS_HUB_XCD=mode)
-    try:
-        plan = E.spmm_plan(rp, col, K)
-        big, real = E.spmm_plan(rp, col, K, compact=False)
-        for name, pl in (('compact', plan), ('build buffer', (big, real)), ('provisional counts', (big, E.provisional_info(rp)))):
-            C, _ = E.spmm(E.SUM, rp, col, val, X, plan=pl)
-            assert not np.isnan(C).any(), name
-            assert_bitexact(C[hub], ref[hub], f'{name}: hub rows N={N}')
-            assert (np.abs(C - ref) <= 1e-5 * np.abs(ref) + 1e-6).all(), name
-            xpitch = (N + 255) // 256 * 256
-            area = E.last_ws[-(int(pl[1].n_hub) * 8 * xpitch * 12 + 256 + 64):]
-            assert (area != 0).any(), 'the accumulators went through the workspace'
-            Cm, _ = E.spmm(E.MEAN, rp, col, None, X, plan=pl)
-            assert_bitexact(Cm[hub], refm[hub], f'{name}: mean, unit weights N={N}')
-        bias, sc = rng.random(N, dtype=np.float32), rng.random(rp.size - 1, dtype=np.float32)
-        Ce = E.spmm_ex(E.SUM, rp, col, val, X, bias=bias, row_scale=sc, relu=True, plan=plan)
-        assert_bitexact(Ce[hub], np.maximum(sc[:, None] * ref + bias[None, :], 0).astype(np.float32)[hub], 'epilogue')
-        Cx, Ex = E.spmm(E.MAX, rp, col, val, X, plan=plan)
-        rx, ex = oracle.spmm('max', rp, col, val, X)
-        assert_bitexact(Cx, rx, 'max over the same plan')
-        assert_bitexact(Ex, ex, 'max arg ids')
-    finally:
-        E.set_env(DGS_HUB_XCD=None)
-
-
-@pytest.mark.parametrize('mode', ['1', '2'], ids=['fixed deal', 'claimed tasks'])
-@pytest.mark.parametrize('order', ['rev', 'rand:3'])
-def test_slice_by_slice_hub_chains_with_consumers_dispatched_before_their_producers(order, mode):
-    """The slice-by-slice hub chains are workgroups that WAIT for one another.  With DGS_EMU_BLOCKS = 64 the emulation keeps
-    that many workgroups resident and lets them take turns (a workgroup gives its turn away when all it did was spin), and
-    DGS_EMU_BLOCK_ORDER dispatches them in reverse / random order: every consumer is resident before its producer and has to
-    wait for the hand-over word, not fail.  (With 4 resident workgroups and reverse dispatch the same case ends in the
-    emulator's deadlock report - the situation the in-order dispatch of the hub blocks at the head of the grid rules out.)"""
-    import subprocess
-    E.lib()
-    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu', 'xcd_case.py')
-    env = dict(os.environ, DGS_EMU_BLOCKS='64', DGS_EMU_BLOCK_ORDER=order)
-    p = subprocess.run([sys.executable, script, mode], capture_output=True, text=True, env=env, timeout=1500)
-    assert p.returncode == 0 and 'hub mismatches 0 all within 1e-5 True' in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
-    if order == 'rev' and mode == '1':
-        env = dict(os.environ, DGS_EMU_BLOCKS='4', DGS_EMU_BLOCK_ORDER='rev')
-        p = subprocess.run([sys.executable, script, mode], capture_output=True, text=True, env=env, timeout=1500)
-        assert p.returncode != 0 and 'DEADLOCK' in p.stderr and 'no room to dispatch' in p.stderr

@@ -287,41 +287,3 @@ def test_single_launch_inputs_chain_their_hub_rows(capi, N):
     assert torch.equal(got, torch.relu(torch.from_numpy(C).to(d) * rs[:, None] + bias)), 'fused == unfused bit for bit'
 
 
-@pytest.mark.parametrize('mode', ['1', '2'], ids=['fixed deal', 'claimed tasks'])
-@pytest.mark.parametrize('N', [64, 128, 41])
-def test_hub_rows_slice_by_slice_across_the_xcds(capi, monkeypatch, N, mode):
-    """DGS_HUB_XCD=1: XCD s chains segment s (column slice s) of every hub row of the plan and hands the accumulators to XCD
-    s + 1 through device-scope words in the workspace.  The chain is the same sequence of fmaf, so the result must equal the
-    one-workgroup chain - and the oracle - bit for bit; repeated calls on one workspace (the hand-over area is zeroed per
-    call), a hub row with unsorted columns, mean with unit weights, and max over the same plan."""
-    monkeypatch.setenv('DGS_HUB_CHAIN', '1024')
-    rp, col, st = graphgen.powerlaw_csr(70000, 900000, alpha=1.9, dmax=20000, seed=21)
-    lens = np.diff(rp)
-    hub = lens > 1024
-    col = col.copy()
-    r = int(np.argmax(lens))
-    np.random.default_rng(3).shuffle(col[rp[r]:rp[r + 1]])
-    val = graphgen.weights(col.shape[0], 'uniform', 5)
-    X = graphgen.features(st['K'], N, 6)
-    ref, _ = oracle.spmm('sum', rp, col, val, X, fma=True, threads=oracle.max_threads())
-    monkeypatch.setenv('DGS_HUB_XCD', '0')
-    C0, _ = _default(capi, 'sum', rp, col, val, X, True)
-    monkeypatch.setenv('DGS_HUB_XCD', mode)  # 2: the workgroups claim ready tasks instead of owning a fixed sequence
-    d = 'cuda'
-    drp, dcol, dval, dX = (torch.from_numpy(a).to(d) for a in (rp, col, val, X))
-    capi.reload_tuning()
-    pl = capi.spmm_plan(drp, dcol, st['K'], N, force=True)
-    assert pl.info.n_hub == int(hub.sum())
-    for it in range(5):
-        C1, _ = capi.spmm(capi.SUM, drp, dcol, dval, dX, plan=pl)
-        torch.cuda.synchronize()
-        C1 = C1.cpu().numpy()
-        assert_bitexact(C1[hub], ref[hub], f'slice by slice == oracle chain (call {it})')
-        assert_bitexact(C1, C0, f'slice by slice == one workgroup per row (call {it})')
-    Cm, _ = capi.spmm(capi.MEAN, drp, dcol, None, dX, plan=pl)
-    refm, _ = oracle.spmm('mean', rp, col, None, X, fma=True, threads=oracle.max_threads())
-    assert_bitexact(Cm.cpu().numpy()[hub], refm[hub], 'mean, unit weights')
-    Cx, Ex = capi.spmm(capi.MAX, drp, dcol, dval, dX, plan=pl)
-    rx, ex = oracle.spmm('max', rp, col, val, X, threads=oracle.max_threads())
-    assert_bitexact(Cx.cpu().numpy(), rx, 'max over the same plan')
-    assert_bitexact(Ex.cpu().numpy(), ex, 'max arg ids')
