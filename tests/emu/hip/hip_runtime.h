@@ -96,7 +96,15 @@ static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMem
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 16; strcpy(p->name, "emu"); return hipSuccess; }
+// 256 CUs like the MI355X, so that every grid-shape decision that depends on cu_count() (hub block caps, panel workgroups) is taken
+// as on the hardware (it used to be 16); DGS_EMU_CUS overrides (read once per process: cu_count() caches it)
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
+  const char *e = getenv("DGS_EMU_CUS");
+  const int n = e && *e ? atoi(e) : 256;
+  p->multiProcessorCount = n > 0 ? n : 256;
+  strcpy(p->name, "emu");
+  return hipSuccess;
+}
 static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipMallocAsync(void **p, size_t n, hipStream_t) { *p = malloc(n); return *p ? hipSuccess : 1; }
 static inline hipError_t hipFreeAsync(void *p, hipStream_t) { free(p); return hipSuccess; }
