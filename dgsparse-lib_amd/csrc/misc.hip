@@ -61,6 +61,19 @@ int cu_count() {
   return v;
 }
 
+// Device gate of the default hub chains (spmm_impl.h hub_threshold): what dgs_spmm_hub_selftest found on each device.
+static std::atomic<int> g_hub_gate[64];
+int hub_gate() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  return g_hub_gate[dev].load(std::memory_order_acquire);
+}
+void hub_gate_set(int state) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+  g_hub_gate[dev].store(state, std::memory_order_release);
+}
+
 // One row per G-lane group, V floats per lane: dst[i,:] = src[ids[i],:]
 template <int V>
 __global__ __launch_bounds__(kBlock) void gather_rows_kernel(int64_t n_ids, int N, const int *__restrict__ ids,

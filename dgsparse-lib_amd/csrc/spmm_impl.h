@@ -1342,10 +1342,21 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
 // (non-negative data; DGS_ALG_STRICT_SUM chains every row).  Why not lower: a chain runs at ~3 - 5 ns per link, so a row of L
 // nnz is an L x 4 ns critical path - 16384 nnz are ~70 us, which a launch over millions of nnz hides, while the 9 - 13 k-nnz
 // hub of an arxiv-sized graph (a 48 us call) would not be.
-static inline int hub_threshold() {
-  const int t = tune(tuning().hub_chain, kHubChain);
-  if (t <= 0 || t > (1 << 24)) return INT_MAX;  // (the class bounds thub << c must stay inside an int)
-  return t < kHubChainMin ? kHubChainMin : t;
+// Two things switch the chains off for a launch: the caller's DGS_ALG_NO_HUB_ROWS hint (it knows the longest row: the launch then
+// takes the kernels without the hub role - spmm_small instead of spmm_small_hub, no hub workgroups at the head of the fused grid),
+// and the device gate - without an explicit DGS_HUB_CHAIN the chains are on only on a device where dgs_spmm_hub_selftest() has
+// compared them with a one-thread-per-element sequential kernel and found them bit-identical (hub_gate(); ADVICE r4: the hub
+// workgroup leans on scheduling behaviour no CPU test can see, so no device runs it unverified by default).
+constexpr int kHintForceHub = 0x40000000;  // internal (the self-test itself): default threshold whatever the gate says
+int hub_gate();                            // misc.hip: 1 = self-test passed on the current device, 0 = not run, -1 = failed
+void hub_gate_set(int state);
+static inline int hub_threshold(int hints = 0) {
+  if (hints & DGS_ALG_NO_HUB_ROWS) return INT_MAX;
+  if (hints & kHintForceHub) return kHubChain;
+  const int e = tuning().hub_chain;
+  if (e == kTuneUnset) return hub_gate() > 0 ? kHubChain : INT_MAX;
+  if (e <= 0 || e > (1 << 24)) return INT_MAX;  // (the class bounds thub << c must stay inside an int)
+  return e < kHubChainMin ? kHubChainMin : e;
 }
 // Hub blocks of a launch: a multiple of 8 (XCD mapping), one per task up to four per CU (they come first in the grid: every hub
 // chain starts at once and the short ones hand their slots to the unit and row blocks within tens of microseconds)
@@ -1388,7 +1399,7 @@ static int launch_impl(const SpmmArgs &a) {
       const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
       int tl = P.tlong > L.ch ? P.tlong : L.ch;  // every long row has >= 2 units => all go through combine
       if (tl > 65534) tl = 65534;  // max keeps 16-bit arg positions (unit lengths never exceed 32768: still >= 2 units)
-      int thub = hub_ok<OP, V, G, ACC>() ? hub_threshold() : INT_MAX;
+      int thub = hub_ok<OP, V, G, ACC>() ? hub_threshold(a.hints) : INT_MAX;
       if (thub < tl) thub = tl;  // rows up to tl belong to the panel sweep (one sequential chain per row already)
       const HubTab ht = hub_tab(a.nnz, thub < INT_MAX ? thub : kHubChainMin, a.nnz / kT1 + 2);
       hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, tl, thub, ht, a.rowptr, hdr,
@@ -1429,8 +1440,9 @@ static int launch_impl(const SpmmArgs &a) {
     const int rpb = (kBlock / kWave) * rpw;
     const dim3 grid((unsigned)((a.M + rpb - 1) / rpb), (unsigned)a.tiles);
     if constexpr (hub_ok<OP, V, G, ACC>()) {
-      const int thub = hub_threshold();
-      if (a.nnz > thub) {  // (a row above the threshold needs that many nnz to begin with)
+      const int thub = hub_threshold(a.hints);
+      if (a.nnz > thub) {  // (a row above the threshold needs that many nnz to begin with; callers that know the longest row
+                           // say so with DGS_ALG_NO_HUB_ROWS and keep spmm_small: VERDICT r4 #7)
         hipLaunchKernelGGL((spmm_small_hub<G, V, OP, HAS_VAL>), grid, dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, rpw, thub,
                            a.rowptr, a.col, a.val, a.B, a.C, a.acc);
         return check_launch();
@@ -1467,7 +1479,7 @@ static int launch_impl(const SpmmArgs &a) {
     const int nbu = (int)(ub < nbu_cap ? (ub < 8 ? 8 : ub) : nbu_cap);
     // hub rows of the plan (longer than the plan's thub): one dense table, longest first, for the sum / mean launches; their
     // units stay in the table (sorted behind the other units of each XCD's share) for every other reduce
-    const bool use_hub = hub_ok<OP, V, G, ACC>() && a.plan_hub > 0 && hub_threshold() < INT_MAX;
+    const bool use_hub = hub_ok<OP, V, G, ACC>() && a.plan_hub > 0 && hub_threshold(a.hints) < INT_MAX;
     HubTab ht{};
     const char *hubp = pb + (a.plan_off_hub ? (size_t)a.plan_off_hub : PL.off_hub);
     HubArg ha{&ph->n_hub, reinterpret_cast<const int4 *>(hubp), ht, 1};
@@ -1492,7 +1504,7 @@ static int launch_impl(const SpmmArgs &a) {
   const UnitTab ut{&hdr->n_units, &hdr->n_long, nullptr, units, longrows};
   if (hipMemsetAsync(hdr, 0, sizeof(SpmmWs), a.st) != hipSuccess) return DGS_ELAUNCH;
   const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
-  const int thub = hub_ok<OP, V, G, ACC>() ? hub_threshold() : INT_MAX;
+  const int thub = hub_ok<OP, V, G, ACC>() ? hub_threshold(a.hints) : INT_MAX;
   const HubTab ht = hub_tab(a.nnz, thub < INT_MAX ? thub : kHubChainMin, a.nnz / kT1 + 2);
   hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, kT2, thub, ht, a.rowptr, hdr,
                      units, longrows);

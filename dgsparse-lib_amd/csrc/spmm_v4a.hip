@@ -53,6 +53,142 @@ extern "C" int dgs_spmm_hub_threshold(void) {
   return t == INT_MAX ? 0 : t;
 }
 
+// ---- device self-test of the hub chains (include/dgsparse_hip.h "Device gate") -------------------------------------------------
+// Generated inputs (no host buffers: everything is a hash of the index), the default sum with the chains forced on, a reference
+// kernel that is beyond suspicion - one thread per (row, feature), one fmaf chain in CSR order - and an element-wise compare.
+namespace dgs {
+namespace selftest {
+struct Shape {
+  int M, K, N;
+  int lens[4];  // lengths of rows 0 .. 3; every other row has `tail` nnz
+  int tail;
+  int nnz() const { return lens[0] + lens[1] + lens[2] + lens[3] + (M - 4) * tail; }
+};
+// general schedule (> 2^16 rows): two hub rows (one of them threshold + 1), a row of exactly the threshold and a mid row (tree)
+constexpr Shape kGeneral{66000, 8192, 64, {20000, kHubChain + 1, kHubChain, 5000}, 2};
+// single-launch schedule, 16-lane and 8-lane feature tiles
+constexpr Shape kSmall64{40, 8192, 64, {20000, 17000, 70, 3}, 3};
+constexpr Shape kSmall20{40, 8192, 20, {20000, 17000, 70, 3}, 3};
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float unit_float(unsigned h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+__global__ __launch_bounds__(kBlock) void gen(Shape sh, int nnz, int *__restrict__ rowptr, int *__restrict__ col,
+                                              float *__restrict__ val, float *__restrict__ B) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i <= sh.M) {
+    int p = 0;
+    for (int r = 0; r < 4 && r < i; r++) p += sh.lens[r];
+    if (i > 4) p += ((int)i - 4) * sh.tail;
+    rowptr[i] = p;
+  }
+  if (i < nnz) {
+    col[i] = (int)(hash32(2u * (unsigned)i + 1u) % (unsigned)sh.K);
+    val[i] = unit_float(hash32(2u * (unsigned)i));
+  }
+  if (i < (int64_t)sh.K * sh.N) B[i] = unit_float(hash32((unsigned)i + 0x9e3779b9u));
+}
+// one workgroup per row, one thread per feature: algorithm 0 as written (include/cuda/spmm_cuda.cuh:27-47), fmaf-contracted
+__global__ __launch_bounds__(kWave) void reference(int N, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                   const float *__restrict__ val, const float *__restrict__ B,
+                                                   float *__restrict__ C) {
+  const int r = blockIdx.x, f = threadIdx.x;
+  if (f >= N) return;
+  const int rs = rowptr[r], re = rowptr[r + 1];
+  float acc = 0.0f;
+  int p = rs;
+  for (; p + 8 <= re; p += 8) {  // eight independent loads in flight, the chain itself strictly in order
+    float w[8], x[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      w[u] = val[p + u];
+      x[u] = B[(int64_t)col[p + u] * N + f];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc = __builtin_fmaf(w[u], x[u], acc);
+  }
+  for (; p < re; p++) acc = __builtin_fmaf(val[p], B[(int64_t)col[p] * N + f], acc);
+  C[(int64_t)r * N + f] = acc;
+}
+// rows the contract chains (<= T1 nnz, > threshold): identical bits; rows in between: 1e-5 relative
+__global__ __launch_bounds__(kBlock) void compare(int M, int N, int thub, const int *__restrict__ rowptr,
+                                                  const float *__restrict__ C, const float *__restrict__ R,
+                                                  int *__restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (int64_t)M * N) return;
+  const int r = (int)(i / N), len = rowptr[r + 1] - rowptr[r];
+  const float c = C[i], ref = R[i];
+  const bool ok = (len <= kT1 || len > thub) ? (__float_as_uint(c) == __float_as_uint(ref))
+                                             : (fabsf(c - ref) <= 1e-5f * fabsf(ref) + 1e-30f);
+  if (!ok) atomicAdd(bad, 1);
+}
+struct Layout {
+  size_t rowptr, col, val, B, C, R, ws, ws_bytes, bad, total;
+};
+static Layout layout(const Shape &sh) {
+  auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+  Layout L;
+  size_t o = 0;
+  L.bad = o;     o += 256;
+  L.rowptr = o;  o += up((size_t)(sh.M + 1) * 4);
+  L.col = o;     o += up((size_t)sh.nnz() * 4);
+  L.val = o;     o += up((size_t)sh.nnz() * 4);
+  L.B = o;       o += up((size_t)sh.K * sh.N * 4);
+  L.C = o;       o += up((size_t)sh.M * sh.N * 4);
+  L.R = o;       o += up((size_t)sh.M * sh.N * 4);
+  L.ws = o;
+  L.ws_bytes = dgs_spmm_csr_workspace_bytes(DGS_SUM, sh.M, sh.N, sh.nnz());
+  L.total = o + up(L.ws_bytes);
+  return L;
+}
+static int run_shape(const Shape &sh, char *base, hipStream_t st) {
+  const Layout L = layout(sh);
+  const int nnz = sh.nnz();
+  int *rowptr = reinterpret_cast<int *>(base + L.rowptr), *col = reinterpret_cast<int *>(base + L.col);
+  float *val = reinterpret_cast<float *>(base + L.val), *B = reinterpret_cast<float *>(base + L.B);
+  float *C = reinterpret_cast<float *>(base + L.C), *R = reinterpret_cast<float *>(base + L.R);
+  int64_t n = (int64_t)sh.K * sh.N;
+  if (n < nnz) n = nnz;
+  if (n < sh.M + 1) n = sh.M + 1;
+  hipLaunchKernelGGL(gen, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sh, nnz, rowptr, col, val, B);
+  if (hipMemsetAsync(C, 0xFF, (size_t)sh.M * sh.N * 4, st) != hipSuccess) return DGS_ELAUNCH;  // NaN: an unwritten element fails
+  const FeatMap fm = feat_map(sh.N, true);
+  SpmmArgs a{sh.M, sh.K, sh.N, nnz, rowptr, col, val, B, C, nullptr, fm.tiles, L.ws_bytes ? base + L.ws : nullptr, st, DGS_SUM};
+  a.hints = kHintForceHub;
+  const int rc = run(fm, a);
+  if (rc != DGS_OK) return rc;
+  hipLaunchKernelGGL(reference, dim3((unsigned)sh.M), dim3(kWave), 0, st, sh.N, rowptr, col, val, B, R);
+  hipLaunchKernelGGL(compare, dim3((unsigned)(((int64_t)sh.M * sh.N + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sh.M, sh.N,
+                     kHubChain, rowptr, C, R, reinterpret_cast<int *>(base + L.bad));
+  return check_launch();
+}
+}  // namespace selftest
+}  // namespace dgs
+
+extern "C" size_t dgs_spmm_hub_selftest_bytes(void) { return selftest::layout(selftest::kGeneral).total; }  // the largest shape
+extern "C" int dgs_spmm_hub_gate(void) { return hub_gate(); }
+extern "C" int dgs_spmm_hub_selftest(void *scratch, size_t scratch_bytes, dgsStream_t stream) {
+  if (!scratch || scratch_bytes < dgs_spmm_hub_selftest_bytes() || !is_aligned16(scratch)) return DGS_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char *base = static_cast<char *>(scratch);
+  if (hipMemsetAsync(base, 0, 256, st) != hipSuccess) return DGS_ELAUNCH;  // the mismatch counter
+  const selftest::Shape shapes[3] = {selftest::kGeneral, selftest::kSmall64, selftest::kSmall20};
+  for (const selftest::Shape &sh : shapes) {
+    const int rc = selftest::run_shape(sh, base, st);  // (stream order: one shape's arrays are dead when the next one's are written)
+    if (rc != DGS_OK) return rc;
+  }
+  int bad = -1;
+  if (hipMemcpyAsync(&bad, base, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return DGS_ELAUNCH;
+  if (hipStreamSynchronize(st) != hipSuccess) return DGS_ELAUNCH;
+  hub_gate_set(bad == 0 ? 1 : -1);
+  return bad == 0 ? 1 : 0;
+}
+
 extern "C" int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz) {
   if (M <= 0 || N <= 0 || nnz <= 0 || tiny_problem(M, nnz)) return DGS_SCHED_SMALL;
   const FeatMap fm = feat_map(N, true);

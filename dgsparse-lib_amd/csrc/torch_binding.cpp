@@ -19,6 +19,7 @@
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
 
+#include <atomic>
 #include <vector>
 
 #include "dgsparse_hip.h"
@@ -54,6 +55,29 @@ Tensor workspace(size_t bytes, const Tensor &like) {
 }
 using OptTensor = c10::optional<Tensor>;
 bool has(const OptTensor &t) { return t.has_value() && t->defined(); }
+
+// The library's device gate (dgsparse_hip.h): the default sum / mean chain their hub rows only on a device that has passed
+// dgs_spmm_hub_selftest in this process.  Run once per device at its first use through this binding (the Python layer does the
+// same for its ctypes path; the library keeps one verdict per device, so whoever comes first decides).  Not during a capture.
+void ensure_hub_selftest(const Tensor &like) {
+  static std::atomic<bool> done[64];
+  const int dev = like.get_device();
+  if (dev < 0 || dev >= 64 || done[dev].load(std::memory_order_acquire)) return;
+  if (dgs_spmm_hub_gate() != 0) {
+    done[dev].store(true, std::memory_order_release);
+    return;
+  }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(static_cast<hipStream_t>(cur_stream()), &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
+  const size_t nb = dgs_spmm_hub_selftest_bytes();
+  Tensor scratch = workspace(nb, like);
+  const int rc = dgs_spmm_hub_selftest(scratch.data_ptr(), nb, cur_stream());
+  TORCH_CHECK(rc >= 0, "dgsparse: hub self-test could not run: ", dgs_strerror(rc), " (", rc, ")");
+  if (rc == 0)
+    TORCH_WARN("dgsparse: the hub-chain self-test FAILED on this device: sum / mean fold rows above 64 nnz with the fixed tree "
+               "here (DGS_ALG_STRICT_SUM is unaffected).  Please report this.");
+  done[dev].store(true, std::memory_order_release);
+}
 void same_device(const Tensor &a, const Tensor &b, const char *what) {
   TORCH_CHECK(a.device() == b.device(), "dgsparse: ", what, " live on different devices (", a.device(), " vs ", b.device(), ")");
 }
@@ -81,6 +105,7 @@ std::vector<Tensor> spmm_fwd(int op, const Tensor &rowptr_, const Tensor &col_, 
   same_device(col, dense, "col and dense");
   if (has_value) same_device(values, dense, "values and dense");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(dense.device());
+  ensure_hub_selftest(dense);
   const int64_t M = rowptr.numel() - 1, nnz = col.numel(), K = dense.size(0), N = dense.size(1);
   TORCH_CHECK(M >= 0, "dgsparse: rowptr must have at least one element");
   if (N % 4 && N > 4 && dgs_spmm_csr_schedule(op, M, K, (N + 3) & ~int64_t(3), nnz) == DGS_SCHED_PANEL) {
@@ -232,7 +257,11 @@ struct SpMM : public torch::autograd::Function<SpMM<OP>> {
   static tensor_list backward(AutogradContext *ctx, tensor_list grad_outs) {
     const Tensor grad_out = grad_outs[0].contiguous();
     const bool has_value = ctx->saved_data["has_value"].toBool();
-    const int64_t algorithm = ctx->saved_data["algorithm"].toInt();
+    // the hints of `algorithm` speak about the forward's matrix; the backward's SpMM runs over its transpose: what the caller
+    // said about the COLUMNS (DGS_ALG_NO_HUB_COLS) becomes the statement about that product's rows
+    const int64_t alg_fwd = ctx->saved_data["algorithm"].toInt();
+    const int64_t algorithm = (alg_fwd & ~(int64_t)(DGS_ALG_NO_HUB_ROWS | DGS_ALG_NO_HUB_COLS)) |
+                              ((alg_fwd & DGS_ALG_NO_HUB_COLS) ? DGS_ALG_NO_HUB_ROWS : 0);
     const auto saved = ctx->get_saved_variables();
     const Tensor &rowptr = saved[0], &col = saved[1], &values = saved[2], &colptr = saved[3], &row = saved[4],
                  &csr2csc = saved[5], &dense = saved[6];
@@ -309,6 +338,7 @@ std::vector<Tensor> spmm_plan_op(Tensor rowptr_, Tensor col_, int64_t n_cols) {
   const Tensor rowptr = i32vec(rowptr_, "rowptr"), col = i32vec(col_, "col");
   same_device(rowptr, col, "rowptr and col");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(rowptr.device());
+  ensure_hub_selftest(rowptr);  // (the hub table of a plan is cut at the threshold in force when it is built)
   const int64_t M = rowptr.numel() - 1, nnz = col.numel();
   TORCH_CHECK(M > 0 && nnz > 0 && n_cols > 0, "dgsparse: cannot plan an empty matrix");
   const size_t pb = dgs_spmm_plan_bytes(M, n_cols, nnz), wb = dgs_spmm_plan_workspace_bytes(M, n_cols, nnz);
@@ -337,6 +367,7 @@ std::vector<Tensor> spmm_plan_start_op(Tensor rowptr_, Tensor col_, int64_t n_co
     TORCH_CHECK(prefix.numel() == n_cols + 1, "dgsparse: col_prefix must have n_cols + 1 entries");
   }
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(rowptr.device());
+  ensure_hub_selftest(rowptr);  // (the hub table of a plan is cut at the threshold in force when it is built)
   const int64_t M = rowptr.numel() - 1, nnz = col.numel();
   TORCH_CHECK(M > 0 && nnz > 0 && n_cols > 0, "dgsparse: cannot plan an empty matrix");
   const size_t pb = dgs_spmm_plan_bytes(M, n_cols, nnz), wb = dgs_spmm_plan_workspace_bytes(M, n_cols, nnz);
@@ -369,6 +400,7 @@ std::vector<Tensor> spmm_plan_finish_op(Tensor plan, Tensor hdr, int64_t nnz) {
 std::vector<Tensor> csr2csc_op(Tensor rowptr_, Tensor colind_, Tensor values) {
   const Tensor rowptr = i32vec(rowptr_, "rowptr"), col = i32vec(colind_, "colind");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(rowptr.device());
+  ensure_hub_selftest(rowptr);  // (setup path, where a Storage first meets its device: the one synchronising step is paid here)
   const int64_t n = rowptr.numel() - 1, nnz = col.numel();
   // square like the reference's op: a column id >= n would alias in the n-bit radix sort (setup path: one sync is fine);
   // rectangular matrices go through csr2csc_perm / dgsparse.csr2csc(SparseTensor), which pass the column count
@@ -390,6 +422,7 @@ std::vector<Tensor> csr2csc_op(Tensor rowptr_, Tensor colind_, Tensor values) {
 std::vector<Tensor> csr2csc_perm_op(Tensor rowptr_, Tensor colind_, int64_t n_cols) {
   const Tensor rowptr = i32vec(rowptr_, "rowptr"), col = i32vec(colind_, "colind");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(rowptr.device());
+  ensure_hub_selftest(rowptr);  // (setup path, where a Storage first meets its device: the one synchronising step is paid here)
   const int64_t M = rowptr.numel() - 1, nnz = col.numel();
   Tensor colptr = at::empty({n_cols + 1}, rowptr.options()), row = at::empty({nnz}, rowptr.options()),
          perm = at::empty({nnz}, rowptr.options());

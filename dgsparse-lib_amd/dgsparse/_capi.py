@@ -16,6 +16,8 @@ SUM, MAX, MIN, MEAN = 0, 1, 2, 3  # include/gspmm.h:13 in the reference
 ALG_SHARED_GPU = 0x100  # `algorithm` hint bit: the GPU is shared with concurrently running kernels
 ALG_STRICT_SUM = 0x200  # sum / mean: one sequential fmaf chain per (row, feature) in CSR order, whatever the row length
 ALG_STRICT_NOFMA = 0x400  # ... with the product rounded before the add (= the reference's host loop under g++)
+ALG_NO_HUB_ROWS = 0x800  # sum / mean: the caller knows that no row is longer than hub_threshold() (kernels without the hub role)
+ALG_NO_HUB_COLS = 0x1000  # ... no column is (the torch binding hands it to the backward's transposed product as NO_HUB_ROWS)
 
 if not os.path.exists(LIB_PATH):  # mirrors dgsparse/__init__.py:25 in the reference (ImportError, no fallback)
     raise ImportError(f"Could not find the HIP kernel library '{LIB_PATH}'. Build it with "
@@ -34,6 +36,12 @@ _lib.dgs_strerror.restype = ctypes.c_char_p
 _lib.dgs_strerror.argtypes = [_int]
 _lib.dgs_spmm_hub_threshold.restype = _int
 _lib.dgs_spmm_hub_threshold.argtypes = []
+_lib.dgs_spmm_hub_gate.restype = _int
+_lib.dgs_spmm_hub_gate.argtypes = []
+_lib.dgs_spmm_hub_selftest_bytes.restype = _sz
+_lib.dgs_spmm_hub_selftest_bytes.argtypes = []
+_lib.dgs_spmm_hub_selftest.restype = _int
+_lib.dgs_spmm_hub_selftest.argtypes = [_vp, _sz, _vp]
 _lib.dgs_reload_tuning.restype = None
 _lib.dgs_reload_tuning.argtypes = []
 _lib.dgs_spmm_csr_workspace_bytes.restype = _sz
@@ -119,7 +127,8 @@ _lib.dgs_spmm_min_merge_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp, ctypes.c
 _lib.dgs_scatter_add_rows_f32.restype = _int
 _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
-EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_reload_tuning', 'dgs_spmm_hub_threshold', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
+EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_reload_tuning', 'dgs_spmm_hub_threshold', 'dgs_spmm_hub_gate',
+           'dgs_spmm_hub_selftest_bytes', 'dgs_spmm_hub_selftest', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
            'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes', 'dgs_spmm_plan_build', 'dgs_spmm_plan_build2',
            'dgs_spmm_plan_compact_bytes', 'dgs_spmm_plan_compact', 'dgs_spmm_plan_info_from_header',
            'dgs_spmm_plan_thresholds', 'dgs_spmm_plan_provisional_info', 'dgs_spmm_csr_ex_f32', 'dgs_spmm_csr_plan_workspace_bytes',
@@ -181,8 +190,45 @@ def arch() -> str:
 
 
 def hub_threshold() -> int:
-    """Rows longer than this many nnz are sequential chains in the default sum / mean schedule (0 = off; DGS_HUB_CHAIN)."""
+    """Rows longer than this many nnz are sequential chains in the default sum / mean schedule on the current device (0 = off:
+    DGS_HUB_CHAIN=0, or the device has not passed the hub self-test - ensure_hub_selftest)."""
+    if torch.cuda.is_available():
+        ensure_hub_selftest(torch.device('cuda', torch.cuda.current_device()))
     return int(_lib.dgs_spmm_hub_threshold())
+
+
+_selftested = set()  # device indices whose hub self-test has run in this process
+
+
+def ensure_hub_selftest(dev) -> None:
+    """Runs the library's device self-test of the hub chains once per device and process (include/dgsparse_hip.h, "Device
+    gate": the default sum / mean chain their hub rows only on a device where that chain has been compared, bit for bit, with a
+    one-thread-per-element sequential kernel).  ~45 MB of scratch for a few milliseconds and ONE stream synchronisation, at the
+    first use of the device; skipped (and retried later) while a stream capture is in progress."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx in _selftested:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    _selftested.add(idx)
+    d = torch.device('cuda', idx)
+    with _on_device(d):
+        nb = int(_lib.dgs_spmm_hub_selftest_bytes())
+        scratch = torch.empty(nb, dtype=torch.uint8, device=d)
+        rc = int(_lib.dgs_spmm_hub_selftest(_p(scratch), nb, _stream(d)))
+    if rc < 0:
+        _selftested.discard(idx)
+        _check(rc, 'spmm_hub_selftest')
+    if rc == 0:
+        import warnings
+        warnings.warn(f'dgsparse: the hub-chain self-test FAILED on cuda:{idx} ({torch.cuda.get_device_name(idx)}): sum / mean '
+                      'fold rows above 64 nnz with the fixed tree on this device (within 1e-5 of the sequential reference except '
+                      'on rows of several 10^4 nnz; DGS_ALG_STRICT_SUM is unaffected).  Please report this.', RuntimeWarning)
+
+
+def hub_gate() -> int:
+    """1 / 0 / -1: the hub self-test passed / has not run / failed on the current device."""
+    return int(_lib.dgs_spmm_hub_gate())
 
 
 def reload_tuning() -> None:
@@ -207,6 +253,8 @@ def _need_gpu(*ts) -> torch.device:
             dev = t.device
         elif t.device != dev:
             raise RuntimeError(f'dgsparse: tensors on different devices ({dev} vs {t.device})')
+    if dev is not None and dev.index not in _selftested:
+        ensure_hub_selftest(dev)
     return dev
 
 

@@ -22,7 +22,7 @@ class _SpMMSumFused(torch.autograd.Function):
         if buf is not None:
             plan = _plan_obj(buf, info, st, 'csr')
         out, _ = _capi.spmm(_capi.SUM, st.rowptr(), st.col(), values.detach() if has_value else None, dense.detach(),
-                            plan=plan, bias=None if bias is None else bias.detach(), row_scale=row_scale, relu=relu)
+                            algorithm=st.hub_hints() & _capi.ALG_NO_HUB_ROWS, plan=plan, bias=None if bias is None else bias.detach(), row_scale=row_scale, relu=relu)
         ctx.sparse, ctx.relu, ctx.has_value = sparse, relu, has_value
         ctx.save_for_backward(dense, values, row_scale, out if relu else None)
         ctx.has_bias = bias is not None
@@ -44,7 +44,8 @@ class _SpMMSumFused(torch.autograd.Function):
             buf, info = st.spmm_plan('csc', N)
             plan_t = _plan_obj(buf, info, st, 'csc') if buf is not None else None
             tv = st.csc_values() if ctx.has_value else None
-            g_dense, _ = _capi.spmm(_capi.SUM, st.colptr(), st.csc_row(), tv, g, plan=plan_t)
+            g_dense, _ = _capi.spmm(_capi.SUM, st.colptr(), st.csc_row(), tv, g, plan=plan_t,
+                                    algorithm=_capi.ALG_NO_HUB_ROWS if st.hub_hints() & _capi.ALG_NO_HUB_COLS else 0)
             if g_dense.shape[0] < dense.shape[0]:
                 g_dense = torch.cat([g_dense, g_dense.new_zeros((dense.shape[0] - g_dense.shape[0], N))])
         if ctx.has_value and ctx.needs_input_grad[2]:

@@ -15,6 +15,8 @@ def _call(op, code, sparse: SparseTensor, dense: torch.Tensor, algorithm) -> tor
     values = st.values()
     cuda = dense.is_cuda and st.col().is_cuda
     plan, pinfo = st.spmm_plan('csr', dense.shape[1]) if cuda else (None, None)
+    if cuda and code in (_capi.SUM, _capi.MEAN):
+        algorithm = int(algorithm) | st.hub_hints()  # the Storage knows its longest row / column: launches without the hub role
     if not (torch.is_grad_enabled() and (dense.requires_grad or (sparse.has_value and values.requires_grad))):
         # inference: nothing to record, skip the autograd.Function (~5 us; on the Cora/Pubmed class of graphs the whole
         # call is ~10 us, so that is a third of it): straight to the C ABI, or to the raw op when a plan exists

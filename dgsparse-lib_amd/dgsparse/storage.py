@@ -162,9 +162,6 @@ class Storage(object):
             n_rows = rowptr.numel() - 1
         else:
             n_rows = int(row.max()) + 1 if row.numel() else 0
-        n_cols = int(col.max()) + 1 if nnz else 0  # one device sync per construction, like the reference
-        self.sparse_sizes = (n_rows, n_cols)
-        self.nnz = nnz
 
         if row is not None:
             row = _index_array(row, col, nnz)
@@ -178,6 +175,15 @@ class Storage(object):
             rowptr = torch.zeros(n_rows + 1, dtype=_INDEX, device=col.device)
             if nnz:
                 rowptr[1:] = torch.cumsum(torch.bincount(row.long(), minlength=n_rows), 0)
+        # one device sync per construction, like the reference (its col.max()); the longest row rides along: callers of the
+        # kernels that know it keep the launches without the hub role (DGS_ALG_NO_HUB_ROWS, hub_hints below)
+        if nnz:
+            cmax, self._max_row_len = torch.stack([col.max(), (rowptr[1:] - rowptr[:-1]).max()]).tolist()
+            n_cols = cmax + 1
+        else:
+            n_cols, self._max_row_len = 0, 0
+        self.sparse_sizes = (n_rows, n_cols)
+        self.nnz = nnz
 
         if values is None:  # unit weights when the caller has none (reference: torch.ones)
             values = torch.ones(nnz, dtype=torch.float32, device=col.device)
@@ -199,7 +205,20 @@ class Storage(object):
         self._plans = {}       # 'csr' / 'csc' -> _SharedPlan (shared with every Storage over the same buffers)
         self._sched = {}       # ('csr' | 'csc', feature width) -> does that shape take the planned schedule?
         self._tvalues = None   # (weakref to values, version, values in CSC order)
+        self._max_col_len = None  # longest column: int once known, (pinned tensor, event) while its copy is in flight
+        self._hints = None     # (hub threshold, hint bits) once both maxima are known
         self.csr2csc_convert()
+        if nnz and col.is_cuda:
+            # the longest COLUMN (for the backward's transposed product) without a second sync: queued behind the transpose,
+            # read when its event has completed; until then the backward simply goes without the hint
+            _capi.ensure_hub_selftest(col.device)
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_((self._colptr[1:] - self._colptr[:-1]).max().reshape(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(col.device))
+            self._max_col_len = (host, ev)
+        elif nnz:
+            self._max_col_len = int((self._colptr[1:] - self._colptr[:-1]).max())
 
     @classmethod
     def empty(cls):
@@ -238,6 +257,29 @@ class Storage(object):
         return self._present('_csc_row')
 
     # ---- per-matrix state of the HIP schedule, built on first use ---------------------------------------------------
+    def hub_hints(self) -> int:
+        """`algorithm` hint bits for sum / mean over this matrix: DGS_ALG_NO_HUB_ROWS when no row is longer than the library's
+        hub threshold, DGS_ALG_NO_HUB_COLS when no column is (the backward's product runs over the transpose).  True of
+        every graph the reference benchmarks (Pubmed, PPI, p2p-Gnutella31, ca-CondMat: longest row 78 .. 280 nnz), which
+        then keep the plain single-launch kernel; same bits with and without the hint."""
+        th = _capi._lib.dgs_spmm_hub_threshold()
+        hit = self._hints
+        if hit is not None and hit[0] == th:
+            return hit[1]
+        if th <= 0:
+            return 0
+        bits = _capi.ALG_NO_HUB_ROWS if self._max_row_len <= th else 0
+        mc = self._max_col_len
+        if isinstance(mc, tuple):
+            if not mc[1].query():
+                return bits  # (not cached: the column maximum is still on its way)
+            mc = self._max_col_len = int(mc[0][0])
+        if mc is not None:
+            if mc <= th:
+                bits |= _capi.ALG_NO_HUB_COLS
+            self._hints = (th, bits)
+        return bits
+
     def spmm_plan(self, which: str = 'csr', n_feat: int = 64, wait: bool = False):
         """(plan buffer, plan info) of the forward ('csr': rowptr/col) or backward ('csc': colptr/csc_row) SpMM, or
         (None, None) when there is none (yet): shapes that do not take the planned schedule at this feature width

@@ -109,6 +109,23 @@ int main(int argc, char **argv) {
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
 
+  // Device gate of the hub chains (include/dgsparse_hip.h): a C caller runs the library's self-test once per device, then tells
+  // the launches what it knows about the matrix - here: the longest row (every matrix the reference ships is far below the
+  // threshold, so sum / mean keep the plain single-launch kernel).
+  {
+    void *d_st;
+    const size_t sb = dgs_spmm_hub_selftest_bytes();
+    HIP_OK(hipMalloc(&d_st, sb));
+    const int v = dgs_spmm_hub_selftest(d_st, sb, st);
+    printf("hub-chain self-test on this device: %s\n", v == 1 ? "passed" : (v == 0 ? "FAILED (chains off)" : dgs_strerror(v)));
+    HIP_OK(hipFree(d_st));
+  }
+  int maxlen = 0;
+  for (int r = 0; r < M; r++) maxlen = std::max(maxlen, indptr[r + 1] - indptr[r]);
+  const int thub = dgs_spmm_hub_threshold();
+  const int alg = (thub > 0 && maxlen <= thub) ? DGS_ALG_NO_HUB_ROWS : 0;
+  printf("longest row %d nnz, hub threshold %d -> algorithm hints 0x%x\n", maxlen, thub, alg);
+
   // Cached locality plan (include/dgsparse_hip.h): built once from (rowptr, col) when the shape takes the row-stream
   // schedule; the same calls then run over the plan's tables.
   void *d_plan = nullptr, *d_pws = nullptr;
@@ -155,7 +172,7 @@ int main(int argc, char **argv) {
         if (op == DGS_SUM || op == DGS_MEAN) res = (float)(op == DGS_MEAN && e > s ? acc / (double)(e - s) : acc);
         Cref[(size_t)r * N + f] = e > s ? res : 0.f;
       }
-    int rc = dgs_spmm_csr_f32(op, M, K, N, nnz, d_ptr, d_idx, d_val, d_B, d_C, d_E, 0, d_ws, wsb, st);
+    int rc = dgs_spmm_csr_f32(op, M, K, N, nnz, d_ptr, d_idx, d_val, d_B, d_C, d_E, alg, d_ws, wsb, st);
     if (rc) {
       fprintf(stderr, "dgs_spmm_csr_f32: %s\n", dgs_strerror(rc));
       return 3;
@@ -166,9 +183,9 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < C.size(); i++)
       if (fabsf(C[i] - Cref[i]) > 1e-5f * fabsf(Cref[i]) + 2e-6f) bad++;
     bad_total += bad != 0;
-    for (int i = 0; i < 10; i++) dgs_spmm_csr_f32(op, M, K, N, nnz, d_ptr, d_idx, d_val, d_B, d_C, d_E, 0, d_ws, wsb, st);
+    for (int i = 0; i < 10; i++) dgs_spmm_csr_f32(op, M, K, N, nnz, d_ptr, d_idx, d_val, d_B, d_C, d_E, alg, d_ws, wsb, st);
     HIP_OK(hipEventRecord(e0, st));
-    for (int i = 0; i < 100; i++) dgs_spmm_csr_f32(op, M, K, N, nnz, d_ptr, d_idx, d_val, d_B, d_C, d_E, 0, d_ws, wsb, st);
+    for (int i = 0; i < 100; i++) dgs_spmm_csr_f32(op, M, K, N, nnz, d_ptr, d_idx, d_val, d_B, d_C, d_E, alg, d_ws, wsb, st);
     HIP_OK(hipEventRecord(e1, st));
     HIP_OK(hipEventSynchronize(e1));
     float ms;

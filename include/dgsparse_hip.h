@@ -69,11 +69,22 @@ void dgs_reload_tuning(void);
  *     DGS_ALG_STRICT_NOFMA  the same with the product rounded before the add (res + (w*x), no contraction): bit-exact
  *                         against the reference's host loop spmm_reference_host (example/util/sp_util.hpp:73-83) as g++
  *                         compiles it.  Never takes the column-panel sweep.  Implies strict order.
+ *     DGS_ALG_NO_HUB_ROWS  sum / mean: the caller knows that no row of THIS matrix is longer than dgs_spmm_hub_threshold()
+ *                         (one max over the row lengths, e.g. kept next to the CSC view): the launch takes the kernels without
+ *                         the hub role - the plain single-launch kernel for small inputs (every graph the reference benchmarks:
+ *                         Pubmed, PPI, p2p-Gnutella31, ca-CondMat ...), no idle hub workgroups in front of a plan-free fused
+ *                         launch.  Same bits as without the hint when it is true; a false hint sends the long rows through the
+ *                         tree (within ~1e-5 of the chain, not bit-identical to it).
+ *     DGS_ALG_NO_HUB_COLS  the same statement about the COLUMNS of the matrix.  Ignored by every dgs_* entry; the torch
+ *                         binding hands it on as NO_HUB_ROWS to the transposed product of the backward pass (and drops the
+ *                         forward's NO_HUB_ROWS there).
  *   The strict bits are ignored by max / min (always exact) and by the accumulating entries.
  */
 #define DGS_ALG_SHARED_GPU 0x100
 #define DGS_ALG_STRICT_SUM 0x200
 #define DGS_ALG_STRICT_NOFMA 0x400
+#define DGS_ALG_NO_HUB_ROWS 0x800
+#define DGS_ALG_NO_HUB_COLS 0x1000
 size_t dgs_spmm_csr_workspace_bytes(int reduce_op, int64_t M, int64_t N, int64_t nnz);
 int dgs_spmm_csr_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz,
                      const int32_t *rowptr, const int32_t *col, const float *val, const float *B,
@@ -104,9 +115,26 @@ int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_
  * The threshold is DGS_HUB_CHAIN (default 16384, clamped to >= 1024, 0 = no hub chains: every row above 64 nnz takes the
  * tree); the chain's own rounding error grows like sqrt(nnz) and passes 1e-5 of the exact sum beyond ~3 10^4 nnz, which is
  * where a tree - however accurate - stops being within 1e-5 of the REFERENCE.  DGS_ALG_STRICT_SUM / _NOFMA chain every row.
- * dgs_spmm_hub_threshold() returns the threshold in force (0 = off).
+ * dgs_spmm_hub_threshold() returns the threshold in force on the current device (0 = off).
+ *
+ * Device gate.  The hub workgroup keeps two register sets of gathers in flight across workgroup barriers while one wave chains
+ * out of LDS - behaviour of the compiler's wait counts and of the memory system that only the hardware can confirm.  So without
+ * an explicit DGS_HUB_CHAIN the chains are ON only on a device where dgs_spmm_hub_selftest() has passed in this process: it runs
+ * the default sum on two generated matrices with hub rows (general and single-launch schedule) against a one-thread-per-element
+ * sequential fmaf kernel and demands identical bits on the hub rows (and 1e-5 elsewhere).  It is the ONE entry point of this
+ * library that synchronises (`stream`, once) - call it once per device at start-up (dgsparse's Python layer and torch binding
+ * do, at the first use of a device); until it has passed, rows above 64 nnz take the fixed tree on that device (the round-3
+ * schedule).  Returns 1 = passed (chains on from now on), 0 = FAILED (chains stay off on this device; results of the tree are
+ * still within the contract's 1e-5 except on rows of > ~3 10^4 nnz), < 0 = DGS_E* (state unchanged).  DGS_HUB_CHAIN=n in the
+ * environment bypasses the gate both ways (n = 0: off, n > 0: on at that threshold, self-test or not).
+ *   scratch: dgs_spmm_hub_selftest_bytes() bytes of device memory, 256-B aligned, contents undefined on entry and exit.
+ * dgs_spmm_hub_gate(): 1 / 0 / -1 = passed / not run / failed on the current device.
+ * No reference counterpart (the reference has one kernel per algorithm id and no self-checks).
  */
 int dgs_spmm_hub_threshold(void);
+size_t dgs_spmm_hub_selftest_bytes(void);
+int dgs_spmm_hub_selftest(void *scratch, size_t scratch_bytes, dgsStream_t stream);
+int dgs_spmm_hub_gate(void);
 
 /*
  * Cached locality plan of the row-stream schedule (new; the reference keeps no per-matrix state - the closest thing is

@@ -9,7 +9,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SUM, MAX, MIN, MEAN = 0, 1, 2, 3
-ALG_STRICT_SUM, ALG_STRICT_NOFMA = 0x200, 0x400
+ALG_STRICT_SUM, ALG_STRICT_NOFMA, ALG_NO_HUB_ROWS = 0x200, 0x400, 0x800
 _lib = None
 
 
@@ -27,8 +27,9 @@ def lib():
         if alt:
             _lib = ctypes.CDLL(alt)
             for f in ('dgs_spmm_csr_workspace_bytes', 'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes',
-                      'dgs_spmm_csr_plan_workspace_bytes', 'dgs_spmm_plan_compact_bytes'):
+                      'dgs_spmm_csr_plan_workspace_bytes', 'dgs_spmm_plan_compact_bytes', 'dgs_spmm_hub_selftest_bytes'):
                 getattr(_lib, f).restype = ctypes.c_size_t
+            hub_selftest()  # (a mutant that breaks the hub workgroup fails it: the chains are then OFF unless DGS_HUB_CHAIN forces them)
             return _lib
         ubsan = os.environ.get('DGS_EMU_UBSAN') == '1'
         r = subprocess.run(['make', '-C', HERE, '-j8'] + (['ASAN=1'] if asan else ['UBSAN=1'] if ubsan else []), capture_output=True,
@@ -37,9 +38,31 @@ def lib():
             raise RuntimeError('emu build failed:\n' + r.stdout[-3000:] + r.stderr[-3000:])
         _lib = ctypes.CDLL(os.path.join(HERE, '_build_asan' if asan else '_build_ubsan' if ubsan else '_build', 'libdgs_emu.so'))
         for f in ('dgs_spmm_csr_workspace_bytes', 'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes',
-                  'dgs_spmm_csr_plan_workspace_bytes', 'dgs_spmm_plan_compact_bytes'):
+                  'dgs_spmm_csr_plan_workspace_bytes', 'dgs_spmm_plan_compact_bytes', 'dgs_spmm_hub_selftest_bytes'):
             getattr(_lib, f).restype = ctypes.c_size_t
+        assert hub_selftest() == 1, 'the hub-chain self-test fails on the emulation'
     return _lib
+
+
+def launch_log(clear=True):
+    """[(kernel expression as written at the launch site, grid.x, grid.y)] of every launch since the log was last cleared."""
+    L = lib()
+    L.emu_launch_log.restype = ctypes.c_size_t
+    buf = ctypes.create_string_buffer(1 << 20)
+    L.emu_launch_log(buf, ctypes.c_size_t(len(buf)), int(clear))
+    out = []
+    for line in buf.value.decode().splitlines():
+        name, gx, gy = line.rsplit(' ', 2)
+        out.append((name, int(gx), int(gy)))
+    return out
+
+
+def hub_selftest():
+    """The device gate of the default hub chains (include/dgsparse_hip.h): what dgsparse's Python layer runs at the first use of
+    a GPU, run here when the emulated library is loaded.  1 = passed (hub chains on by default), 0 = failed (off)."""
+    nb = _lib.dgs_spmm_hub_selftest_bytes()
+    scratch = _buf(nb)
+    return _lib.dgs_spmm_hub_selftest(_p(scratch), ctypes.c_size_t(nb), None)
 
 
 def _p(a):

@@ -14,6 +14,8 @@
 #include <utility>
 #include <vector>
 
+#include <string>
+
 #include "hip/hip_runtime.h"
 
 // AddressSanitizer build (make ASAN=1): the fibers switch stacks behind the sanitizer's back, so every switch is announced
@@ -404,6 +406,23 @@ void block_sync() {
   while (me->st != RUN) yield();
 }
 
+// Launch log: the source text of the kernel argument of every hipLaunchKernelGGL since the last emu_launch_log(clear = 1), one
+// "name grid.x grid.y" line each - how the tests see WHICH kernels a C-ABI call took and how many launches it cost.
+static std::string g_launch_log;
+void log_launch(const char *kern, dim3 grid) {
+  if (g_launch_log.size() < (1u << 20)) g_launch_log += std::string(kern) + " " + std::to_string(grid.x) + " " + std::to_string(grid.y) + "\n";
+}
+}  // namespace emu
+extern "C" size_t emu_launch_log(char *buf, size_t cap, int clear) {
+  const size_t n = emu::g_launch_log.size() < cap ? emu::g_launch_log.size() : (cap ? cap - 1 : 0);
+  if (buf && cap) {
+    memcpy(buf, emu::g_launch_log.data(), n);
+    buf[n] = 0;
+  }
+  if (clear) emu::g_launch_log.clear();
+  return n;
+}
+namespace emu {
 void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx) {
   const unsigned nthr = block.x * block.y * block.z;
   if (block.y != 1 || block.z != 1 || nthr == 0 || nthr > 1024) {

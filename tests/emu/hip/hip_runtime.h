@@ -59,6 +59,7 @@ void wave_sync();
 void block_sync();
 void relax();
 void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx);
+void log_launch(const char *kern, dim3 grid);  // tests ask which kernels a call launched (emu_launch_log)
 template <typename F>
 inline void launch(dim3 grid, dim3 block, F &&f) {
   auto tramp = [](void *c) { (*static_cast<typename std::remove_reference<F>::type *>(c))(); };
@@ -109,7 +110,7 @@ static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int
 static inline hipError_t hipMallocAsync(void **p, size_t n, hipStream_t) { *p = malloc(n); return *p ? hipSuccess : 1; }
 static inline hipError_t hipFreeAsync(void *p, hipStream_t) { free(p); return hipSuccess; }
 #define hipLaunchKernelGGL(kern, grid, block, ldsbytes, stream, ...) \
-  ::emu::launch((grid), (block), [&]() { kern(__VA_ARGS__); })
+  (::emu::log_launch(#kern, (grid)), ::emu::launch((grid), (block), [&]() { kern(__VA_ARGS__); }))
 #define HIP_SYMBOL(x) x
 #define hipGetSymbolAddress(pp, sym) ((*(pp) = (void *)&(sym)), hipSuccess)
 #define hipMemcpyToSymbol(sym, src, n) (memcpy((void *)&(sym), (src), (n)), hipSuccess)

@@ -295,3 +295,76 @@ def test_single_launch_inputs_chain_their_hub_rows(N):
         assert (np.abs(C0 - ref) <= 1e-5 * np.abs(ref) + 1e-6).all()
 
 
+
+
+def _kernels(log):
+    return [name.split('<')[0].strip('( ') for name, _, _ in log]
+
+
+def test_no_hub_rows_hint_keeps_the_plain_kernels():
+    """VERDICT r4 #7 / ADVICE r4: the single-launch hub kernel was chosen by `nnz > threshold`, i.e. for every graph the reference
+    benchmarks although none of them has such a row.  A caller that knows the longest row says so (DGS_ALG_NO_HUB_ROWS): small
+    inputs keep spmm_small, plan-free general launches lose the idle hub workgroups in front of the grid.  Same bits either way."""
+    E.set_env(DGS_HUB_CHAIN=None)  # the default threshold, gated on the self-test the loader ran
+    assert E.lib().dgs_spmm_hub_gate() == 1 and E.lib().dgs_spmm_hub_threshold() == 16384
+    rng = np.random.default_rng(5)
+    M, K, N = 6000, 6000, 64  # Gnutella-like: 30 k nnz > threshold in total, longest row 280
+    deg = rng.integers(0, 10, M)
+    deg[17], deg[4000] = 280, 78
+    rp = np.zeros(M + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    col = np.concatenate([np.sort(rng.choice(K, d, replace=False)) for d in deg]).astype(np.int32)
+    val = rng.random(col.size, dtype=np.float32)
+    X = feats(K, N)
+    assert col.size > 16384 and E.schedule(E.SUM, M, K, N, col.size) == 'small'
+    E.launch_log()
+    C0, _ = E.spmm(E.SUM, rp, col, val, X)
+    assert _kernels(E.launch_log()) == ['spmm_small_hub']  # what a caller without knowledge of the matrix gets
+    C1, _ = E.spmm(E.SUM, rp, col, val, X, algorithm=E.ALG_NO_HUB_ROWS)
+    assert _kernels(E.launch_log()) == ['spmm_small']
+    assert_bitexact(C0, C1, 'hint == no hint on a matrix without hub rows')
+    ref, _ = oracle.spmm('sum', rp, col, val, X, fma=True)
+    assert (np.abs(C1 - ref) <= 1e-5 * np.abs(ref) + 1e-6).all()
+    # general schedule, plan-free: the fused launch without / with the hub role (512 hub workgroups at 256 CUs)
+    M2 = 66000
+    deg2 = rng.integers(0, 3, M2)
+    deg2[5] = 900
+    rp2 = np.zeros(M2 + 1, np.int32)
+    rp2[1:] = np.cumsum(deg2)
+    col2 = np.concatenate([np.sort(rng.choice(K, d, replace=False)) for d in deg2]).astype(np.int32)
+    val2 = rng.random(col2.size, dtype=np.float32)
+    E.launch_log()
+    D0, _ = E.spmm(E.SUM, rp2, col2, val2, X)
+    log0 = E.launch_log()
+    D1, _ = E.spmm(E.SUM, rp2, col2, val2, X, algorithm=E.ALG_NO_HUB_ROWS)
+    log1 = E.launch_log()
+    f0 = [x for x in log0 if x[0].startswith('(spmm_fused')][0]
+    f1 = [x for x in log1 if x[0].startswith('(spmm_fused')][0]
+    assert 'true>' in f0[0].replace(' ', '') and 'false>' in f1[0].replace(' ', ''), (f0, f1)
+    assert f0[1] - f1[1] == 512, 'the hub workgroups of a plan-free launch: two per CU'
+    assert_bitexact(D0, D1, 'general schedule: hint == no hint')
+
+
+def test_hub_chains_are_gated_on_the_device_self_test():
+    """no device runs the hub workgroup unverified by default.  Without DGS_HUB_CHAIN the threshold is in
+    force only after dgs_spmm_hub_selftest() has passed on the device; an explicit DGS_HUB_CHAIN wins both ways."""
+    import subprocess
+    code = ('import sys, ctypes, numpy as np; sys.path.insert(0, %r); import emu_lib as E\n'
+            'import os; os.environ["DGS_EMU_LIB"] = os.path.join(%r, "_build", "libdgs_emu.so")\n'
+            'L = ctypes.CDLL(os.environ["DGS_EMU_LIB"])\n'  # loaded WITHOUT the loader's self-test
+            'print("before", L.dgs_spmm_hub_gate(), L.dgs_spmm_hub_threshold())\n'
+            'os.environ["DGS_HUB_CHAIN"] = "2048"; L.dgs_reload_tuning(); print("forced", L.dgs_spmm_hub_threshold())\n'
+            'os.environ["DGS_HUB_CHAIN"] = "0"; L.dgs_reload_tuning(); print("off", L.dgs_spmm_hub_threshold())\n'
+            'del os.environ["DGS_HUB_CHAIN"]; L.dgs_reload_tuning()\n'
+            'L.dgs_spmm_hub_selftest_bytes.restype = ctypes.c_size_t; nb = L.dgs_spmm_hub_selftest_bytes()\n'
+            'buf = np.zeros(nb + 64, np.uint8)\n'
+            'print("small_scratch", L.dgs_spmm_hub_selftest(ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(nb - 1), None))\n'
+            'print("selftest", L.dgs_spmm_hub_selftest(ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(nb), None))\n'
+            'print("after", L.dgs_spmm_hub_gate(), L.dgs_spmm_hub_threshold())\n') % (os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'),
+                                                                                      os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    E.lib()  # (built)
+    env = {k: v for k, v in os.environ.items() if not k.startswith('DGS_')}
+    p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = dict(line.split(' ', 1) for line in p.stdout.strip().splitlines())
+    assert out == {'before': '0 0', 'forced': '2048', 'off': '0', 'small_scratch': '-2', 'selftest': '1', 'after': '1 16384'}, p.stdout

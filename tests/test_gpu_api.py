@@ -648,3 +648,68 @@ def test_gin_cached_neighbourhood_is_keyed_on_the_graph():
     b = conv(e2, X, 4)
     assert conv._cached_dcsr is not d1 and b.shape == (4, 4)
     assert torch.equal(b, X + X[[1, 0, 3, 2]])
+
+
+def test_hub_self_test_passes_on_this_device_and_gates_the_default(monkeypatch):
+    """The default sum / mean chain their hub rows only on a device where the library's self-test has compared that chain, bit
+    for bit, with a one-thread-per-element sequential kernel (include/dgsparse_hip.h "Device gate").  On a healthy
+    MI355X it passes - so the default IS the chained schedule - and an explicit DGS_HUB_CHAIN wins both ways."""
+    from dgsparse import _capi
+    monkeypatch.delenv('DGS_HUB_CHAIN', raising=False)
+    _capi.ensure_hub_selftest(torch.device('cuda', torch.cuda.current_device()))
+    assert _capi.hub_gate() == 1, 'the hub-chain self-test FAILED on this device'
+    assert _capi.hub_threshold() == 16384
+    monkeypatch.setenv('DGS_HUB_CHAIN', '0')
+    assert _capi.hub_threshold() == 0
+    monkeypatch.setenv('DGS_HUB_CHAIN', '3000')
+    assert _capi.hub_threshold() == 3000
+    monkeypatch.delenv('DGS_HUB_CHAIN')
+    assert _capi.hub_threshold() == 16384
+    # the C entry again, by hand: idempotent, reports 1
+    nb = int(_capi._lib.dgs_spmm_hub_selftest_bytes())
+    scratch = torch.empty(nb, dtype=torch.uint8, device='cuda')
+    assert _capi._lib.dgs_spmm_hub_selftest(scratch.data_ptr(), nb, torch.cuda.current_stream().cuda_stream) == 1
+    assert _capi._lib.dgs_spmm_hub_selftest(scratch.data_ptr(), nb - 1, torch.cuda.current_stream().cuda_stream) == -2
+
+
+def test_storage_tells_the_launches_its_longest_row_and_column(monkeypatch):
+    """single-launch inputs are routed by the longest ROW, not by nnz.  The Storage learns the longest row in the
+    one sync its construction already has and the longest column without another one; spmm_sum / spmm_mean pass the hints on
+    (forward: rows, backward: columns).  Same bits with and without them; a matrix WITH a hub row gets no hint."""
+    import dgsparse
+    import oracle
+    from dgsparse import _capi
+    monkeypatch.delenv('DGS_HUB_CHAIN', raising=False)
+    rng = np.random.default_rng(9)
+    M = K = 6000
+    deg = rng.integers(0, 10, M)
+    deg[17], deg[4000] = 280, 78
+    rp = np.zeros(M + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    col = np.concatenate([np.sort(rng.choice(K, d, replace=False)) for d in deg]).astype(np.int32)
+    col[-1] = K - 1
+    val = rng.random(col.size, dtype=np.float32)
+    d = 'cuda'
+    drp, dcol, dval = (torch.from_numpy(a).to(d) for a in (rp, col, val))
+    A = dgsparse.SparseTensor(rowptr=drp, col=dcol, values=dval, has_value=True)
+    st = A.storage
+    assert st._max_row_len == 280
+    torch.cuda.synchronize()
+    want = _capi.ALG_NO_HUB_ROWS | _capi.ALG_NO_HUB_COLS
+    assert st.hub_hints() == want and st._hints == (16384, want)
+    assert st._max_col_len == int(np.bincount(col, minlength=K).max())
+    X = torch.rand((K, 64), device=d, requires_grad=True)
+    out = dgsparse.spmm_sum(A, X, 0)
+    plain, _ = _capi.spmm(_capi.SUM, drp, dcol, dval, X.detach())  # no hint: the single-launch hub kernel (nnz > threshold)
+    assert torch.equal(out.detach(), plain)
+    G = torch.rand_like(out)
+    out.backward(G)
+    colptr, row, tval, _ = oracle.csr2csc(rp, col, val, K)
+    gX, _ = oracle.spmm('sum', colptr, row, tval, G.cpu().numpy(), fma=True)
+    assert_close(X.grad.cpu().numpy(), gX, 1e-5, 2e-6, 'dX with the column hint')
+    monkeypatch.setenv('DGS_HUB_CHAIN', '200')  # now row 17 IS a hub row: no row hint, the column hint survives if true
+    bits = st.hub_hints()
+    assert not bits & _capi.ALG_NO_HUB_ROWS
+    out2 = dgsparse.spmm_sum(A, X.detach(), 0)
+    ref, _ = oracle.spmm('sum', rp, col, val, X.detach().cpu().numpy(), fma=True)
+    assert np.array_equal(out2.cpu().numpy()[17].view(np.int32), ref[17].view(np.int32)), 'the hub row is chained'
