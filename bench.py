@@ -276,12 +276,12 @@ def main():
         extra['backend'] = 'gloo (one-GPU dry run)' if one_gpu else 'nccl (RCCL)'
 
     def make_graph(seed):
+        # counter-based sampler (bench/graphgen.py hash_bits): the SAME graph, values and features on the GPU and on the CPU, so
+        # the emulation (bench/emu_parity.py) and the tests check exactly the tensors timed here (VERDICT r4 #2b)
         rp_, col_, st_ = graphgen.powerlaw_csr(Mloc, Mloc * a.deg, K=(a.ncols or None), alpha=a.alpha, dmax=a.dmax,
-                                               cols=a.cols, seed=seed, device=str(dev), as_torch=True)
-        g_ = torch.Generator(device=dev)
-        g_.manual_seed(seed + 1)
-        val_ = torch.rand(st_['nnz'], generator=g_, device=dev)
-        X_ = torch.rand((st_['K'], N), generator=g_, device=dev)
+                                               cols=a.cols, seed=seed, device=str(dev), as_torch=True, sampler='hash')
+        val_ = graphgen.values_t(st_['nnz'], seed, dev)
+        X_ = graphgen.features_t(st_['K'], N, seed, dev)
         return rp_, col_, st_, val_, X_
 
     strict_alg = {'': 0, 'fma': _capi.ALG_STRICT_SUM, 'nofma': _capi.ALG_STRICT_NOFMA}[a.strict]
@@ -477,12 +477,36 @@ def main():
                 continue
             rp2, col2, st2, val2, X2 = make_graph(s)
             st2p, _ = make_step(rp2, col2, val2, X2)
-            st2p()
+            C2, _ = st2p()
             seeds[str(s)] = dict(ms=round(sorted(event_ms(st2p, max(10, a.steps // 5)) for _ in range(3))[1], 5),
                                  nnz=int(st2['nnz']))
-            del rp2, col2, val2, X2, st2p
+            if a.reduce == 'sum' and not a.no_cpu_baseline:
+                # the 1e-5 claim is a property of the schedule, not of seed 0 (VERDICT r4 #2a): every element of every seed
+                # against the reference's sequential chain (the oracle's mul-add chain, pinned bit for bit to
+                # spmm_reference_host by tests/test_oracle_pin.py, on all host cores)
+                seeds[str(s)]['parity'] = parity_vs_sequential(C2.cpu().numpy(), rp2.cpu().numpy(), col2.cpu().numpy(),
+                                                               val2.cpu().numpy(), X2.cpu().numpy())
+            del rp2, col2, val2, X2, st2p, C2
         prot['seeds'] = seeds
         res['protocol'] = prot
+        if '+hub' in res.get('schedule', ''):
+            # what the hub chains cost next to the tree on the same tensors (the decision rule needs both numbers
+            # in every line): DGS_HUB_CHAIN=0 for one measurement, then back to what this process was started with
+            had = os.environ.get('DGS_HUB_CHAIN')
+            os.environ['DGS_HUB_CHAIN'] = '0'
+            _capi.reload_tuning()
+            step0, _ = make_step(rp, col, val, X)
+            step0()
+            off_ms = sorted(event_ms(step0, max(10, a.steps // 5)) for _ in range(3))[1]
+            del step0
+            if had is None:
+                os.environ.pop('DGS_HUB_CHAIN')
+            else:
+                os.environ['DGS_HUB_CHAIN'] = had
+            _capi.reload_tuning()
+            res['hub_chain'].update(on_ms=prot['median_ms'], off_ms=round(off_ms, 5),
+                                    cost_frac=round(prot['median_ms'] / off_ms - 1.0, 4),
+                                    rule='chains stay the default while they cost <= 5 % over the tree (DESIGN.md 4.1g)')
 
     C_strict = {}
     if not a.no_protocol and not use_dist:

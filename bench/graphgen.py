@@ -45,38 +45,86 @@ def powerlaw_degrees(M: int, nnz: int, alpha: float, dmax: int, rng) -> np.ndarr
     return deg
 
 
-def _sample_cols(deg_t, K, cols, cdf, gen, device):
+def hash_bits(n: int, seed: int, stream: int, device='cpu', start: int = 0):
+    """n pseudo-random int64 words, word i = splitmix64(seed, stream, start + i): a COUNTER-based generator written with integer
+    tensor ops only, so the CPU and the GPU produce the same words (torch's own generators differ per device type: the round-4
+    emulation could only reproduce a sibling of the graph bench.py timed on the GPU, VERDICT r4 #2b)."""
+    import torch
+
+    def lsr(x, k):  # logical shift right of an int64 tensor
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    def c(v):  # 64-bit constant as a signed int64 (multiplication wraps)
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    z = torch.arange(start, start + n, dtype=torch.int64, device=device)
+    z = (z + c((seed * 0xD1B54A32D192ED03 + stream * 0x8CB92BA72F3D8DD7 + 0x9E3779B97F4A7C15) & ((1 << 64) - 1))) * c(0x9E3779B97F4A7C15)
+    z = (z ^ lsr(z, 30)) * c(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * c(0x94D049BB133111EB)
+    return z ^ lsr(z, 31)
+
+
+def hash_unit(n: int, seed: int, stream: int, device='cpu', dtype=None, start: int = 0):
+    """n numbers in [0, 1) from hash_bits: float64 with 53 random bits, or float32 with 24 (exact conversions: the same values
+    on every device)."""
+    import torch
+    b = hash_bits(n, seed, stream, device, start)
+    if dtype in (None, torch.float64):
+        return ((b >> 11) & ((1 << 53) - 1)).to(torch.float64) * (1.0 / (1 << 53))
+    assert dtype == torch.float32
+    return ((b >> 40) & ((1 << 24) - 1)).to(torch.float32) * (1.0 / (1 << 24))
+
+
+def values_t(nnz: int, seed: int, device='cpu'):
+    """Edge values U[0,1) float32 as a torch tensor on `device`, the same bits on CPU and GPU (what bench.py times)."""
+    return hash_unit(nnz, seed, 101, device, __import__('torch').float32)
+
+
+def features_t(K: int, N: int, seed: int, device='cpu'):
+    """Dense operand U[0,1) float32 [K, N] as a torch tensor on `device`, the same bits on CPU and GPU."""
+    return hash_unit(K * N, seed, 102, device, __import__('torch').float32).view(K, N)
+
+
+def _sample_cols(deg_t, K, cols, cdf, gen, device, stream=1):
+    """`gen`: a torch.Generator (the historical streams, different on CPU and GPU) or an int seed (hash_bits: device-independent)."""
     import torch
     total = int(deg_t.sum())
     row = torch.repeat_interleave(torch.arange(deg_t.shape[0], device=device), deg_t)
+    hashed = isinstance(gen, int)
     if cols == 'uniform':
-        col = torch.randint(0, K, (total,), generator=gen, device=device)
+        col = (hash_bits(total, gen, stream, device) >> 1 & ((1 << 62) - 1)) % K if hashed else \
+            torch.randint(0, K, (total,), generator=gen, device=device)
     elif cols == 'local':  # community-like: columns within a window around the row id (graphs in a locality-
         w = max(64, K // 256)  # preserving order, e.g. after METIS/RCM reordering)
-        off = torch.randint(-w, w + 1, (total,), generator=gen, device=device)
+        off = ((hash_bits(total, gen, stream, device) >> 1 & ((1 << 62) - 1)) % (2 * w + 1) - w) if hashed else \
+            torch.randint(-w, w + 1, (total,), generator=gen, device=device)
         col = (row * K // deg_t.shape[0] + off).clamp_(0, K - 1)
     else:
-        u = torch.rand(total, generator=gen, device=device, dtype=torch.float64)
+        u = hash_unit(total, gen, stream, device) if hashed else torch.rand(total, generator=gen, device=device, dtype=torch.float64)
         col = torch.searchsorted(cdf, u, right=True).clamp_(max=K - 1)
     return row * K + col
 
 
 def powerlaw_csr(M: int, nnz: int, K: int | None = None, alpha: float = 2.1, dmax: int | None = None,
                  cols: str = 'powerlaw', seed: int = 0, dedup: bool = True, device: str = 'cpu',
-                 as_torch: bool = False):
+                 as_torch: bool = False, sampler: str = 'torch'):
     """Power-law CSR.  ``cols``: 'powerlaw' = column popularity follows the same degree law
     (Chung-Lu style: hubs are both prolific and popular, as in citation/social graphs);
     'uniform' = columns uniform in [0,K) (worst case for cache reuse of the dense operand).
     The big arrays are built with torch on ``device`` (a GPU when bench.py has one; streams differ
-    per device type but are seeded).  Duplicates are removed and topped up once, so nnz' ~= nnz.
+    per device type but are seeded; ``sampler='hash'``: the counter-based generator above instead - the SAME graph whatever the
+    device, which is what bench.py times since round 5).  Duplicates are removed and topped up once, so nnz' ~= nnz.
     Returns (rowptr int32 [M+1], col int32 [nnz'], stats dict)."""
     import torch
     rng = np.random.Generator(np.random.PCG64(seed))
     K = M if K is None else K
     dmax = min(K, dmax if dmax is not None else max(1, M // 16))
     deg = powerlaw_degrees(M, nnz, alpha, dmax, rng)
-    gen = torch.Generator(device=device)
-    gen.manual_seed(seed)
+    if sampler == 'hash':
+        gen = int(seed)
+    else:
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)
     cdf = None
     if cols == 'powerlaw':
         w = powerlaw_degrees(K, nnz, alpha, dmax, rng).astype(np.float64) + 0.05
@@ -94,7 +142,7 @@ def powerlaw_csr(M: int, nnz: int, K: int | None = None, alpha: float = 2.1, dma
         lack = (deg_t - have).clamp_(min=0)
         lack = torch.minimum(lack, K - have)
         if int(lack.sum()) > 0:  # one top-up round for rows that lost duplicates
-            extra = _sample_cols(lack, K, cols, cdf, gen, device)
+            extra = _sample_cols(lack, K, cols, cdf, gen, device, stream=2)
             key = torch.unique_consecutive(torch.sort(torch.cat([key, extra])).values)
     row = key // K
     col = (key - row * K).to(torch.int32)
@@ -103,7 +151,7 @@ def powerlaw_csr(M: int, nnz: int, K: int | None = None, alpha: float = 2.1, dma
     torch.cumsum(counts, 0, out=rowptr[1:])
     assert int(rowptr[-1]) < 2**31
     stats = dict(M=M, K=K, nnz=int(rowptr[-1]), max_deg=int(counts.max()),
-                 empty_rows=int((counts == 0).sum()), cols=cols, alpha=alpha, seed=seed, gen_device=device)
+                 empty_rows=int((counts == 0).sum()), cols=cols, alpha=alpha, seed=seed, gen_device=device, sampler=sampler)
     rowptr = rowptr.to(torch.int32)
     if as_torch:
         return rowptr, col, stats

@@ -291,7 +291,7 @@ inline int check_launch() { return hipGetLastError() == hipSuccess ? DGS_OK : DG
 constexpr int kTuneUnset = INT_MIN;
 struct Tuning {
   int panel, panel_kb, panel_lead, panel_tlong, min_waves, nbu, strict_mid, strict_hub, strict_nbu, sddmm_fused;
-  int plan_tslice, plan_unit, plan_ch, plan_nocut, hub_chain;
+  int plan_tslice, plan_unit, plan_ch, plan_nocut, hub_chain, fold;
 };
 const Tuning &tuning();
 inline int tune(int v, int dflt) { return v == kTuneUnset ? dflt : v; }

@@ -37,6 +37,7 @@ static void tuning_read(Tuning &t) {
   t.plan_ch = rd("DGS_PLAN_CH");
   t.plan_nocut = rd("DGS_PLAN_NOCUT");
   t.hub_chain = rd("DGS_HUB_CHAIN");
+  t.fold = rd("DGS_FOLD");
 }
 static void tuning_publish() {
   std::lock_guard<std::mutex> lk(g_tuning_mu);
@@ -72,6 +73,17 @@ void hub_gate_set(int state) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
   g_hub_gate[dev].store(state, std::memory_order_release);
+}
+static std::atomic<int> g_fold_gate[64];
+int fold_gate() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  return g_fold_gate[dev].load(std::memory_order_acquire);
+}
+void fold_gate_set(int state) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+  g_fold_gate[dev].store(state, std::memory_order_release);
 }
 
 // One row per G-lane group, V floats per lane: dst[i,:] = src[ids[i],:]

@@ -114,10 +114,15 @@ struct UnitTab {
   const int4 *longrows;
   const int *xcd_end = nullptr;  // [8] where each XCD's walk stops (a plan's hub-row units are skipped when the hub blocks
                                  // chain those rows), or nullptr = the next share's start
+  // In-kernel fold (round 5): long-row index of every partial slot + one arrival counter per long row (zero at launch).  The
+  // unit wave that brings a row's count to its number of units folds the row on the spot - no combine launch.  nullptr = the
+  // partial rows wait for spmm_combine.
+  const int *slot_long = nullptr;
+  int *arrive = nullptr;
 };
 
 struct WsLayout {
-  size_t off_units, off_long, off_part, off_parte, total;
+  size_t off_units, off_long, off_part, off_parte, off_slot, off_arrive, total;
   int64_t max_units, max_pslots, max_long;
   int ch;
 };
@@ -129,6 +134,8 @@ static inline int unit_len(int64_t nnz) {
   return ch;
 }
 
+// feature tiles a launch over N floats can have (16-byte lanes: 256- or, narrowed, 64-float tiles; scalar lanes: 64-float tiles)
+static inline int64_t max_tiles(int64_t N) { return (N + 63) / 64 + 1; }
 static inline WsLayout ws_layout(int reduce_op, int64_t N, int64_t nnz) {
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
   WsLayout L;
@@ -145,20 +152,25 @@ static inline WsLayout ws_layout(int reduce_op, int64_t N, int64_t nnz) {
   const size_t prow = up((size_t)L.max_pslots * N * sizeof(float));  // one partial row per unit of a multi-unit row
   L.off_parte = L.off_part + prow;
   const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
-  L.total = L.off_parte + (arg ? prow : 0) + 256;
+  L.off_slot = L.off_parte + (arg ? prow : 0);                         // long-row index of every partial slot
+  L.off_arrive = L.off_slot + up((size_t)L.max_pslots * sizeof(int));  // arrival counter of every long row
+  L.total = L.off_arrive + up((size_t)L.max_long * max_tiles(N) * sizeof(int)) + 256;  // (one counter per row and feature tile)
   return L;
 }
 
 // With a cached plan the workspace only holds the partial rows of the multi-unit rows.
-static inline WsLayout ws_layout_plan(int reduce_op, int64_t N, int64_t pslots) {
+// (+ the arrival counters of the in-kernel fold, one int per long row; the slot -> long-row map is part of the plan)
+static inline WsLayout ws_layout_plan(int reduce_op, int64_t N, int64_t pslots, int64_t n_long) {
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
   WsLayout L{};
   L.max_pslots = pslots;
+  L.max_long = n_long;
   L.off_part = 0;
   const size_t prow = up((size_t)(pslots > 0 ? pslots : 1) * N * sizeof(float));
   L.off_parte = prow;
   const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
-  L.total = prow + (arg ? prow : 0) + 256;
+  L.off_arrive = prow + (arg ? prow : 0);
+  L.total = L.off_arrive + up((size_t)(n_long > 0 ? n_long : 1) * max_tiles(N) * sizeof(int)) + 256;
   return L;
 }
 // plan buffer: [256-byte header][column grid: 129 ints][units: max_units int4][long rows: max_long int4]; the capacities
@@ -172,8 +184,10 @@ constexpr int kHubChain = 16384;    // default hub threshold of the sum / mean l
 constexpr int kHubChainMin = 1024;  // smallest threshold accepted (bounds the hub tables: nnz / 1024 rows)
 struct PlanLayout {
   int64_t max_units, max_long, max_hub;
-  size_t off_bounds, off_units, off_long, off_hub, total;
+  size_t off_bounds, off_units, off_long, off_hub, off_slot, total;
 };
+// where the slot -> long-row map sits: behind the hub table (build-time layout: capacities; compact plan: counts)
+static inline size_t plan_off_slot(size_t off_hub, int64_t n_hub) { return off_hub + (((size_t)n_hub * sizeof(int4) + 255) & ~size_t(255)); }
 static inline PlanLayout plan_layout(int64_t nnz) {
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
   PlanLayout L;
@@ -185,8 +199,10 @@ static inline PlanLayout plan_layout(int64_t nnz) {
   L.max_hub = nnz / kHubChainMin + 16;
   L.off_long = L.off_units + up((size_t)L.max_units * sizeof(int4));
   L.off_hub = L.off_long + up((size_t)L.max_long * sizeof(int4));
-  // hub region: max_hub entries {row, first nnz, nnz, -}  (a compact plan: n_hub entries)
-  L.total = L.off_hub + up((size_t)L.max_hub * sizeof(int4)) + 256;
+  // hub region: max_hub entries {row, first nnz, nnz, -}  (a compact plan: n_hub entries); then one int per partial slot: the
+  // index of the slot's row in the long-row table (what the in-kernel fold needs to find the row's arrival counter)
+  L.off_slot = plan_off_slot(L.off_hub, L.max_hub);
+  L.total = L.off_slot + up((size_t)L.max_units * sizeof(int)) + 256;
   return L;
 }
 
@@ -358,7 +374,8 @@ constexpr int kK0Rows = 16;
 static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, int tlong, int thub, const HubTab ht,
                                                                const int *__restrict__ rowptr,
                                                                SpmmWs *__restrict__ hdr, int4 *__restrict__ units,
-                                                               int4 *__restrict__ longrows) {
+                                                               int4 *__restrict__ longrows, int *__restrict__ slot_long,
+                                                               int *__restrict__ arrive, int ntiles) {
   __shared__ int s_wsum[kBlock / kWave], s_psum[kBlock / kWave], s_lsum[kBlock / kWave];
   __shared__ int s_base, s_pbase, s_lbase;
   // block b owns the CONTIGUOUS rows [b*4096, (b+1)*4096): its units form one run of the table that covers
@@ -449,9 +466,12 @@ static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, in
     for (int k = 0; k < nch; k++) {
       const int p0 = rs + k * ch;
       units[off + k] = make_int4(r, p0, min(ch, re - p0), nch > 1 ? poff + k : -1);
+      if (nch > 1 && slot_long) slot_long[poff + k] = loff;  // in-kernel fold: which long row a partial slot belongs to
     }
     off += nch;
     if (nch > 1) {
+      if (arrive)  // ... and the row's arrival counters, one per feature tile (the workspace's contents are undefined on entry)
+        for (int t = 0; t < ntiles; t++) arrive[(int64_t)loff * ntiles + t] = 0;
       longrows[loff++] = make_int4(r, poff, nch, 0);
       poff += nch;
     }
@@ -900,6 +920,134 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Fold of ONE multi-unit row by one wave: the row's partial rows in unit order (groups take interleaved units, UP independent
+// partial loads in flight per lane, then the fixed cross-group tree), MIN's NaN redo, mean, epilogue, store.  Two callers: the
+// combine kernel (K3: one wave per entry of the long-row table, after the fused launch) and - round 5, COH = true - the unit wave
+// that completed the row inside the fused launch (spmm_units_body: last arriver), which reads the partial rows other workgroups
+// - other XCDs - wrote moments ago: those loads are agent-scope (sc1: past the XCD's own L2), like the stores that wrote them.
+#ifndef DGS_COMBINE_UP
+#define DGS_COMBINE_UP 8  // partial rows in flight per lane: 4 -> 8 takes the fold of a 400-unit hub row from 25 to 13 dependent rounds (combine 13.6 -> ~8 us on the headline graph, 8.7 -> 6.5 us arxiv-shaped); 16 adds little
+#endif
+#ifndef DGS_COMBINE_UP_ARG
+#define DGS_COMBINE_UP_ARG 4  // max / min carry (value, arg) per partial row: 8 in flight cost 134 VGPRs = 3 waves per SIMD
+#endif
+template <int V, bool COH, typename T>
+__device__ __forceinline__ void load_part(const T *p, T (&o)[V]) {
+  if constexpr (COH) {
+#pragma unroll
+    for (int v = 0; v < V; v++) o[v] = __hip_atomic_load(p + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    load_vec<V>(p, o);
+  }
+}
+template <int V, typename T>
+__device__ __forceinline__ void store_part_coherent(T *p, const T (&o)[V]) {
+#pragma unroll
+  for (int v = 0; v < V; v++) __hip_atomic_store(p + v, o[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int G, int V, int OP, bool ACC, bool COH>
+__device__ __forceinline__ void fold_row(const int4 d, const int lane, const int N, const int *__restrict__ rowptr,
+                                         const int *__restrict__ col, const float *__restrict__ val,
+                                         const float *__restrict__ B, float *__restrict__ C, int *__restrict__ E,
+                                         const float *__restrict__ part, const int *__restrict__ parte, const AccArg &aa) {
+  constexpr int NG = kWave / G;
+  constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
+  // max: a partial row that never improved on the identity carries the identity as its value, so the fold needs values and
+  // positions only; the arg id of each element's winner is fetched once at the end (half the loads, 8 rows in flight again)
+  constexpr bool LATE_ARG = (OP == DGS_MAX);
+  constexpr int UP = (ARG && !LATE_ARG) ? DGS_COMBINE_UP_ARG : DGS_COMBINE_UP;
+  const int g = lane / G, l = lane % G;
+  const int f0 = (blockIdx.y * G + l) * V;
+  const bool fl = f0 < N;
+  float acc[V];
+  int ei[V], ep[V], el[V];
+  unsigned nm = 0;  // MIN: elements whose partials met a NaN product
+#pragma unroll
+  for (int v = 0; v < V; v++) {
+    acc[v] = reduce_init<OP>();
+    ei[v] = -1;
+    ep[v] = INT_MAX;
+    el[v] = -1;
+  }
+  for (int k = g; k < d.z; k += NG * UP) {
+    float x[UP][V];
+    int xe[UP][V];
+    // every load is issued, with its index clamped into the row's slots: conditional loads end up in basic blocks of their
+    // own, and hipcc's waitcnt pass then puts a vmcnt(1) in front of each - 8 dependent latencies per round instead of
+    // one (ISA read, late round 3: combine of max 54.8 us for 10.4 us of sum on the headline graph)
+#pragma unroll
+    for (int q = 0; q < UP; q++) {
+      const int64_t slot = (int64_t)(d.y + min(k + q * NG, d.z - 1)) * N + (fl ? f0 : 0);
+      load_part<V, COH>(part + slot, x[q]);
+      if constexpr (ARG && !LATE_ARG) load_part<V, COH>(parte + slot, xe[q]);
+    }
+    // branch-free folds (selects on fresh values): the merges of one round are 32 short data-dependent branches otherwise
+#pragma unroll
+    for (int q = 0; q < UP; q++) {
+      const int pos = k + q * NG;
+      const bool valid = (pos < d.z) & fl;
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        if constexpr (OP == DGS_MIN) {
+          // units arrive in increasing k inside a group: a strictly smaller partial takes everything, an equal one
+          // only refreshes the value (later operand wins ties in the MIN macro); E=-1 partials never improved
+          const bool nanp = valid & (xe[q][v] == kNanMark);
+          const bool live = valid & (xe[q][v] != kNanMark) & (xe[q][v] != -1);
+          const bool lt = live & (acc[v] > x[q][v]);
+          const bool le = lt | (live & (acc[v] == x[q][v]));
+          nm |= nanp ? (1u << v) : 0u;
+          acc[v] = le ? x[q][v] : acc[v];
+          ei[v] = lt ? xe[q][v] : ei[v];
+          ep[v] = lt ? pos : ep[v];
+          el[v] = le ? pos : el[v];
+        } else if constexpr (ARG) {
+          // a partial that never improved on the identity (E = -1) holds the identity itself: it can take the position of
+          // another such partial, never that of a real one, and the arg id fetched for it at the end is its -1
+          const bool take = valid & arg_better<OP>(acc[v], ep[v], x[q][v], pos);
+          acc[v] = take ? x[q][v] : acc[v];
+          ep[v] = take ? pos : ep[v];
+        } else {
+          if (valid) acc[v] += x[q][v];
+        }
+      }
+    }
+  }
+  cross_group_reduce<G, V, OP>(acc, ei, ep, el);
+  if constexpr (LATE_ARG) {
+    if (g == 0 && fl) {
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        if (ep[v] != INT_MAX) {
+          const int *q = parte + (int64_t)(d.y + ep[v]) * N + f0 + v;
+          ei[v] = COH ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+        } else {
+          ei[v] = -1;
+        }
+      }
+    }
+  }
+  if constexpr (OP == DGS_MIN) {
+#pragma unroll
+    for (int dd = G; dd < 64; dd <<= 1) nm |= (unsigned)__shfl_xor((int)nm, dd, 64);
+    if (nm && g == 0 && fl) seq_redo<V, OP>(nm, rowptr[d.x], rowptr[d.x + 1], N, f0, col, val, B, acc, ei);
+  }
+  if (g == 0 && fl) {
+    if constexpr (OP == DGS_MEAN) {
+      const float dg = (float)(rowptr[d.x + 1] - rowptr[d.x]);
+#pragma unroll
+      for (int v = 0; v < V; v++) acc[v] /= dg;
+    }
+    if constexpr (ACC) {
+      acc_commit<V, OP, false>(C, E, aa.rowmap ? aa.rowmap[d.x] : d.x, N, f0, acc, ei, aa);
+    } else {
+      if constexpr (epi_op<OP>()) epi_apply<V>(acc, d.x, f0, aa.epi);
+      store_vec_stream<V>(C + (int64_t)d.x * N + f0, acc);
+      if constexpr (ARG) store_vec_stream<V>(E + (int64_t)d.x * N + f0, ei);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // K2: one wave per unit (<= ch nnz of a long row).
 template <int G, int V, int OP, bool HAS_VAL, bool ACC = false>
 __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &lds, int N,
@@ -933,6 +1081,28 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
     uend = n_units;
     wstride = nblocks * (kBlock / kWave);
   }
+  // In-kernel fold (ut.arrive != nullptr): a unit's partial row is written with agent-scope stores, and ONE unit later - when the
+  // wave has waited for that unit's gathers anyway, so the stores are long complete and the wait below is free - the wave counts
+  // the unit in on its row's arrival counter; whoever brings the count to the row's number of units folds the row right here
+  // (fold_row: fixed unit order, so the result does not depend on who that is).  Ordering: stores performed at agent scope
+  // (s_waitcnt vmcnt(0)) -> atomic add on the counter -> the last arriver's loads, issued after its own add has returned.
+  const bool folding = ut.arrive != nullptr;
+  int pend = -1;  // long-row index of the partial row this wave wrote last and has not counted in yet
+  auto arrive = [&](int li) {
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's partial-row stores have been performed
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    int old = 0;
+    // (one counter per long row AND feature tile: the tiles of a launch fold independently)
+    if (lane == 0)
+      old = __hip_atomic_fetch_add(ut.arrive + (int64_t)li * gridDim.y + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __shfl(old, 0, 64);
+    const int4 lr = ut.longrows[li];  // {row, first partial slot, units in the row, -}
+    if (old == lr.z - 1) {
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      fold_row<G, V, OP, ACC, true>(lr, lane, N, rowptr, col, HAS_VAL ? val : nullptr, B, C, E, part, parte, aa);
+    }
+  };
   for (; u < uend; u += wstride) {
     const int4 d = ut.units[u];  // {row, first nnz, nnz in the unit, partial slot | -1}
     const int p0 = d.y, p1 = d.y + d.z;
@@ -961,6 +1131,10 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
         }
       }
     }
+    if (folding && pend >= 0) {  // the previous partial row of this wave: its stores are a whole unit old, the wait is free
+      arrive(pend);
+      pend = -1;
+    }
     if (g == 0 && fl) {
       if (whole) {  // the whole row was this unit: final result
         if constexpr (OP == DGS_MEAN) {
@@ -977,11 +1151,18 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
         }
       } else {
         const int64_t slot = (int64_t)d.w * N + f0;
-        store_vec<V>(part + slot, acc);
-        if constexpr (ARG) store_vec<V>(parte + slot, ei);
+        if (folding) {
+          store_part_coherent<V>(part + slot, acc);
+          if constexpr (ARG) store_part_coherent<V>(parte + slot, ei);
+        } else {
+          store_vec<V>(part + slot, acc);
+          if constexpr (ARG) store_vec<V>(parte + slot, ei);
+        }
       }
     }
+    if (folding && !whole) pend = ut.slot_long[d.w];
   }
+  if (folding && pend >= 0) arrive(pend);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1138,8 +1319,7 @@ __global__ __launch_bounds__(kBlock) void spmm_small_strict(int M, int N, int rp
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K3: one wave per entry of the long-row table folds that row's partial rows in unit order (groups take interleaved
-// units, 4 independent partial loads in flight per lane, then the fixed cross-group tree).
+// K3: one wave per entry of the long-row table (launches that do not fold inside the fused kernel).
 template <int G, int V, int OP, bool ACC = false>
 __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restrict__ rowptr,
                                                        const int *__restrict__ col, const float *__restrict__ val,
@@ -1147,108 +1327,13 @@ __global__ __launch_bounds__(kBlock) void spmm_combine(int N, const int *__restr
                                                        int *__restrict__ E, const UnitTab ut,
                                                        const float *__restrict__ part,
                                                        const int *__restrict__ parte, const AccArg aa, const int skip_hub) {
-  constexpr int NG = kWave / G;
-  constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
-#ifndef DGS_COMBINE_UP
-#define DGS_COMBINE_UP 8  // partial rows in flight per lane: 4 -> 8 takes the fold of a 400-unit hub row from 25 to 13 dependent rounds (combine 13.6 -> ~8 us on the headline graph, 8.7 -> 6.5 us arxiv-shaped); 16 adds little
-#endif
-#ifndef DGS_COMBINE_UP_ARG
-#define DGS_COMBINE_UP_ARG 4  // max / min carry (value, arg) per partial row: 8 in flight cost 134 VGPRs = 3 waves per SIMD
-#endif
-  // max: a partial row that never improved on the identity carries the identity as its value, so the fold needs values and
-  // positions only; the arg id of each element's winner is fetched once at the end (half the loads, 8 rows in flight again)
-  constexpr bool LATE_ARG = (OP == DGS_MAX);
-  constexpr int UP = (ARG && !LATE_ARG) ? DGS_COMBINE_UP_ARG : DGS_COMBINE_UP;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int g = lane / G, l = lane % G;
-  const int f0 = (blockIdx.y * G + l) * V;
-  const bool fl = f0 < N;
   const int n_long = *ut.n_long;
   const int wstride = gridDim.x * (kBlock / kWave);
   for (int i = blockIdx.x * (kBlock / kWave) + wave; i < n_long; i += wstride) {
     const int4 d = ut.longrows[i];  // {row, first partial slot, units in the row, 1 = a plan's hub row}
     if (skip_hub && d.w) continue;  // chained whole by the hub blocks of the fused launch: nothing to fold
-    {
-    float acc[V];
-    int ei[V], ep[V], el[V];
-    unsigned nm = 0;  // MIN: elements whose partials met a NaN product
-#pragma unroll
-    for (int v = 0; v < V; v++) {
-      acc[v] = reduce_init<OP>();
-      ei[v] = -1;
-      ep[v] = INT_MAX;
-      el[v] = -1;
-    }
-    for (int k = g; k < d.z; k += NG * UP) {
-      float x[UP][V];
-      int xe[UP][V];
-      // every load is issued, with its index clamped into the row's slots: conditional loads end up in basic blocks of their
-      // own, and hipcc's waitcnt pass then puts a vmcnt(1) in front of each - 8 dependent latencies per round instead of
-      // one (ISA read, late round 3: combine of max 54.8 us for 10.4 us of sum on the headline graph)
-#pragma unroll
-      for (int q = 0; q < UP; q++) {
-        const int64_t slot = (int64_t)(d.y + min(k + q * NG, d.z - 1)) * N + (fl ? f0 : 0);
-        load_vec<V>(part + slot, x[q]);
-        if constexpr (ARG && !LATE_ARG) load_vec<V>(parte + slot, xe[q]);
-      }
-      // branch-free folds (selects on fresh values): the merges of one round are 32 short data-dependent branches otherwise
-#pragma unroll
-      for (int q = 0; q < UP; q++) {
-        const int pos = k + q * NG;
-        const bool valid = (pos < d.z) & fl;
-#pragma unroll
-        for (int v = 0; v < V; v++) {
-          if constexpr (OP == DGS_MIN) {
-            // units arrive in increasing k inside a group: a strictly smaller partial takes everything, an equal one
-            // only refreshes the value (later operand wins ties in the MIN macro); E=-1 partials never improved
-            const bool nanp = valid & (xe[q][v] == kNanMark);
-            const bool live = valid & (xe[q][v] != kNanMark) & (xe[q][v] != -1);
-            const bool lt = live & (acc[v] > x[q][v]);
-            const bool le = lt | (live & (acc[v] == x[q][v]));
-            nm |= nanp ? (1u << v) : 0u;
-            acc[v] = le ? x[q][v] : acc[v];
-            ei[v] = lt ? xe[q][v] : ei[v];
-            ep[v] = lt ? pos : ep[v];
-            el[v] = le ? pos : el[v];
-          } else if constexpr (ARG) {
-            // a partial that never improved on the identity (E = -1) holds the identity itself: it can take the position of
-            // another such partial, never that of a real one, and the arg id fetched for it at the end is its -1
-            const bool take = valid & arg_better<OP>(acc[v], ep[v], x[q][v], pos);
-            acc[v] = take ? x[q][v] : acc[v];
-            ep[v] = take ? pos : ep[v];
-          } else {
-            if (valid) acc[v] += x[q][v];
-          }
-        }
-      }
-    }
-    cross_group_reduce<G, V, OP>(acc, ei, ep, el);
-    if constexpr (LATE_ARG) {
-      if (g == 0 && fl) {
-#pragma unroll
-        for (int v = 0; v < V; v++) ei[v] = (ep[v] != INT_MAX) ? parte[(int64_t)(d.y + ep[v]) * N + f0 + v] : -1;
-      }
-    }
-    if constexpr (OP == DGS_MIN) {
-#pragma unroll
-      for (int dd = G; dd < 64; dd <<= 1) nm |= (unsigned)__shfl_xor((int)nm, dd, 64);
-      if (nm && g == 0 && fl) seq_redo<V, OP>(nm, rowptr[d.x], rowptr[d.x + 1], N, f0, col, val, B, acc, ei);
-    }
-    if (g == 0 && fl) {
-      if constexpr (OP == DGS_MEAN) {
-        const float dg = (float)(rowptr[d.x + 1] - rowptr[d.x]);
-#pragma unroll
-        for (int v = 0; v < V; v++) acc[v] /= dg;
-      }
-      if constexpr (ACC) {
-        acc_commit<V, OP, false>(C, E, aa.rowmap ? aa.rowmap[d.x] : d.x, N, f0, acc, ei, aa);
-      } else {
-        if constexpr (epi_op<OP>()) epi_apply<V>(acc, d.x, f0, aa.epi);
-        store_vec_stream<V>(C + (int64_t)d.x * N + f0, acc);
-        if constexpr (ARG) store_vec_stream<V>(E + (int64_t)d.x * N + f0, ei);
-      }
-    }
-    }
+    fold_row<G, V, OP, ACC, false>(d, lane, N, rowptr, col, val, B, C, E, part, parte, aa);
   }
 }
 
@@ -1348,8 +1433,22 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
 // compared them with a one-thread-per-element sequential kernel and found them bit-identical (hub_gate(); ADVICE r4: the hub
 // workgroup leans on scheduling behaviour no CPU test can see, so no device runs it unverified by default).
 constexpr int kHintForceHub = 0x40000000;  // internal (the self-test itself): default threshold whatever the gate says
+constexpr int kHintForceFold = 0x20000000;  // internal (the self-test): fold inside the fused launch whatever the gate says
+constexpr int kHintNoFold = 0x10000000;     // internal (the self-test's hub pass): separate combine launch
 int hub_gate();                            // misc.hip: 1 = self-test passed on the current device, 0 = not run, -1 = failed
 void hub_gate_set(int state);
+int fold_gate();                           // the same for the in-kernel fold of partial rows
+void fold_gate_set(int state);
+// Fold the partial rows of multi-unit rows INSIDE the fused launch (last-arriving unit wave, spmm_units_body) instead of in a
+// combine launch behind it: DGS_FOLD=0 | 1 decides; unset, the device self-test does (the hand-over of partial rows between
+// workgroups on different XCDs rests on agent-scope stores / loads around an atomic counter - memory-system behaviour the CPU
+// emulation cannot see, so like the hub chains it is on only where dgs_spmm_hub_selftest has seen it produce the right bits).
+static inline bool fold_enabled(int hints) {
+  if (hints & kHintNoFold) return false;
+  if (hints & kHintForceFold) return true;
+  const int e = tuning().fold;
+  return e == kTuneUnset ? fold_gate() > 0 : e != 0;
+}
 static inline int hub_threshold(int hints = 0) {
   if (hints & DGS_ALG_NO_HUB_ROWS) return INT_MAX;
   if (hints & kHintForceHub) return kHubChain;
@@ -1394,7 +1493,7 @@ static int launch_impl(const SpmmArgs &a) {
       int4 *longrows = reinterpret_cast<int4 *>(w + L.off_long);
       float *part = reinterpret_cast<float *>(w + L.off_part);
       int *parte = reinterpret_cast<int *>(w + L.off_parte);
-      const UnitTab ut{&hdr->n_units, &hdr->n_long, nullptr, units, longrows};
+      UnitTab ut{&hdr->n_units, &hdr->n_long, nullptr, units, longrows};
       if (hipMemsetAsync(hdr, 0, sizeof(SpmmWs), a.st) != hipSuccess) return DGS_ELAUNCH;
       const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
       int tl = P.tlong > L.ch ? P.tlong : L.ch;  // every long row has >= 2 units => all go through combine
@@ -1402,8 +1501,13 @@ static int launch_impl(const SpmmArgs &a) {
       int thub = hub_ok<OP, V, G, ACC>() ? hub_threshold(a.hints) : INT_MAX;
       if (thub < tl) thub = tl;  // rows up to tl belong to the panel sweep (one sequential chain per row already)
       const HubTab ht = hub_tab(a.nnz, thub < INT_MAX ? thub : kHubChainMin, a.nnz / kT1 + 2);
+      const bool fold = fold_enabled(a.hints);
+      if (fold) {
+        ut.slot_long = reinterpret_cast<const int *>(w + L.off_slot);
+        ut.arrive = reinterpret_cast<int *>(w + L.off_arrive);
+      }
       hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, tl, thub, ht, a.rowptr, hdr,
-                         units, longrows);
+                         units, longrows, const_cast<int *>(ut.slot_long), ut.arrive, (int)a.tiles);
       auto kern = spmm_panel<G, OP, HAS_VAL>;
       static std::atomic<bool> attr_set[64];  // per instantiation and device: allow the large dynamic LDS (setting it twice is harmless)
       int dev_id = 0;
@@ -1425,10 +1529,12 @@ static int launch_impl(const SpmmArgs &a) {
       const int nbu = 1024;
       launch_fused<G, V, OP, HAS_VAL, ACC>(a, thub < INT_MAX ? hub_blocks(2 * cu_count()) : 0, nbu, 0, kRowsPerWave, ut, part, parte,
                                            HubArg{hdr->hub, units, ht, kHubClasses});
-      const int64_t cb = (L.max_long + 3) / 4;
-      const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
-      hipLaunchKernelGGL((spmm_combine<G, V, OP, ACC>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B,
-                         a.C, a.E, ut, part, parte, a.acc, 0);
+      if (!fold) {
+        const int64_t cb = (L.max_long + 3) / 4;
+        const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
+        hipLaunchKernelGGL((spmm_combine<G, V, OP, ACC>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B,
+                           a.C, a.E, ut, part, parte, a.acc, 0);
+      }
       return check_launch();
     }
   }
@@ -1463,7 +1569,7 @@ static int launch_impl(const SpmmArgs &a) {
     // cached plan: the unit tables already exist (hub rows cut at column-slice boundaries, sorted by slice and first
     // column, one slice per XCD), so the call is fused + combine; the workspace only holds the partial rows
     const char *pb = reinterpret_cast<const char *>(a.plan);
-    const WsLayout L = ws_layout_plan(a.reduce_op, a.N, a.plan_pslots);
+    const WsLayout L = ws_layout_plan(a.reduce_op, a.N, a.plan_pslots, a.plan_long);
     char *w = static_cast<char *>(a.ws);
     float *part = reinterpret_cast<float *>(w + L.off_part);
     int *parte = reinterpret_cast<int *>(w + L.off_parte);
@@ -1485,8 +1591,16 @@ static int launch_impl(const SpmmArgs &a) {
     HubArg ha{&ph->n_hub, reinterpret_cast<const int4 *>(hubp), ht, 1};
     const int nbh = use_hub ? hub_blocks((int64_t)a.plan_hub * strict_shub(G, V)) : 0;
     if (use_hub) ut.xcd_end = ph->xcd_hub;  // the hub rows' units (behind the others of each share) are not walked
+    // in-kernel fold: the slot -> long-row map is part of the plan (behind the hub table), the arrival counters are the one piece
+    // of the workspace a planned call has to zero (4 bytes per long row: 0.1 MB on the headline graph)
+    const bool fold = a.plan_long > 0 && fold_enabled(a.hints);
+    if (fold) {
+      ut.slot_long = reinterpret_cast<const int *>(pb + (a.plan_off_hub ? plan_off_slot((size_t)a.plan_off_hub, a.plan_hub) : PL.off_slot));
+      ut.arrive = reinterpret_cast<int *>(w + L.off_arrive);
+      if (hipMemsetAsync(ut.arrive, 0, (size_t)a.plan_long * a.tiles * sizeof(int), a.st) != hipSuccess) return DGS_ELAUNCH;
+    }
     launch_fused<G, V, OP, HAS_VAL, ACC>(a, nbh, nbu, nbr, rpw, ut, part, parte, ha);
-    if (a.plan_long > 0) {
+    if (a.plan_long > 0 && !fold) {
       const int64_t cb = ((int64_t)a.plan_long + 3) / 4;
       const dim3 g3((unsigned)(cb < 2048 ? cb : 2048), (unsigned)a.tiles);
       hipLaunchKernelGGL((spmm_combine<G, V, OP, ACC>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B,
@@ -1501,13 +1615,18 @@ static int launch_impl(const SpmmArgs &a) {
   int4 *longrows = reinterpret_cast<int4 *>(w + L.off_long);
   float *part = reinterpret_cast<float *>(w + L.off_part);
   int *parte = reinterpret_cast<int *>(w + L.off_parte);
-  const UnitTab ut{&hdr->n_units, &hdr->n_long, nullptr, units, longrows};
+  UnitTab ut{&hdr->n_units, &hdr->n_long, nullptr, units, longrows};
   if (hipMemsetAsync(hdr, 0, sizeof(SpmmWs), a.st) != hipSuccess) return DGS_ELAUNCH;
   const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
   const int thub = hub_ok<OP, V, G, ACC>() ? hub_threshold(a.hints) : INT_MAX;
   const HubTab ht = hub_tab(a.nnz, thub < INT_MAX ? thub : kHubChainMin, a.nnz / kT1 + 2);
+  const bool fold = fold_enabled(a.hints);  // (the classify pass fills the slot map and zeroes the counters of the rows it lists)
+  if (fold) {
+    ut.slot_long = reinterpret_cast<const int *>(w + L.off_slot);
+    ut.arrive = reinterpret_cast<int *>(w + L.off_arrive);
+  }
   hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, kT2, thub, ht, a.rowptr, hdr,
-                     units, longrows);
+                     units, longrows, const_cast<int *>(ut.slot_long), ut.arrive, (int)a.tiles);
   // unit / multi counts live on the device: a bounded number of persistent unit blocks stride over the table
   const int64_t ub = (L.max_units + 3) / 4;
   int nbu_cap = tune(tuning().nbu, DGS_NBU);
@@ -1517,11 +1636,13 @@ static int launch_impl(const SpmmArgs &a) {
   // they read six zeros and leave)
   launch_fused<G, V, OP, HAS_VAL, ACC>(a, thub < INT_MAX ? hub_blocks(2 * cu_count()) : 0, nbu, nbr, rpw, ut, part, parte,
                                        HubArg{hdr->hub, units, ht, kHubClasses});
-  // combine: one wave per multi-unit row
-  const int64_t cb = (L.max_long + 3) / 4;
-  const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
-  hipLaunchKernelGGL((spmm_combine<G, V, OP, ACC>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B, a.C,
-                     a.E, ut, part, parte, a.acc, 0);
+  // combine: one wave per multi-unit row (unless the unit waves fold the rows themselves)
+  if (!fold) {
+    const int64_t cb = (L.max_long + 3) / 4;
+    const dim3 g3((unsigned)(cb < 2048 ? (cb < 1 ? 1 : cb) : 2048), (unsigned)a.tiles);
+    hipLaunchKernelGGL((spmm_combine<G, V, OP, ACC>), g3, dim3(kBlock), 0, a.st, (int)a.N, a.rowptr, a.col, a.val, a.B, a.C,
+                       a.E, ut, part, parte, a.acc, 0);
+  }
   return check_launch();
 }
 

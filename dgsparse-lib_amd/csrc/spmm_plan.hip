@@ -257,7 +257,8 @@ __global__ __launch_bounds__(kBlock) void plan_emit(int ch, const int *__restric
                                                     const PlanWs *__restrict__ pw, const int *__restrict__ bounds,
                                                     const int *__restrict__ list, const int4 *__restrict__ info,
                                                     const int4 *__restrict__ scan, int4 *__restrict__ units,
-                                                    unsigned long long *__restrict__ keys, int4 *__restrict__ longrows) {
+                                                    unsigned long long *__restrict__ keys, int4 *__restrict__ longrows,
+                                                    int *__restrict__ slot_long) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = pw->n_longlist;
   for (int i = blockIdx.x * (kBlock / kWave) + wave; i < n; i += gridDim.x * (kBlock / kWave)) {
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(kBlock) void plan_emit(int ch, const int *__restric
         const unsigned long long slice = (unsigned long long)((2 * lane + q) >> j);
         for (int p0 = a; p0 < b; p0 += ch, k++) {
           units[sc.x + k] = make_int4(r, p0, min(ch, b - p0), nu > 1 ? sc.y + k : -1);
+          if (nu > 1) slot_long[sc.y + k] = sc.z;  // (in-kernel fold: the long row a partial slot belongs to)
           keys[sc.x + k] = (slice << 33) | (hub << 32) | (unsigned)col[p0];
         }
       }
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(kBlock) void plan_emit(int ch, const int *__restric
       for (int k = lane; k < nu; k += kWave) {
         const int p0 = rs + k * ch;
         units[sc.x + k] = make_int4(r, p0, min(ch, re - p0), nu > 1 ? sc.y + k : -1);
+        if (nu > 1) slot_long[sc.y + k] = sc.z;
         keys[sc.x + k] = ((unsigned long long)(hash32((unsigned)r * 31u + (unsigned)k) & 7u) << 33) | (hub << 32) | (unsigned)col[p0];
       }
     }
@@ -413,7 +416,7 @@ extern "C" int dgs_spmm_plan_build2(int64_t M, int64_t K, int64_t nnz, const int
     return DGS_ELAUNCH;
   hipLaunchKernelGGL(plan_totals, dim3(1), dim3(1), 0, st, pw, rinfo, rscan, hdr);
   hipLaunchKernelGGL(plan_emit, dim3(1024), dim3(kBlock), 0, st, ch, rowptr, col, pw, bounds, list, rinfo, rscan, units_in,
-                     keys_in, longrows);
+                     keys_in, longrows, reinterpret_cast<int *>(pb + PL.off_slot));
   tb = WL.tmp_bytes;
   if (rocprim::radix_sort_pairs(tmp, tb, keys_in, keys_out, units_in, units, (size_t)PL.max_units, 0, 37, st, false) !=
       hipSuccess)
@@ -497,14 +500,14 @@ extern "C" int dgs_spmm_plan_provisional_info(int64_t nnz, int64_t rows_gt_t1, i
 extern "C" size_t dgs_spmm_csr_plan_workspace_bytes(int reduce_op, int64_t M, int64_t N, int64_t nnz,
                                                     const dgsSpmmPlanInfo *info) {
   if (M <= 0 || N <= 0 || nnz <= 0 || !info) return 0;
-  return ws_layout_plan(reduce_op, N, info->n_pslots).total;
+  return ws_layout_plan(reduce_op, N, info->n_pslots, info->n_long).total;
 }
 
 extern "C" size_t dgs_spmm_plan_compact_bytes(const dgsSpmmPlanInfo *info) {
   if (!info) return 0;
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
   return 256 + 768 + up((size_t)info->n_units * sizeof(int4)) + up((size_t)info->n_long * sizeof(int4)) +
-         up((size_t)info->n_hub * sizeof(int4)) + 256;
+         up((size_t)info->n_hub * sizeof(int4)) + up((size_t)info->n_pslots * sizeof(int)) + 256;
 }
 
 extern "C" int dgs_spmm_plan_compact(const void *plan, dgsSpmmPlanInfo *info, void *compact, size_t compact_bytes,
@@ -519,11 +522,13 @@ extern "C" int dgs_spmm_plan_compact(const void *plan, dgsSpmmPlanInfo *info, vo
   const size_t ub = (size_t)info->n_units * sizeof(int4), lb = (size_t)info->n_long * sizeof(int4);
   const size_t hb = (size_t)info->n_hub * sizeof(int4);
   const size_t off_long = PL.off_units + up(ub), off_hub = off_long + up(lb);
-  if (off_hub + up(hb) > (size_t)INT32_MAX) return DGS_ERANGE;  // the offsets are 32-bit (2^27 units: beyond any int32 nnz / 64)
+  const size_t sb = (size_t)info->n_pslots * sizeof(int), off_slot = plan_off_slot(off_hub, info->n_hub);
+  if (off_slot + up(sb) > (size_t)INT32_MAX) return DGS_ERANGE;  // the offsets are 32-bit (2^27 units: beyond any int32 nnz / 64)
   if (hipMemcpyAsync(dst, src, PL.off_units + ub, hipMemcpyDeviceToDevice, st) != hipSuccess) return DGS_ELAUNCH;
   if (lb && hipMemcpyAsync(dst + off_long, src + PL.off_long, lb, hipMemcpyDeviceToDevice, st) != hipSuccess)
     return DGS_ELAUNCH;
   if (hb && hipMemcpyAsync(dst + off_hub, src + PL.off_hub, hb, hipMemcpyDeviceToDevice, st) != hipSuccess) return DGS_ELAUNCH;
+  if (sb && hipMemcpyAsync(dst + off_slot, src + PL.off_slot, sb, hipMemcpyDeviceToDevice, st) != hipSuccess) return DGS_ELAUNCH;
   info->off_long = (int32_t)off_long;
   info->off_hub = (int32_t)off_hub;
   return DGS_OK;

@@ -53,22 +53,28 @@ extern "C" int dgs_spmm_hub_threshold(void) {
   return t == INT_MAX ? 0 : t;
 }
 
-// ---- device self-test of the hub chains (include/dgsparse_hip.h "Device gate") -------------------------------------------------
-// Generated inputs (no host buffers: everything is a hash of the index), the default sum with the chains forced on, a reference
-// kernel that is beyond suspicion - one thread per (row, feature), one fmaf chain in CSR order - and an element-wise compare.
+// ---- device self-test of the hub chains and of the in-kernel fold (include/dgsparse_hip.h "Device gate") ----------------------
+// Generated inputs (no host buffers: everything is a hash of the index).  Hub pass: the default sum with the chains forced on
+// against a reference kernel that is beyond suspicion - one thread per (row, feature), one fmaf chain in CSR order.  Fold pass:
+// sum and max over a matrix with hundreds of multi-unit rows, folded inside the fused launch, against the SAME launches with
+// the combine kernel behind them (identical trees: identical bits, values and arg ids).
 namespace dgs {
 namespace selftest {
 struct Shape {
   int M, K, N;
-  int lens[4];  // lengths of rows 0 .. 3; every other row has `tail` nnz
-  int tail;
-  int nnz() const { return lens[0] + lens[1] + lens[2] + lens[3] + (M - 4) * tail; }
+  int lens[4];       // lengths of rows 0 .. 3
+  int nmid, midlen;  // rows 4 .. 4 + nmid - 1
+  int tail;          // every other row
+  int nnz() const { return lens[0] + lens[1] + lens[2] + lens[3] + nmid * midlen + (M - 4 - nmid) * tail; }
 };
 // general schedule (> 2^16 rows): two hub rows (one of them threshold + 1), a row of exactly the threshold and a mid row (tree)
-constexpr Shape kGeneral{66000, 8192, 64, {20000, kHubChain + 1, kHubChain, 5000}, 2};
+constexpr Shape kGeneral{66000, 8192, 64, {20000, kHubChain + 1, kHubChain, 5000}, 0, 0, 2};
 // single-launch schedule, 16-lane and 8-lane feature tiles
-constexpr Shape kSmall64{40, 8192, 64, {20000, 17000, 70, 3}, 3};
-constexpr Shape kSmall20{40, 8192, 20, {20000, 17000, 70, 3}, 3};
+constexpr Shape kSmall64{40, 8192, 64, {20000, 17000, 70, 3}, 0, 0, 3};
+constexpr Shape kSmall20{40, 8192, 20, {20000, 17000, 70, 3}, 0, 0, 3};
+// fold pass: 404 multi-unit rows (3 .. 59 units each) whose ~2 600 partial rows are written and folded by workgroups all over
+// the chip
+constexpr Shape kFold{66000, 8192, 64, {15000, 9000, 3000, 700}, 400, 1500, 2};
 __device__ __forceinline__ unsigned hash32(unsigned x) {
   x ^= x >> 16;
   x *= 0x7feb352du;
@@ -84,7 +90,8 @@ __global__ __launch_bounds__(kBlock) void gen(Shape sh, int nnz, int *__restrict
   if (i <= sh.M) {
     int p = 0;
     for (int r = 0; r < 4 && r < i; r++) p += sh.lens[r];
-    if (i > 4) p += ((int)i - 4) * sh.tail;
+    if (i > 4) p += (int)min((int64_t)sh.nmid, i - 4) * sh.midlen;
+    if (i > 4 + sh.nmid) p += ((int)i - 4 - sh.nmid) * sh.tail;
     rowptr[i] = p;
   }
   if (i < nnz) {
@@ -127,66 +134,109 @@ __global__ __launch_bounds__(kBlock) void compare(int M, int N, int thub, const 
                                              : (fabsf(c - ref) <= 1e-5f * fabsf(ref) + 1e-30f);
   if (!ok) atomicAdd(bad, 1);
 }
+__global__ __launch_bounds__(kBlock) void compare_bits(int64_t n, const unsigned *__restrict__ a, const unsigned *__restrict__ b,
+                                                       int *__restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n && a[i] != b[i]) atomicAdd(bad, 1);
+}
 struct Layout {
-  size_t rowptr, col, val, B, C, R, ws, ws_bytes, bad, total;
+  size_t rowptr, col, val, B, C, R, E1, E2, ws, ws_bytes, bad, total;
 };
-static Layout layout(const Shape &sh) {
+static Layout layout(const Shape &sh, bool with_arg) {
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
   Layout L;
   size_t o = 0;
-  L.bad = o;     o += 256;
+  L.bad = o;     o += 256;  // two counters: [0] hub pass, [1] fold pass
   L.rowptr = o;  o += up((size_t)(sh.M + 1) * 4);
   L.col = o;     o += up((size_t)sh.nnz() * 4);
   L.val = o;     o += up((size_t)sh.nnz() * 4);
   L.B = o;       o += up((size_t)sh.K * sh.N * 4);
   L.C = o;       o += up((size_t)sh.M * sh.N * 4);
   L.R = o;       o += up((size_t)sh.M * sh.N * 4);
+  L.E1 = o;      o += with_arg ? up((size_t)sh.M * sh.N * 4) : 0;
+  L.E2 = o;      o += with_arg ? up((size_t)sh.M * sh.N * 4) : 0;
   L.ws = o;
-  L.ws_bytes = dgs_spmm_csr_workspace_bytes(DGS_SUM, sh.M, sh.N, sh.nnz());
+  L.ws_bytes = dgs_spmm_csr_workspace_bytes(with_arg ? DGS_MAX : DGS_SUM, sh.M, sh.N, sh.nnz());
   L.total = o + up(L.ws_bytes);
   return L;
 }
-static int run_shape(const Shape &sh, char *base, hipStream_t st) {
-  const Layout L = layout(sh);
-  const int nnz = sh.nnz();
-  int *rowptr = reinterpret_cast<int *>(base + L.rowptr), *col = reinterpret_cast<int *>(base + L.col);
-  float *val = reinterpret_cast<float *>(base + L.val), *B = reinterpret_cast<float *>(base + L.B);
-  float *C = reinterpret_cast<float *>(base + L.C), *R = reinterpret_cast<float *>(base + L.R);
+static void generate(const Shape &sh, const Layout &L, char *base, hipStream_t st) {
   int64_t n = (int64_t)sh.K * sh.N;
-  if (n < nnz) n = nnz;
+  if (n < sh.nnz()) n = sh.nnz();
   if (n < sh.M + 1) n = sh.M + 1;
-  hipLaunchKernelGGL(gen, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sh, nnz, rowptr, col, val, B);
+  hipLaunchKernelGGL(gen, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sh, sh.nnz(),
+                     reinterpret_cast<int *>(base + L.rowptr), reinterpret_cast<int *>(base + L.col),
+                     reinterpret_cast<float *>(base + L.val), reinterpret_cast<float *>(base + L.B));
+}
+static int product(const Shape &sh, const Layout &L, char *base, int op, int hints, float *C, int *E, hipStream_t st) {
   if (hipMemsetAsync(C, 0xFF, (size_t)sh.M * sh.N * 4, st) != hipSuccess) return DGS_ELAUNCH;  // NaN: an unwritten element fails
+  if (E && hipMemsetAsync(E, 0x7F, (size_t)sh.M * sh.N * 4, st) != hipSuccess) return DGS_ELAUNCH;
   const FeatMap fm = feat_map(sh.N, true);
-  SpmmArgs a{sh.M, sh.K, sh.N, nnz, rowptr, col, val, B, C, nullptr, fm.tiles, L.ws_bytes ? base + L.ws : nullptr, st, DGS_SUM};
-  a.hints = kHintForceHub;
-  const int rc = run(fm, a);
+  SpmmArgs a{sh.M, sh.K, sh.N, sh.nnz(), reinterpret_cast<int *>(base + L.rowptr), reinterpret_cast<int *>(base + L.col),
+             reinterpret_cast<float *>(base + L.val), reinterpret_cast<float *>(base + L.B), C, E, fm.tiles,
+             L.ws_bytes ? base + L.ws : nullptr, st, op};
+  a.hints = hints;
+  return run(fm, a);
+}
+static int hub_shape(const Shape &sh, char *base, hipStream_t st) {
+  const Layout L = layout(sh, false);
+  float *C = reinterpret_cast<float *>(base + L.C), *R = reinterpret_cast<float *>(base + L.R);
+  generate(sh, L, base, st);
+  const int rc = product(sh, L, base, DGS_SUM, kHintForceHub | kHintNoFold, C, nullptr, st);
   if (rc != DGS_OK) return rc;
-  hipLaunchKernelGGL(reference, dim3((unsigned)sh.M), dim3(kWave), 0, st, sh.N, rowptr, col, val, B, R);
+  hipLaunchKernelGGL(reference, dim3((unsigned)sh.M), dim3(kWave), 0, st, sh.N, reinterpret_cast<int *>(base + L.rowptr),
+                     reinterpret_cast<int *>(base + L.col), reinterpret_cast<float *>(base + L.val),
+                     reinterpret_cast<float *>(base + L.B), R);
   hipLaunchKernelGGL(compare, dim3((unsigned)(((int64_t)sh.M * sh.N + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sh.M, sh.N,
-                     kHubChain, rowptr, C, R, reinterpret_cast<int *>(base + L.bad));
+                     kHubChain, reinterpret_cast<int *>(base + L.rowptr), C, R, reinterpret_cast<int *>(base + L.bad));
+  return check_launch();
+}
+static int fold_shape(const Shape &sh, char *base, hipStream_t st) {
+  const Layout L = layout(sh, true);
+  float *C = reinterpret_cast<float *>(base + L.C), *R = reinterpret_cast<float *>(base + L.R);
+  int *E1 = reinterpret_cast<int *>(base + L.E1), *E2 = reinterpret_cast<int *>(base + L.E2);
+  int *bad = reinterpret_cast<int *>(base + L.bad) + 1;
+  const int64_t n = (int64_t)sh.M * sh.N;
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+  generate(sh, L, base, st);
+  const int ops[2] = {DGS_SUM, DGS_MAX};
+  for (int op : ops) {
+    int *e1 = op == DGS_MAX ? E1 : nullptr, *e2 = op == DGS_MAX ? E2 : nullptr;
+    int rc = product(sh, L, base, op, kHintForceFold, C, e1, st);
+    if (rc == DGS_OK) rc = product(sh, L, base, op, kHintNoFold, R, e2, st);
+    if (rc != DGS_OK) return rc;
+    hipLaunchKernelGGL(compare_bits, grid, dim3(kBlock), 0, st, n, reinterpret_cast<unsigned *>(C), reinterpret_cast<unsigned *>(R), bad);
+    if (e1) hipLaunchKernelGGL(compare_bits, grid, dim3(kBlock), 0, st, n, reinterpret_cast<unsigned *>(e1), reinterpret_cast<unsigned *>(e2), bad);
+  }
   return check_launch();
 }
 }  // namespace selftest
 }  // namespace dgs
 
-extern "C" size_t dgs_spmm_hub_selftest_bytes(void) { return selftest::layout(selftest::kGeneral).total; }  // the largest shape
+extern "C" size_t dgs_spmm_hub_selftest_bytes(void) {
+  const size_t a = selftest::layout(selftest::kGeneral, false).total, b = selftest::layout(selftest::kFold, true).total;
+  return a > b ? a : b;
+}
 extern "C" int dgs_spmm_hub_gate(void) { return hub_gate(); }
+extern "C" int dgs_spmm_fold_gate(void) { return fold_gate(); }
 extern "C" int dgs_spmm_hub_selftest(void *scratch, size_t scratch_bytes, dgsStream_t stream) {
   if (!scratch || scratch_bytes < dgs_spmm_hub_selftest_bytes() || !is_aligned16(scratch)) return DGS_EWORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   char *base = static_cast<char *>(scratch);
-  if (hipMemsetAsync(base, 0, 256, st) != hipSuccess) return DGS_ELAUNCH;  // the mismatch counter
+  if (hipMemsetAsync(base, 0, 256, st) != hipSuccess) return DGS_ELAUNCH;  // the mismatch counters
   const selftest::Shape shapes[3] = {selftest::kGeneral, selftest::kSmall64, selftest::kSmall20};
   for (const selftest::Shape &sh : shapes) {
-    const int rc = selftest::run_shape(sh, base, st);  // (stream order: one shape's arrays are dead when the next one's are written)
+    const int rc = selftest::hub_shape(sh, base, st);  // (stream order: one shape's arrays are dead when the next one's are written)
     if (rc != DGS_OK) return rc;
   }
-  int bad = -1;
-  if (hipMemcpyAsync(&bad, base, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return DGS_ELAUNCH;
+  const int rc = selftest::fold_shape(selftest::kFold, base, st);
+  if (rc != DGS_OK) return rc;
+  int bad[2] = {-1, -1};
+  if (hipMemcpyAsync(bad, base, sizeof(bad), hipMemcpyDeviceToHost, st) != hipSuccess) return DGS_ELAUNCH;
   if (hipStreamSynchronize(st) != hipSuccess) return DGS_ELAUNCH;
-  hub_gate_set(bad == 0 ? 1 : -1);
-  return bad == 0 ? 1 : 0;
+  hub_gate_set(bad[0] == 0 ? 1 : -1);
+  fold_gate_set(bad[1] == 0 ? 1 : -1);
+  return bad[0] == 0 ? 1 : 0;
 }
 
 extern "C" int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz) {

@@ -38,6 +38,8 @@ _lib.dgs_spmm_hub_threshold.restype = _int
 _lib.dgs_spmm_hub_threshold.argtypes = []
 _lib.dgs_spmm_hub_gate.restype = _int
 _lib.dgs_spmm_hub_gate.argtypes = []
+_lib.dgs_spmm_fold_gate.restype = _int
+_lib.dgs_spmm_fold_gate.argtypes = []
 _lib.dgs_spmm_hub_selftest_bytes.restype = _sz
 _lib.dgs_spmm_hub_selftest_bytes.argtypes = []
 _lib.dgs_spmm_hub_selftest.restype = _int
@@ -127,7 +129,7 @@ _lib.dgs_spmm_min_merge_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp, ctypes.c
 _lib.dgs_scatter_add_rows_f32.restype = _int
 _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
-EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_reload_tuning', 'dgs_spmm_hub_threshold', 'dgs_spmm_hub_gate',
+EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_reload_tuning', 'dgs_spmm_hub_threshold', 'dgs_spmm_hub_gate', 'dgs_spmm_fold_gate',
            'dgs_spmm_hub_selftest_bytes', 'dgs_spmm_hub_selftest', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
            'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes', 'dgs_spmm_plan_build', 'dgs_spmm_plan_build2',
            'dgs_spmm_plan_compact_bytes', 'dgs_spmm_plan_compact', 'dgs_spmm_plan_info_from_header',
@@ -219,6 +221,10 @@ def ensure_hub_selftest(dev) -> None:
     if rc < 0:
         _selftested.discard(idx)
         _check(rc, 'spmm_hub_selftest')
+    if fold_gate() < 0:
+        import warnings
+        warnings.warn(f'dgsparse: the in-kernel fold self-test FAILED on cuda:{idx}: multi-unit rows are folded by a separate '
+                      'combine launch on this device (same results).  Please report this.', RuntimeWarning)
     if rc == 0:
         import warnings
         warnings.warn(f'dgsparse: the hub-chain self-test FAILED on cuda:{idx} ({torch.cuda.get_device_name(idx)}): sum / mean '
@@ -229,6 +235,12 @@ def ensure_hub_selftest(dev) -> None:
 def hub_gate() -> int:
     """1 / 0 / -1: the hub self-test passed / has not run / failed on the current device."""
     return int(_lib.dgs_spmm_hub_gate())
+
+
+def fold_gate() -> int:
+    """1 / 0 / -1: the self-test of the in-kernel fold (partial rows folded by the last-arriving unit wave instead of a combine
+    launch) passed / has not run / failed on the current device; DGS_FOLD=0 | 1 overrides."""
+    return int(_lib.dgs_spmm_fold_gate())
 
 
 def reload_tuning() -> None:

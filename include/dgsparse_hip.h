@@ -129,12 +129,22 @@ int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_
  * environment bypasses the gate both ways (n = 0: off, n > 0: on at that threshold, self-test or not).
  *   scratch: dgs_spmm_hub_selftest_bytes() bytes of device memory, 256-B aligned, contents undefined on entry and exit.
  * dgs_spmm_hub_gate(): 1 / 0 / -1 = passed / not run / failed on the current device.
+ *
+ * The same self-test has a second part with its own verdict (dgs_spmm_fold_gate(), same three values): the IN-KERNEL FOLD.  Rows
+ * that are cut into several units leave partial rows in the workspace; by default a combine launch behind the fused launch folds
+ * them.  With the fold on, the unit wave that completes a row (an arrival counter per row, zeroed per call) folds it inside
+ * the fused launch - one launch less per call, and the fold overlaps the rest of the launch.  The partial rows then cross from
+ * one workgroup to another - possibly on another XCD, behind another L2 - through agent-scope stores and loads ordered around
+ * the counter's atomic: the self-test runs sum and max over a generated matrix with ~400 multi-unit rows both ways and demands
+ * identical bits (values and arg ids).  DGS_FOLD=0 | 1 in the environment overrides the gate.  Same results either way: the
+ * fold order is the fixed unit order in both.
  * No reference counterpart (the reference has one kernel per algorithm id and no self-checks).
  */
 int dgs_spmm_hub_threshold(void);
 size_t dgs_spmm_hub_selftest_bytes(void);
 int dgs_spmm_hub_selftest(void *scratch, size_t scratch_bytes, dgsStream_t stream);
 int dgs_spmm_hub_gate(void);
+int dgs_spmm_fold_gate(void);
 
 /*
  * Cached locality plan of the row-stream schedule (new; the reference keeps no per-matrix state - the closest thing is

@@ -180,6 +180,7 @@ static inline T emu_readfirstlane(T v) {
 #define __builtin_amdgcn_s_barrier() ::emu::block_sync()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)  // (every access completes at once here)
 #define __builtin_amdgcn_s_sleep(x) ::emu::relax()  // the yield point of a spin-wait
 
 // atomics: one fiber runs at a time, so plain read-modify-write is atomic

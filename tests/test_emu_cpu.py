@@ -368,3 +368,68 @@ def test_hub_chains_are_gated_on_the_device_self_test():
     assert p.returncode == 0, p.stderr[-2000:]
     out = dict(line.split(' ', 1) for line in p.stdout.strip().splitlines())
     assert out == {'before': '0 0', 'forced': '2048', 'off': '0', 'small_scratch': '-2', 'selftest': '1', 'after': '1 16384'}, p.stdout
+
+
+FOLD_CASE = r'''
+import sys, os, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests')); sys.path.insert(0, %(here)r)
+import emu_lib as E, oracle
+rng = np.random.default_rng(11)
+M, K = 66000, 5000
+deg = rng.integers(0, 3, M)
+for r, d in ((100, 3000), (7000, 1500), (65000, 1100), (50000, 1025), (300, 200), (301, 70), (40000, 600), (12, 1024), (13, 65), (9, 4500)):
+    deg[r] = d
+deg[2000:2200] = 700  # many multi-unit rows: their units meet on the arrival counters from all over the grid
+rp = np.zeros(M + 1, np.int32); rp[1:] = np.cumsum(deg)
+col = np.concatenate([np.sort(rng.choice(K, d, replace=False)) for d in deg]).astype(np.int32)
+val = (rng.random(col.size, dtype=np.float32) - 0.3).astype(np.float32)
+bad = 0
+for N, ops in ((64, (E.SUM, E.MEAN, E.MAX, E.MIN)), (256, (E.SUM, E.MAX)), (7, (E.SUM, E.MIN))):
+    X = rng.random((K, N), dtype=np.float32)
+    for op in ops:
+        out = {}
+        for fold in (0, 1):
+            E.set_env(DGS_FOLD=fold, DGS_HUB_CHAIN=2048, DGS_NBU=16)
+            plan = E.spmm_plan(rp, col, K)
+            res = []
+            for kw in ({}, dict(plan=plan)):
+                E.launch_log()
+                C, Eo = E.spmm(op, rp, col, val, X, **kw)
+                names = [n.split('<')[0].strip('( ') for n, _, _ in E.launch_log()]
+                if fold:
+                    assert 'spmm_combine' not in names and names.count('spmm_fused') == 1, names
+                    if kw: assert names == ['spmm_fused'], names  # a planned call is ONE kernel launch
+                else:
+                    assert 'spmm_combine' in names, names
+                res.append((C, Eo))
+            out[fold] = res
+        for (C0, E0), (C1, E1) in zip(out[0], out[1]):
+            bad += int((C0.view(np.int32) != C1.view(np.int32)).sum())
+            if E0 is not None: bad += int((E0 != E1).sum())
+        ref, Er = oracle.spmm({E.SUM: 'sum', E.MEAN: 'mean', E.MAX: 'max', E.MIN: 'min'}[op], rp, col, val, X, fma=True)
+        C1, E1 = out[1][1]
+        if op in (E.MAX, E.MIN):
+            bad += int((C1.view(np.int32) != ref.view(np.int32)).sum()) + int((E1 != Er).sum())
+        else:
+            bad += int(np.isnan(C1).sum())
+print('BAD', bad)
+'''
+
+
+@pytest.mark.parametrize('blocks,order', [('1', 'fwd'), ('40', 'rand:1'), ('40', 'rev')])
+def test_in_kernel_fold_equals_the_combine_launch(blocks, order):
+    """VERDICT r3 #4 / r4 #5: the partial rows of multi-unit rows are folded by the unit wave that completes the row (arrival
+    counter per row and feature tile) inside the fused launch instead of by a combine launch behind it - a planned call is ONE
+    kernel launch.  The fold order is the fixed unit order either way, so fold on == fold off bit for bit: sum / mean / max / min
+    (values and arg ids), plan-free and planned, one and several feature tiles, scalar lanes, signed data.  With resident
+    workgroups taking turns in random / reverse dispatch order (DGS_EMU_BLOCKS / DGS_EMU_BLOCK_ORDER, read once per process:
+    hence the subprocess) the LAST arriver is a different unit every time - the result must not care who folds."""
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    E.lib()  # built
+    env = {k: v for k, v in os.environ.items() if not k.startswith('DGS_')}
+    env.update(DGS_EMU_BLOCKS=blocks, DGS_EMU_BLOCK_ORDER=order)
+    p = subprocess.run([sys.executable, '-c', FOLD_CASE % dict(root=root, here=here)], capture_output=True, text=True, env=env,
+                       timeout=2400)
+    assert p.returncode == 0 and 'BAD 0' in p.stdout, (p.stdout[-500:], p.stderr[-2500:])

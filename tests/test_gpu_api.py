@@ -658,6 +658,7 @@ def test_hub_self_test_passes_on_this_device_and_gates_the_default(monkeypatch):
     monkeypatch.delenv('DGS_HUB_CHAIN', raising=False)
     _capi.ensure_hub_selftest(torch.device('cuda', torch.cuda.current_device()))
     assert _capi.hub_gate() == 1, 'the hub-chain self-test FAILED on this device'
+    assert _capi.fold_gate() == 1, 'the in-kernel fold self-test FAILED on this device'
     assert _capi.hub_threshold() == 16384
     monkeypatch.setenv('DGS_HUB_CHAIN', '0')
     assert _capi.hub_threshold() == 0

@@ -432,3 +432,38 @@ def test_plan_build_with_the_csc_prefix_equals_the_counted_one(capi):
     # and the Storage path uses it: plan built through Storage == counted plan's counts
     pb, pinfo = A.storage.spmm_plan('csr', N, wait=True)
     assert (int(pinfo[0]), int(pinfo[1]), int(pinfo[2])) == (ci.n_units, ci.n_long, ci.n_pslots)
+
+
+@pytest.mark.parametrize('N', [64, 256, 33])
+def test_in_kernel_fold_equals_the_combine_launch(capi, N, monkeypatch):
+    """Round 5: multi-unit rows are folded by the unit wave that completes them - arrival counter per
+    row and feature tile, partial rows handed over with agent-scope stores / loads - inside the fused launch; a planned call is
+    one kernel launch.  The fold order is the fixed unit order with or without it: DGS_FOLD=1 == DGS_FOLD=0 bit for bit, every
+    reduce, plan-free and planned, repeated calls (a stale counter or a stale partial row would show as a wrong or unwritten
+    row); and the device self-test (which gates the default) has passed here."""
+    assert capi.fold_gate() == 1, 'the in-kernel fold self-test FAILED on this device'
+    rp, col, st = graphgen.powerlaw_csr(300000, 3000000, alpha=2.0, dmax=20000, seed=31)
+    val = graphgen.weights(col.shape[0], 'signed', 3)
+    X = graphgen.features(st['K'], N, 4)
+    d = 'cuda'
+    drp, dcol, dval, dX = (torch.from_numpy(a).to(d) for a in (rp, col, val, X))
+    res = {}
+    for fold in ('0', '1'):
+        monkeypatch.setenv('DGS_FOLD', fold)
+        plan = capi.spmm_plan(drp, dcol, st['K'], N, force=True)
+        out = []
+        for op in (capi.SUM, capi.MEAN, capi.MAX, capi.MIN):
+            for kw in ({}, dict(plan=plan)):
+                for it in range(3):
+                    C, E = capi.spmm(op, drp, dcol, dval, dX, **kw)
+                    torch.cuda.synchronize()
+                    assert not torch.isnan(C).any()
+                    out.append((C.clone(), None if E is None else E.clone()))
+        res[fold] = out
+    for (C0, E0), (C1, E1) in zip(res['0'], res['1']):
+        assert torch.equal(C0, C1)
+        assert E0 is None or torch.equal(E0, E1)
+    Cm, Em = res['1'][-1]
+    rx, ex = oracle.spmm('min', rp, col, val, X, threads=oracle.max_threads())
+    assert_bitexact(Cm.cpu().numpy(), rx, 'min over the plan, folded in the kernel')
+    assert_bitexact(Em.cpu().numpy(), ex, 'min arg ids')
