@@ -348,6 +348,10 @@ def main():
                 worst = self_check(C)
             assert worst < 1e-5, f'bench self-check failed: rel err {worst} (in units of the bar: 1e-5, 4e-5 on chained rows)'
             extra['self_check_max_rel_err_vs_fp64'] = worst
+            extra['self_check_bar'] = ('value above is in units of the bar per row: rel. error vs an fp64 gather-sum / 1.0 for rows the '
+                                       'schedule folds with a tree (bar 1e-5), / 4.0 for rows it CHAINS sequentially (hub rows, strict '
+                                       'runs: bar 4e-5 vs fp64, because the reference\'s own chain is ~1.2e-5 from fp64 at 50 k nnz); '
+                                       'pass = < 1e-5.  The contract check is `parity` (every element vs the sequential reference)')
         if a.reduce == 'sum' and not a.no_cpu_baseline:
             C_check = C.cpu().numpy()
         del C
@@ -489,6 +493,25 @@ def main():
             del rp2, col2, val2, X2, st2p, C2
         prot['seeds'] = seeds
         res['protocol'] = prot
+        if planned:
+            # the in-kernel fold of partial rows (round 5; on where the device self-test passed) next to the combine launch it
+            # replaces, on the same tensors: DGS_FOLD = 1 / 0 for one measurement each, then back to the process's own setting
+            had = os.environ.get('DGS_FOLD')
+            fd = dict(gate=_capi.fold_gate(), default_on=bool((had not in (None, '')) and had != '0') if had not in (None, '') else _capi.fold_gate() > 0)
+            for name, v in (('on_ms', '1'), ('off_ms', '0')):
+                os.environ['DGS_FOLD'] = v
+                _capi.reload_tuning()
+                stepf, _ = make_step(rp, col, val, X)
+                stepf()
+                fd[name] = round(sorted(event_ms(stepf, max(10, a.steps // 5)) for _ in range(3))[1], 5)
+                del stepf
+            if had is None:
+                os.environ.pop('DGS_FOLD')
+            else:
+                os.environ['DGS_FOLD'] = had
+            _capi.reload_tuning()
+            fd['note'] = 'fold on: one kernel launch per planned call (+ a memset of 4 B per long row); off: fused + combine'
+            res['fold'] = fd
         if '+hub' in res.get('schedule', ''):
             # what the hub chains cost next to the tree on the same tensors (the decision rule needs both numbers
             # in every line): DGS_HUB_CHAIN=0 for one measurement, then back to what this process was started with

@@ -55,7 +55,7 @@ def run_driver(mtx, N):
         if m:
             key = m.group(1).replace('SpMM-', '').replace(', ', '_').replace(' ', '_')
             res[key] = dict(check=m.group(2), ms=float(m.group(3)), gflops=float(m.group(4)) if m.group(4) else None)
-        elif line.startswith('plan:') or line.startswith('matrix '):
+        elif line.startswith(('plan:', 'matrix ', 'hub-chain self-test', 'longest row')):
             res.setdefault('notes', []).append(line.strip())
     if out.returncode:
         res['stderr'] = out.stderr[-400:]
@@ -86,7 +86,7 @@ def hipsparse_ms(rowptr, col, shape, N):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r04_mtx'))
+    ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r05_mtx'))
     ap.add_argument('--feats', default='32,64,128')
     a = ap.parse_args()
     feats = [int(x) for x in a.feats.split(',')]

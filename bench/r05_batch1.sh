@@ -1,35 +1,41 @@
 #!/bin/bash
-# round 5, GPU batch 1: first hardware contact of the round-4 hub-chain default, in the order asked:
-# hub smoke (stop on hang) -> all -m gpu tests (slice_by_slice last) -> bench line -> kernel stats + PMC, hub chains on / off.
+# round 5, GPU batch 1: first hardware contact of the round-4 hub-chain default and of round 5's gates / in-kernel fold, in the
+# order VERDICT r4 #1 asks for: device self-test + hub smoke (stop on hang) -> all -m gpu tests -> bench line -> kernel stats +
+# PMC with the hub chains on / off and the fold on / off -> the reference's mtx benchmark on HEAD.
 set -x
 cd "$(dirname "$0")/.."
 O=gpurun_out/r05b1
 mkdir -p $O
 export TMPDIR=/tmp PYTHONPATH=$PWD:$PWD/dgsparse-lib_amd
+timeout 300 python -c "
+import torch
+from dgsparse import _capi
+_capi.ensure_hub_selftest(torch.device('cuda', 0))
+print('hub gate', _capi.hub_gate(), 'fold gate', _capi.fold_gate(), 'threshold', _capi.hub_threshold())
+" > $O/selftest.txt 2>&1; echo "selftest rc=$?" >> $O/selftest.txt
+cat $O/selftest.txt
+if grep -q "rc=124" $O/selftest.txt; then echo "self-test hung: stopping"; exit 1; fi
 timeout 300 python bench/hub_smoke.py > $O/hub_smoke.txt 2>&1; echo "hub_smoke rc=$?" >> $O/hub_smoke.txt
 tail -n 30 $O/hub_smoke.txt
 if grep -q "rc=124" $O/hub_smoke.txt; then echo "hub smoke hung: stopping"; exit 1; fi
-timeout 1500 python -m pytest tests -q -m gpu -k "not slice_by_slice" > $O/pytest_all.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_all.txt
+timeout 1800 python -m pytest tests -q -m gpu > $O/pytest_all.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_all.txt
 tail -n 25 $O/pytest_all.txt
 timeout 900 python bench.py --sweep > $O/bench_line.json 2> $O/bench_err.txt; echo "bench rc=$?"
 timeout 600 python bench.py --steps 20 --warmup 5 --no-dense > $O/bench_line_steps20_warmup5.json 2>/dev/null
-DGS_HUB_CHAIN=0 timeout 600 python bench.py --no-dense > $O/bench_line_nohub.json 2>/dev/null
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_bench -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-dense --no-protocol > /dev/null 2>&1
-cp $(ls $O/kstats_bench/*/*kernel_stats.csv | head -1) $O/kernel_stats_bench_feat64_sum_plan_hub.csv; rm -rf $O/kstats_bench
-DGS_HUB_CHAIN=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_nohub -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-dense --no-protocol > /dev/null 2>&1
-cp $(ls $O/kstats_nohub/*/*kernel_stats.csv | head -1) $O/kernel_stats_bench_feat64_sum_plan_nohub.csv; rm -rf $O/kstats_nohub
-timeout 400 bash bench/prof_pmc.sh $O/pmc_plan_hub --no-dense --no-protocol > /dev/null 2>&1
-DGS_HUB_CHAIN=0 timeout 400 bash bench/prof_pmc.sh $O/pmc_plan_nohub --no-dense --no-protocol > /dev/null 2>&1
+DGS_HUB_CHAIN=0 timeout 600 python bench.py --no-dense --no-protocol > $O/bench_line_nohub.json 2>/dev/null
+DGS_FOLD=0 timeout 600 python bench.py --no-dense --no-protocol > $O/bench_line_nofold.json 2>/dev/null
+for cfg in "hub_fold:" "hub_nofold:DGS_FOLD=0" "nohub_fold:DGS_HUB_CHAIN=0" "nohub_nofold:DGS_HUB_CHAIN=0 DGS_FOLD=0"; do
+  tag=${cfg%%:*}; envs=${cfg#*:}
+  env $envs timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$tag -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-dense --no-protocol > /dev/null 2>&1
+  cp $(ls $O/ks_$tag/*/*kernel_stats.csv | head -1) $O/kernel_stats_bench_feat64_sum_plan_$tag.csv; rm -rf $O/ks_$tag
+done
+timeout 400 bash bench/prof_pmc.sh $O/pmc_plan_hub_fold --no-dense --no-protocol > /dev/null 2>&1
+DGS_HUB_CHAIN=0 DGS_FOLD=0 timeout 400 bash bench/prof_pmc.sh $O/pmc_plan_nohub_nofold --no-dense --no-protocol > /dev/null 2>&1
+DGS_FOLD=0 timeout 400 bash bench/prof_pmc.sh $O/pmc_plan_hub_nofold --no-dense --no-protocol > /dev/null 2>&1
 timeout 600 python bench/strict_parts.py 64 > $O/strict_parts.txt 2>&1
 timeout 600 python bench/strict_time.py > $O/strict_time.txt 2>&1
-# the experimental DGS_HUB_XCD modes wait across workgroups: after everything that matters
-timeout 300 python -m pytest tests/test_gpu_strict.py -x -q -m gpu -k "slice_by_slice" > $O/pytest_hub_xcd.txt 2>&1; echo "hub_xcd rc=$?" >> $O/pytest_hub_xcd.txt
-tail -n 5 $O/pytest_hub_xcd.txt
-if ! grep -q "rc=124" $O/pytest_hub_xcd.txt; then
-  timeout 900 python bench/nocut_probe.py 64 > $O/nocut_probe.txt 2>&1
-  DGS_HUB_XCD=1 timeout 600 python bench.py --no-dense --no-cpu-baseline > $O/bench_line_hub_xcd1.json 2> $O/bench_err_hub_xcd1.txt
-  DGS_HUB_XCD=2 timeout 600 python bench.py --no-dense --no-cpu-baseline > $O/bench_line_hub_xcd2.json 2> $O/bench_err_hub_xcd2.txt
-fi
+timeout 900 python bench/nocut_probe.py 64 > $O/nocut_probe.txt 2>&1
+make -C examples > /dev/null 2>&1
 timeout 900 python bench/mtx_bench.py --out $O/r05_mtx > $O/mtx_bench.txt 2>&1
 timeout 300 python bench/bench_configs.py > $O/configs.jsonl 2>/dev/null
 ls -la $O
