@@ -44,6 +44,8 @@ def main():
     del key
     X = rng.random((K, N), dtype=np.float32)
     nthr = oracle.max_threads()
+    E.set_env(DGS_PANEL=0)  # (368 nnz per row would take the column-panel sweep; this probe is about the row-stream schedule's tree)
+    assert E.schedule(E.SUM, M, K, N, nnz) == 'rows'
     out = dict(matrix=f'{M} rows, {nnz} nnz: {per} rows each of exactly {classes} nnz, the rest 0 .. 3; {K} columns (uniform, sorted), feat {N}',
                hub_threshold=int(E.lib().dgs_spmm_hub_threshold()), emulation='tests/emu, 256 CUs', cases={})
     for vname in ('uniform U[0,1)', 'tied {0,.1,.2}'):

@@ -57,8 +57,11 @@ def one_case(rng, it):
     val = graphgen.weights(col.shape[0], kind, it) if kind else None
     X = (rng.integers(-3, 4, (K, N)) / 8).astype(np.float32)
     hubth = int(rng.choice([0, 1024, 1024, 2048, 16384]))
-    E.set_env(DGS_HUB_CHAIN=hubth, DGS_NBU=int(rng.choice([8, 16, 64])), DGS_STRICT_NBU=int(rng.choice([8, 16, 64])))
-    tag = f'it={it} M={M} K={K} N={N} nnz={col.shape[0]} maxdeg={st["max_deg"]} val={kind} hub={hubth}'
+    fold = int(rng.integers(0, 2))  # round 5: partial rows folded inside the fused launch (last-arriving unit wave) / by the combine launch
+    E.set_env(DGS_HUB_CHAIN=hubth, DGS_NBU=int(rng.choice([8, 16, 64])), DGS_STRICT_NBU=int(rng.choice([8, 16, 64])), DGS_FOLD=fold)
+    # round 5: callers that know the longest row say so (DGS_ALG_NO_HUB_ROWS) - the kernels without the hub role, same results
+    hint = E.ALG_NO_HUB_ROWS if (hubth > 0 and int(np.diff(rp).max(initial=0)) <= max(hubth, 1024) and rng.integers(0, 2)) else 0
+    tag = f'it={it} M={M} K={K} N={N} nnz={col.shape[0]} maxdeg={st["max_deg"]} val={kind} hub={hubth} fold={fold} hint={hint:#x}'
     if os.environ.get('FUZZ_VERBOSE'):
         print('case', tag, flush=True)
     if os.environ.get('FUZZ_DUMP'):  # the inputs of the case that is about to run (to replay a hang or a crash outside the campaign)
@@ -72,7 +75,7 @@ def one_case(rng, it):
     for reduce in ('sum', 'mean', 'max', 'min'):
         Co, Eo = oracle.spmm(reduce, rp, col, val, X, fma=True)
         for kw in ([{}] + ([dict(plan=plan)] if plan is not None else [])):
-            C, Ee = E.spmm(OPS[reduce], rp, col, val, X, **kw)
+            C, Ee = E.spmm(OPS[reduce], rp, col, val, X, **(kw if kw else dict(algorithm=hint)))
             what = f'{tag} {reduce} {"plan" if kw else "plan-free"}'
             if reduce in ('max', 'min'):
                 assert_bitexact(C, Co, what)

@@ -233,3 +233,33 @@ def test_hub_work_deal_covers_every_task_once(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip() == 'ok', r.stdout + r.stderr
+
+
+def test_counter_based_sampler_matches_its_definition():
+    """bench/graphgen.py hash_bits is splitmix64 of (seed, stream, index) written with integer tensor ops, so that the GPU and the
+    CPU build the SAME graphs / values / features (bench.py, bench/emu_parity.py, tests/test_gpu_fullsize.py rely on it): check
+    the words against plain Python integers, the unit floats against their definition, and a small graph against itself."""
+    from bench import graphgen
+
+    def sm(i, seed, stream):
+        m = (1 << 64) - 1
+        z = (i + ((seed * 0xD1B54A32D192ED03 + stream * 0x8CB92BA72F3D8DD7 + 0x9E3779B97F4A7C15) & m)) & m
+        z = (z * 0x9E3779B97F4A7C15) & m
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+        z ^= z >> 31
+        return z - (1 << 64) if z >= (1 << 63) else z
+
+    for seed, stream, start in ((0, 1, 0), (3, 102, 12345), (4, 2, (1 << 33) + 7)):
+        got = graphgen.hash_bits(6, seed, stream, start=start).tolist()
+        assert got == [sm(start + i, seed, stream) for i in range(6)]
+    u = graphgen.hash_unit(4, 1, 5).tolist()
+    assert u == [((sm(i, 1, 5) % (1 << 64)) >> 11) / float(1 << 53) for i in range(4)]
+    v = graphgen.values_t(4, 2).tolist()
+    assert v == [((sm(i, 2, 101) % (1 << 64)) >> 40) / float(1 << 24) for i in range(4)]
+    a = graphgen.powerlaw_csr(5000, 60000, alpha=2.0, dmax=700, seed=5, sampler='hash')
+    b = graphgen.powerlaw_csr(5000, 60000, alpha=2.0, dmax=700, seed=5, sampler='hash')
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[2]['nnz'] > 55000
+    for cols in ('uniform', 'local'):
+        rp, col, st = graphgen.powerlaw_csr(3000, 30000, alpha=2.2, dmax=300, cols=cols, seed=1, sampler='hash')
+        assert 0 <= col.min() and col.max() < 3000 and rp[-1] == col.shape[0]
