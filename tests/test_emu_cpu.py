@@ -416,7 +416,7 @@ print('BAD', bad)
 '''
 
 
-@pytest.mark.parametrize('blocks,order', [('1', 'fwd'), ('40', 'rand:1'), ('40', 'rev')])
+@pytest.mark.parametrize('blocks,order', [('1', 'fwd'), ('40', 'rand:1')] + ([('40', 'rev'), ('64', 'rand:5')] if os.environ.get('DGS_TEST_LONG') else []))
 def test_in_kernel_fold_equals_the_combine_launch(blocks, order):
     """the partial rows of multi-unit rows are folded by the unit wave that completes the row (arrival
     counter per row and feature tile) inside the fused launch instead of by a combine launch behind it - a planned call is ONE
