@@ -115,6 +115,11 @@ int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_
  * The threshold is DGS_HUB_CHAIN (default 16384, clamped to >= 1024, 0 = no hub chains: every row above 64 nnz takes the
  * tree); the chain's own rounding error grows like sqrt(nnz) and passes 1e-5 of the exact sum beyond ~3 10^4 nnz, which is
  * where a tree - however accurate - stops being within 1e-5 of the REFERENCE.  DGS_ALG_STRICT_SUM / _NOFMA chain every row.
+ * "Within 1e-5 of the chain" is a statement about CONTINUOUS data (the reference's tests: U[0,1) features; measured with thousands of
+ * rows at the threshold: max 6.9e-6).  Operands drawn from a handful of values (the reference's example drivers fill both with
+ * {0, .1, .2}) give the chain itself a systematic rounding bias - 1.1e-5 of the exact sum at 2 048 nnz, 2.7e-5 at 16 384, on every
+ * element of a row - which no accurate summation shares: callers that need the reference's bits on such data use the strict bits
+ * (or DGS_HUB_CHAIN=1024).  DESIGN.md 4.1g, profiles/r05_chain_error_by_value_law.txt.
  * dgs_spmm_hub_threshold() returns the threshold in force on the current device (0 = off).
  *
  * Device gate.  The hub workgroup keeps two register sets of gathers in flight across workgroup barriers while one wave chains
