@@ -442,6 +442,9 @@ def main():
                      'alg_bytes_per_launch': int(b_alg), 'kernel_us': round(kern_s * 1e6, 2)},
     }
     res.update(extra)
+    res['device_gate'] = dict(hub_chains=_capi.hub_gate(), in_kernel_fold=_capi.fold_gate(), hub_threshold=_capi.hub_threshold(),
+                              note='1 = dgs_spmm_hub_selftest passed on this device (the feature is on by default), -1 = failed (off), '
+                                   '0 = not run; DGS_HUB_CHAIN / DGS_FOLD override')
     # roofline.traffic is NOT measured by this process (PMC passes cannot run beside the timed region): it is the
     # figure of the committed rocprofv3 counter passes for this very configuration, with its provenance next to it
     tf = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
