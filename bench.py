@@ -290,10 +290,10 @@ def main():
         """One SpMM through the C ABI; with a plan (Storage-cached locality plan, built once outside the timed region)
         when the library offers one for this shape."""
         plan = None
-        if strict_alg:
-            return (lambda: _capi.spmm(op, rp_, col_, val_, X_, algorithm=strict_alg)), False
         if a.plan != 0 and hasattr(_capi, 'spmm_plan'):
             plan = _capi.spmm_plan(rp_, col_, X_.shape[0], N, force=(a.plan == 1))
+        if strict_alg:  # (over the plan's strict table when there is a plan: one launch, no classify pass)
+            return (lambda: _capi.spmm(op, rp_, col_, val_, X_, algorithm=strict_alg, plan=plan)), plan is not None
         if plan is not None:
             return (lambda: _capi.spmm(op, rp_, col_, val_, X_, plan=plan)), True
         return (lambda: _capi.spmm(op, rp_, col_, val_, X_)), False
@@ -552,8 +552,9 @@ def main():
         # the strict-order schedule on the same tensors (opt-in `algorithm` bits): time + full parity in cpu_baseline
         if a.reduce in ('sum', 'mean'):
             sd = {}
+            plan_s = _capi.spmm_plan(rp, col, K, N, force=(a.plan == 1)) if planned else None
             for mode, alg in (('fma', _capi.ALG_STRICT_SUM), ('nofma', _capi.ALG_STRICT_NOFMA)):
-                fn = (lambda alg=alg: _capi.spmm(op, rp, col, val, X, algorithm=alg))
+                fn = (lambda alg=alg: _capi.spmm(op, rp, col, val, X, algorithm=alg, plan=plan_s))
                 Cs, _ = fn()
                 if a.reduce == 'sum' and not a.no_cpu_baseline:
                     C_strict[mode] = Cs.cpu().numpy()
@@ -562,6 +563,7 @@ def main():
                 sd[mode] = dict(ms_per_step=round(ms_s, 5), gflops=round(flops / (ms_s / 1e3) / 1e9, 1),
                                 frac=round(b_alg / (ms_s / 1e3) / 1e9 / HBM_PEAK_GBS, 4))
             sd['algorithm_bits'] = dict(fma=hex(_capi.ALG_STRICT_SUM), nofma=hex(_capi.ALG_STRICT_NOFMA))
+            sd['over_the_plan'] = plan_s is not None
             res['strict'] = sd
         # the PUBLIC operator on the same graph (reference harness times this: benchmark/bench_spmm_time.py:35-45)
         try:

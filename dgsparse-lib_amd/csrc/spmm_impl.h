@@ -183,9 +183,16 @@ constexpr int kPlanCells = 128;       // finest column grid: 8 slices (one per X
 constexpr int kHubChain = 16384;    // default hub threshold of the sum / mean launches (DGS_HUB_CHAIN; 0 = no hub chains)
 constexpr int kHubChainMin = 1024;  // smallest threshold accepted (bounds the hub tables: nnz / 1024 rows)
 struct PlanLayout {
-  int64_t max_units, max_long, max_hub;
-  size_t off_bounds, off_units, off_long, off_hub, off_slot, total;
+  int64_t max_units, max_long, max_hub, max_srows;
+  size_t off_bounds, off_units, off_long, off_hub, off_slot, off_strict, total;
 };
+// The strict-order schedule over a plan (round 5): every row longer than T1 as {row, first nnz, nnz, -}, sorted LONGEST FIRST,
+// behind a 32-byte header with the sizes of its three length classes - what spmm_classify_strict builds per call otherwise.
+struct StrictPlanHdr {
+  int n_hub, n_mid, n_whole;  // rows > kStrictHub (one dense table, chained by hub workgroups), > kStrictMid (4 feature slices), the rest
+  int pad[5];
+};
+static inline size_t plan_off_strict(size_t off_slot, int64_t n_pslots) { return off_slot + (((size_t)n_pslots * sizeof(int) + 255) & ~size_t(255)); }
 // where the slot -> long-row map sits: behind the hub table (build-time layout: capacities; compact plan: counts)
 static inline size_t plan_off_slot(size_t off_hub, int64_t n_hub) { return off_hub + (((size_t)n_hub * sizeof(int4) + 255) & ~size_t(255)); }
 static inline PlanLayout plan_layout(int64_t nnz) {
@@ -202,7 +209,9 @@ static inline PlanLayout plan_layout(int64_t nnz) {
   // hub region: max_hub entries {row, first nnz, nnz, -}  (a compact plan: n_hub entries); then one int per partial slot: the
   // index of the slot's row in the long-row table (what the in-kernel fold needs to find the row's arrival counter)
   L.off_slot = plan_off_slot(L.off_hub, L.max_hub);
-  L.total = L.off_slot + up((size_t)L.max_units * sizeof(int)) + 256;
+  L.max_srows = nnz / kT1 + 2;  // rows longer than T1
+  L.off_strict = plan_off_strict(L.off_slot, L.max_units);
+  L.total = L.off_strict + up(sizeof(StrictPlanHdr) + (size_t)L.max_srows * sizeof(int4)) + 256;
   return L;
 }
 
@@ -1252,14 +1261,15 @@ __global__ __launch_bounds__(kBlock, 4) void spmm_fused_strict(int M, int N, int
                                                                const int *__restrict__ rowptr, const int *__restrict__ col,
                                                                const float *__restrict__ val, const float *__restrict__ B,
                                                                float *__restrict__ C, const SpmmWs *__restrict__ hdr,
-                                                               const int4 *__restrict__ units) {
+                                                               const int4 *__restrict__ units,
+                                                               const StrictPlanHdr *__restrict__ sp) {
   __shared__ union U {
     RowsLds r;
     StrictLds s;
     __device__ U() {}
   } lds;
   if ((int)blockIdx.x < nbu) {
-    spmm_units_strict_body<G, V, OP == DGS_MEAN, HAS_VAL, STRICT != 2>(blockIdx.x, nbu, lds.s, N, col, val, B, C, hdr, units, ht);
+    spmm_units_strict_body<G, V, OP == DGS_MEAN, HAS_VAL, STRICT != 2>(blockIdx.x, nbu, lds.s, N, col, val, B, C, hdr, units, ht, sp);
   } else {
     int rb = blockIdx.x - nbu;
 #if DGS_XCD_REMAP
@@ -1646,6 +1656,10 @@ static int launch_impl(const SpmmArgs &a) {
   return check_launch();
 }
 
+// The strict schedule runs over a cached plan's strict table (built with the default class thresholds) unless an experiment
+// override moved those thresholds.
+static inline bool strict_over_plan_ok() { return tuning().strict_mid == kTuneUnset && tuning().strict_hub == kTuneUnset; }
+
 #if defined(DGS_TU_STRICT)
 // Strict-order sum / mean (spmm_strict.h).  memset + classify_strict + ONE fused launch (no combine); dense graphs keep the
 // column-panel sweep for rows up to tlong nnz (its per-row accumulator is a sequential fmaf chain already) and send only
@@ -1661,6 +1675,27 @@ static int launch_strict(const SpmmArgs &a) {
     const dim3 grid((unsigned)((a.M + rpb - 1) / rpb), (unsigned)a.tiles);
     hipLaunchKernelGGL((spmm_small_strict<G, V, OP, HAS_VAL, STRICT>), grid, dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, rpw,
                        a.rowptr, a.col, a.val, a.B, a.C);
+    return check_launch();
+  }
+  if (a.plan) {
+    // over a cached plan (round 5, VERDICT r3 #1b): the plan carries every row > T1 sorted longest first with the sizes of the
+    // three length classes (spmm_plan.hip: plan_strict_*), so the call is ONE launch - no memset, no classify pass, no workspace
+    int nbu_req = tune(tuning().strict_nbu, 8 * cu_count());
+    if (nbu_req < 8) nbu_req = 8;
+    const int nbu = (nbu_req + 7) & ~7;
+    int rpw = kRowsPerWave;
+    const int min_waves = tune(tuning().min_waves, 8192);
+    while (rpw > 8 && a.M / rpw < min_waves) rpw >>= 1;
+    const int rows_per_block = (kBlock / kWave) * rpw;
+    const int64_t nbr = (a.M + rows_per_block - 1) / rows_per_block;
+    const char *pb = reinterpret_cast<const char *>(a.plan);
+    const PlanLayout PL = plan_layout(a.nnz);
+    const size_t off_strict = a.plan_off_hub ? plan_off_strict(plan_off_slot((size_t)a.plan_off_hub, a.plan_hub), a.plan_pslots)
+                                             : PL.off_strict;
+    const StrictPlanHdr *sp = reinterpret_cast<const StrictPlanHdr *>(pb + off_strict);
+    hipLaunchKernelGGL((spmm_fused_strict<G, V, OP, HAS_VAL, STRICT>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles),
+                       dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, nbu, rpw, HubTab{}, a.rowptr, a.col, a.val, a.B, a.C,
+                       (const SpmmWs *)nullptr, reinterpret_cast<const int4 *>(sp + 1), sp);
     return check_launch();
   }
   const WsLayout L = ws_layout(a.reduce_op, a.N, a.nnz);
@@ -1706,7 +1741,8 @@ static int launch_strict(const SpmmArgs &a) {
                            (int *)nullptr, &hdr->arrivals, Epi{});
       }
       hipLaunchKernelGGL((spmm_fused_strict<G, V, OP, HAS_VAL, STRICT>), dim3((unsigned)nbu, (unsigned)a.tiles), dim3(kBlock),
-                         0, a.st, (int)a.M, (int)a.N, nbu, kRowsPerWave, ht, a.rowptr, a.col, a.val, a.B, a.C, hdr, units);
+                         0, a.st, (int)a.M, (int)a.N, nbu, kRowsPerWave, ht, a.rowptr, a.col, a.val, a.B, a.C, hdr, units,
+                         (const StrictPlanHdr *)nullptr);
       return check_launch();
     }
   }
@@ -1719,7 +1755,8 @@ static int launch_strict(const SpmmArgs &a) {
   hipLaunchKernelGGL(spmm_classify_strict, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, kT1, tmid, thub, ht, a.rowptr,
                      hdr, units);
   hipLaunchKernelGGL((spmm_fused_strict<G, V, OP, HAS_VAL, STRICT>), dim3((unsigned)(nbr + nbu), (unsigned)a.tiles),
-                     dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, nbu, rpw, ht, a.rowptr, a.col, a.val, a.B, a.C, hdr, units);
+                     dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, nbu, rpw, ht, a.rowptr, a.col, a.val, a.B, a.C, hdr, units,
+                     (const StrictPlanHdr *)nullptr);
   return check_launch();
 }
 

@@ -34,7 +34,7 @@ struct PlanWs {  // build-time counters (zeroed by the first memset)
 
 struct PlanWsLayout {
   size_t off_cnt, off_cum, off_list, off_info, off_scan, off_keys_in, off_keys_out, off_units_in, off_hkeys_in, off_hkeys_out,
-      off_hub_in, off_tmp, tmp_bytes, total;
+      off_hub_in, off_skeys_in, off_skeys_out, off_srows_in, off_tmp, tmp_bytes, total;
   int64_t cap_long;
 };
 
@@ -59,8 +59,11 @@ static PlanWsLayout plan_ws_layout(int64_t K, int64_t nnz) {
   size_t t4 = 0;
   unsigned *hp = nullptr;
   (void)rocprim::radix_sort_pairs(nullptr, t4, hp, hp, i4, i4, (size_t)PL.max_hub, 0, 32, nullptr, false);
+  size_t t5 = 0;  // strict table: the rows longer than T1 sorted by length
+  (void)rocprim::radix_sort_pairs(nullptr, t5, hp, hp, i4, i4, (size_t)L.cap_long, 0, 32, nullptr, false);
   L.tmp_bytes = t1 > t2 ? (t1 > t3 ? t1 : t3) : (t2 > t3 ? t2 : t3);
   if (t4 > L.tmp_bytes) L.tmp_bytes = t4;
+  if (t5 > L.tmp_bytes) L.tmp_bytes = t5;
   size_t o = up(sizeof(PlanWs));
   L.off_cnt = o;          o += up((size_t)(K + 1) * 4);
   L.off_cum = o;          o += up((size_t)(K + 1) * 4);
@@ -73,6 +76,9 @@ static PlanWsLayout plan_ws_layout(int64_t K, int64_t nnz) {
   L.off_hkeys_in = o;     o += up((size_t)PL.max_hub * 4);
   L.off_hkeys_out = o;    o += up((size_t)PL.max_hub * 4);
   L.off_hub_in = o;       o += up((size_t)PL.max_hub * 16);
+  L.off_skeys_in = o;     o += up((size_t)L.cap_long * 4);
+  L.off_skeys_out = o;    o += up((size_t)L.cap_long * 4);
+  L.off_srows_in = o;     o += up((size_t)L.cap_long * 16);
   L.off_tmp = o;          o += up(L.tmp_bytes);
   L.total = o + 256;
   return L;
@@ -95,7 +101,7 @@ __global__ void plan_bounds(int K, int nnz, const int *__restrict__ cum, PlanHdr
   const int x = threadIdx.x;
   if (x == 0) {
     hdr->magic = kPlanMagic;
-    hdr->version = 2;
+    hdr->version = 3;  // 3: slot -> long-row map and strict table behind the hub table (round 5)
     hdr->M = M;
     hdr->nnz = nnz;
     hdr->K = K;
@@ -188,6 +194,37 @@ __device__ __forceinline__ int cut_row(const int *__restrict__ col, const int *_
   }
   rc.excl = incl - rc.n0 - rc.n1;
   return __shfl(incl, 63, 64);
+}
+
+// Strict table (the strict-order schedule over a plan, spmm_strict.h): every listed row as {row, first nnz, nnz, -} with key
+// ~nnz (ascending keys = longest first; unused slots keep 0xFFFFFFFF and sort last) ...
+__global__ __launch_bounds__(kBlock) void plan_strict_rows(const int *__restrict__ rowptr, const PlanWs *__restrict__ pw,
+                                                           const int *__restrict__ list, unsigned *__restrict__ keys,
+                                                           int4 *__restrict__ rows) {
+  const int n = pw->n_longlist;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const int r = list[i];
+    const int rs = rowptr[r], len = rowptr[r + 1] - rs;
+    keys[i] = ~(unsigned)len;
+    rows[i] = make_int4(r, rs, len, 0);
+  }
+}
+// ... and, once sorted, the sizes of its three length classes (len > T  <=>  key < ~T)
+__global__ void plan_strict_hdr(const PlanWs *__restrict__ pw, const unsigned *__restrict__ keys, StrictPlanHdr *__restrict__ sh) {
+  const int n = pw->n_longlist;
+  auto above = [&](int T) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (keys[mid] < ~(unsigned)T) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  const int nh = above(kStrictHub), nm = above(kStrictMid);
+  sh->n_hub = nh;
+  sh->n_mid = nm - nh;
+  sh->n_whole = n - nm;
+  for (int i = 0; i < 5; i++) sh->pad[i] = 0;
 }
 
 // One wave per long row: is it cut on the column grid (long enough AND sorted)?  how many units?
@@ -372,6 +409,10 @@ extern "C" int dgs_spmm_plan_build2(int64_t M, int64_t K, int64_t nnz, const int
   unsigned *hkeys_in = reinterpret_cast<unsigned *>(ws + WL.off_hkeys_in);
   unsigned *hkeys_out = reinterpret_cast<unsigned *>(ws + WL.off_hkeys_out);
   int4 *hub_in = reinterpret_cast<int4 *>(ws + WL.off_hub_in);
+  unsigned *skeys_in = reinterpret_cast<unsigned *>(ws + WL.off_skeys_in);
+  unsigned *skeys_out = reinterpret_cast<unsigned *>(ws + WL.off_skeys_out);
+  int4 *srows_in = reinterpret_cast<int4 *>(ws + WL.off_srows_in);
+  StrictPlanHdr *shdr = reinterpret_cast<StrictPlanHdr *>(pb + PL.off_strict);
   int4 *hub_rows = reinterpret_cast<int4 *>(pb + PL.off_hub);
   void *tmp = ws + WL.off_tmp;
   // unit length: 256 nnz when there is plenty of work; smaller inputs get shorter units (a unit is a chain of up to
@@ -389,6 +430,8 @@ extern "C" int dgs_spmm_plan_build2(int64_t M, int64_t K, int64_t nnz, const int
   if (hipMemsetAsync(units_in, 0, (size_t)PL.max_units * 16, st) != hipSuccess) return DGS_ELAUNCH;
   if (hipMemsetAsync(hkeys_in, 0xFF, (size_t)PL.max_hub * 4, st) != hipSuccess) return DGS_ELAUNCH;
   if (hipMemsetAsync(hub_in, 0, (size_t)PL.max_hub * 16, st) != hipSuccess) return DGS_ELAUNCH;
+  if (hipMemsetAsync(skeys_in, 0xFF, (size_t)WL.cap_long * 4, st) != hipSuccess) return DGS_ELAUNCH;
+  if (hipMemsetAsync(srows_in, 0, (size_t)WL.cap_long * 16, st) != hipSuccess) return DGS_ELAUNCH;
 
   size_t tb = WL.tmp_bytes;
   const int *prefix = col_prefix;
@@ -402,6 +445,13 @@ extern "C" int dgs_spmm_plan_build2(int64_t M, int64_t K, int64_t nnz, const int
                      unit, thub);
   hipLaunchKernelGGL(plan_longlist, dim3((unsigned)((M + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int)M, kT1, rowptr,
                      pw, list);
+  // strict table: the listed rows sorted longest first + the sizes of the strict schedule's length classes
+  hipLaunchKernelGGL(plan_strict_rows, dim3(512), dim3(kBlock), 0, st, rowptr, pw, list, skeys_in, srows_in);
+  tb = WL.tmp_bytes;
+  if (rocprim::radix_sort_pairs(tmp, tb, skeys_in, skeys_out, srows_in, reinterpret_cast<int4 *>(shdr + 1), (size_t)WL.cap_long, 0, 32,
+                                st, false) != hipSuccess)
+    return DGS_ELAUNCH;
+  hipLaunchKernelGGL(plan_strict_hdr, dim3(1), dim3(1), 0, st, pw, skeys_out, shdr);
   // DGS_PLAN_NOCUT (experiment): rows longer than this are chunked without column cuts (what a hub row costs when it leaves
   // the column-slice order)
   hipLaunchKernelGGL(plan_rowunits, dim3(1024), dim3(kBlock), 0, st, ch, tslice, tune(tuning().plan_nocut, INT_MAX), unit, thub,
@@ -503,11 +553,15 @@ extern "C" size_t dgs_spmm_csr_plan_workspace_bytes(int reduce_op, int64_t M, in
   return ws_layout_plan(reduce_op, N, info->n_pslots, info->n_long).total;
 }
 
+// rows longer than T1 = single-unit rows + multi-unit rows (the units of multi-unit rows are exactly the partial slots)
+static inline int64_t plan_srows(const dgsSpmmPlanInfo *info) { return (int64_t)info->n_units - info->n_pslots + info->n_long; }
+
 extern "C" size_t dgs_spmm_plan_compact_bytes(const dgsSpmmPlanInfo *info) {
   if (!info) return 0;
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
   return 256 + 768 + up((size_t)info->n_units * sizeof(int4)) + up((size_t)info->n_long * sizeof(int4)) +
-         up((size_t)info->n_hub * sizeof(int4)) + up((size_t)info->n_pslots * sizeof(int)) + 256;
+         up((size_t)info->n_hub * sizeof(int4)) + up((size_t)info->n_pslots * sizeof(int)) +
+         up(sizeof(StrictPlanHdr) + (size_t)plan_srows(info) * sizeof(int4)) + 256;
 }
 
 extern "C" int dgs_spmm_plan_compact(const void *plan, dgsSpmmPlanInfo *info, void *compact, size_t compact_bytes,
@@ -523,12 +577,14 @@ extern "C" int dgs_spmm_plan_compact(const void *plan, dgsSpmmPlanInfo *info, vo
   const size_t hb = (size_t)info->n_hub * sizeof(int4);
   const size_t off_long = PL.off_units + up(ub), off_hub = off_long + up(lb);
   const size_t sb = (size_t)info->n_pslots * sizeof(int), off_slot = plan_off_slot(off_hub, info->n_hub);
-  if (off_slot + up(sb) > (size_t)INT32_MAX) return DGS_ERANGE;  // the offsets are 32-bit (2^27 units: beyond any int32 nnz / 64)
+  const size_t tb = sizeof(StrictPlanHdr) + (size_t)plan_srows(info) * sizeof(int4), off_strict = plan_off_strict(off_slot, info->n_pslots);
+  if (off_strict + up(tb) > (size_t)INT32_MAX) return DGS_ERANGE;  // the offsets are 32-bit (2^27 units: beyond any int32 nnz / 64)
   if (hipMemcpyAsync(dst, src, PL.off_units + ub, hipMemcpyDeviceToDevice, st) != hipSuccess) return DGS_ELAUNCH;
   if (lb && hipMemcpyAsync(dst + off_long, src + PL.off_long, lb, hipMemcpyDeviceToDevice, st) != hipSuccess)
     return DGS_ELAUNCH;
   if (hb && hipMemcpyAsync(dst + off_hub, src + PL.off_hub, hb, hipMemcpyDeviceToDevice, st) != hipSuccess) return DGS_ELAUNCH;
   if (sb && hipMemcpyAsync(dst + off_slot, src + PL.off_slot, sb, hipMemcpyDeviceToDevice, st) != hipSuccess) return DGS_ELAUNCH;
+  if (hipMemcpyAsync(dst + off_strict, src + PL.off_strict, tb, hipMemcpyDeviceToDevice, st) != hipSuccess) return DGS_ELAUNCH;
   info->off_long = (int32_t)off_long;
   info->off_hub = (int32_t)off_hub;
   return DGS_OK;

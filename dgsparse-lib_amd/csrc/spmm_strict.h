@@ -550,7 +550,7 @@ __device__ __forceinline__ void spmm_units_strict_body(int bid, int nblocks, Str
                                                        const int *__restrict__ col, const float *__restrict__ val,
                                                        const float *__restrict__ B, float *__restrict__ C,
                                                        const SpmmWs *__restrict__ hdr, const int4 *__restrict__ units,
-                                                       const HubTab ht) {
+                                                       const HubTab ht, const StrictPlanHdr *__restrict__ sp) {
   constexpr int SM = strict_smid(G);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float *xb = lds.wave_region(wave);
@@ -558,6 +558,21 @@ __device__ __forceinline__ void spmm_units_strict_body(int bid, int nblocks, Str
   const int nx = (nblocks & 7) == 0 ? 8 : 1;
   const int x = bid % nx;
   const int s = (bid / nx) * (kBlock / kWave) + wave, SP = (nblocks / nx) * (kBlock / kWave);  // wave slots of this XCD
+  if (sp) {
+    // over a cached plan (round 5): `units` is the plan's strict table - every row > T1, longest first: [hub rows | rows worked as
+    // 4 feature slices | whole-tile rows], sizes in the header in front of it; nothing was classified for this call
+    const int nh = sp->n_hub, nm = sp->n_mid, nw = sp->n_whole;
+    int rot = spmm_hub_body<G, V, MEAN, HAS_VAL, FMA>(bid, nblocks, lds.f, N, col, val, B, C, HubArg{&sp->n_hub, units, HubTab{}, 1});
+    strict_deal(nm, SM, x, nx, s, SP, rot, [&](int g, int j) {
+      const int4 d = units[nh + g];
+      strict_unit<V, G / SM, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, j, lane, N, col, val, B, C, xb);
+    });
+    strict_deal(nw, 1, x, nx, s, SP, rot, [&](int g, int) {
+      const int4 d = units[nh + nm + g];
+      strict_unit<V, G, MEAN, HAS_VAL, FMA>(d.x, d.y, d.z, tbase, 0, lane, N, col, val, B, C, xb);
+    });
+    return;
+  }
   int rot = spmm_hub_body<G, V, MEAN, HAS_VAL, FMA>(bid, nblocks, lds.f, N, col, val, B, C, HubArg{hdr->hub, units, ht, kHubClasses});
   // 4-slice units {row, first nnz, nnz, -}: SM entries' worth of work per row, table grows down from mid_top
   strict_deal(hdr->n_pslots, SM, x, nx, s, SP, rot, [&](int g, int j) {  // (SM = 1 for one-lane tiles: the whole tile again)

@@ -36,8 +36,8 @@ static int run(FeatMap fm, SpmmArgs a) {
   fm = narrow_tiles(fm, a);
   a.tiles = fm.tiles;
   if ((a.hints & (DGS_ALG_STRICT_SUM | DGS_ALG_STRICT_NOFMA)) && (a.reduce_op == DGS_SUM || a.reduce_op == DGS_MEAN) &&
-      !a.accumulate && !a.plan)
-    return spmm_run_strict(fm.G, fm.V, a);
+      !a.accumulate)
+    return spmm_run_strict(fm.G, fm.V, a);  // (with a.plan: over the plan's strict table)
   if (fm.V != 4) return spmm_run_v1(fm.G, a);
   return (a.reduce_op == DGS_MAX || a.reduce_op == DGS_MIN) ? spmm_run_v4_arg(fm.G, a) : spmm_run_v4_sum(fm.G, a);
 }
@@ -288,7 +288,8 @@ extern "C" int dgs_spmm_csr_ex_f32(int reduce_op, int64_t M, int64_t K, int64_t 
   if (E && !arg) {
     if (hipMemsetAsync(E, 0xFF, (size_t)M * N * sizeof(int32_t), st) != hipSuccess) return DGS_ELAUNCH;
   }
-  const bool planned = plan && info && !strict && nnz > 0 && !tiny_problem(M, nnz) &&
+  // (a strict call uses the plan's strict table unless an experiment override moved the class thresholds)
+  const bool planned = plan && info && (!strict || strict_over_plan_ok()) && nnz > 0 && !tiny_problem(M, nnz) &&
                        dgs_spmm_csr_schedule(reduce_op, M, K, N, nnz) == DGS_SCHED_ROWS;
   if (planned && !is_aligned16(plan)) return DGS_EINVAL;
   const size_t need = planned ? dgs_spmm_csr_plan_workspace_bytes(reduce_op, M, N, nnz, info)

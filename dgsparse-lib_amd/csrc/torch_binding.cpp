@@ -125,6 +125,19 @@ std::vector<Tensor> spmm_fwd(int op, const Tensor &rowptr_, const Tensor &col_, 
   const dgsSpmmPlanInfo *pi = plan_info(plan, pinfo, rowptr);
   // strict-order sum / mean (DGS_ALG_STRICT_*) has its own unit table: the locality plan does not apply
   const bool strict = (algorithm & (DGS_ALG_STRICT_SUM | DGS_ALG_STRICT_NOFMA)) && (op == DGS_SUM || op == DGS_MEAN);
+  if (pi && strict && M > 0 && N > 0 && nnz > 0 && dgs_spmm_csr_schedule(op, M, K, N, nnz) == DGS_SCHED_ROWS) {
+    // strict order over the plan's strict table (rows > 64 nnz sorted by length: one launch, no classify pass): the general entry
+    TORCH_CHECK((size_t)plan->numel() >= (pi->off_long ? dgs_spmm_plan_compact_bytes(pi) : dgs_spmm_plan_bytes(M, K, nnz)),
+                "dgsparse: plan buffer too small for this matrix");
+    const size_t wa = dgs_spmm_csr_plan_workspace_bytes(op, M, N, nnz, pi), wb = dgs_spmm_csr_workspace_bytes(op, M, N, nnz);
+    const size_t wsb = wa > wb ? wa : wb;  // (an experiment override of the class thresholds sends the call plan-free)
+    Tensor ws = workspace(wsb, dense);
+    check_rc(dgs_spmm_csr_ex_f32(op, M, K, N, nnz, rowptr.data_ptr<int>(), col.data_ptr<int>(), vptr, dense.data_ptr<float>(),
+                                 out.data_ptr<float>(), nullptr, (int)algorithm, nullptr, nullptr, 0, plan->data_ptr(), pi,
+                                 ws.data_ptr(), wsb, cur_stream()),
+             "spmm (strict over the plan)");
+    return {out, E};
+  }
   if (pi && !strict && M > 0 && N > 0 && nnz > 0 && dgs_spmm_csr_schedule(op, M, K, N, nnz) == DGS_SCHED_ROWS) {
     TORCH_CHECK((size_t)plan->numel() >= (pi->off_long ? dgs_spmm_plan_compact_bytes(pi) : dgs_spmm_plan_bytes(M, K, nnz)),
                 "dgsparse: plan buffer too small for this matrix");

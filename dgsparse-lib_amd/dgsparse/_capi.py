@@ -438,6 +438,15 @@ def spmm(reduce_op, rowptr, col, values, dense, algorithm=0, want_E=None, plan=N
         return out, E
     with _on_device(dev):
         strict = (int(algorithm) & (ALG_STRICT_SUM | ALG_STRICT_NOFMA)) and reduce_op in (SUM, MEAN)
+        if plan is not None and strict and _lib.dgs_spmm_csr_schedule(int(reduce_op), M, K, N, nnz) == 1:
+            # strict order over the plan's strict table (rows > 64 nnz sorted by length: no classify pass): the general entry
+            wsb = _lib.dgs_spmm_csr_plan_workspace_bytes(reduce_op, M, N, nnz, ctypes.byref(plan.info))
+            wsb = max(wsb, _lib.dgs_spmm_csr_workspace_bytes(reduce_op, M, N, nnz))  # (an experiment override may send it plan-free)
+            ws = _new(wsb, dtype=torch.uint8, device=dev)
+            _check(_lib.dgs_spmm_csr_ex_f32(reduce_op, M, K, N, nnz, _p(rowptr), _p(col), _p(values), _p(dense), _p(out), _p(E),
+                                            int(algorithm), None, None, 0, _p(plan.buf), ctypes.byref(plan.info), _p(ws), wsb,
+                                            _stream(dev)), 'spmm_ex (strict over the plan)')
+            return out, E
         if plan is not None and not strict and _lib.dgs_spmm_csr_schedule(int(reduce_op), M, K, N, nnz) == 1:
             wsb = _lib.dgs_spmm_csr_plan_workspace_bytes(reduce_op, M, N, nnz, ctypes.byref(plan.info))
             ws = _new(wsb, dtype=torch.uint8, device=dev)

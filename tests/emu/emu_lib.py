@@ -135,8 +135,9 @@ def spmm_ex(op, rp, col, val, X, bias=None, row_scale=None, relu=False, plan=Non
     C = np.full((M, N), np.nan, np.float32)
     i64 = ctypes.c_int64
     pbuf, info = plan if plan is not None else (None, None)
-    if plan is not None:
-        wsb = L.dgs_spmm_csr_plan_workspace_bytes(op, i64(M), i64(N), i64(nnz), ctypes.byref(info))
+    if plan is not None:  # (a strict call whose class thresholds were overridden ignores the plan and wants the plan-free workspace)
+        wsb = max(L.dgs_spmm_csr_plan_workspace_bytes(op, i64(M), i64(N), i64(nnz), ctypes.byref(info)),
+                  L.dgs_spmm_csr_workspace_bytes(op, i64(M), i64(N), i64(nnz)))
     else:
         wsb = L.dgs_spmm_csr_workspace_bytes(op, i64(M), i64(N), i64(nnz))
     ws = _buf(wsb)

@@ -433,3 +433,32 @@ def test_in_kernel_fold_equals_the_combine_launch(blocks, order):
     p = subprocess.run([sys.executable, '-c', FOLD_CASE % dict(root=root, here=here)], capture_output=True, text=True, env=env,
                        timeout=2400)
     assert p.returncode == 0 and 'BAD 0' in p.stdout, (p.stdout[-500:], p.stderr[-2500:])
+
+
+@pytest.mark.parametrize('N', [64, 41, 256])
+def test_strict_order_over_the_cached_plan(graph, N):
+    """VERDICT r3 #1b / r4 #7: the plan carries every row longer than 64 nnz sorted longest first with the sizes of the strict
+    schedule's three length classes, so a strict call over a plan is ONE launch (no memset, no classify pass) - and the same
+    chains: bit for bit the oracle's, both roundings, compact plan / build buffer / provisional counts, mean with unit weights."""
+    rp, col, val, K, deg = graph
+    X = feats(K, N)
+    plan = E.spmm_plan(rp, col, K)
+    big, real = E.spmm_plan(rp, col, K, compact=False)
+    for alg, fma in ((E.ALG_STRICT_SUM, True), (E.ALG_STRICT_NOFMA, False)):
+        ref, _ = oracle.spmm('sum', rp, col, val, X, fma=fma)
+        E.launch_log()
+        C0 = E.spmm_ex(E.SUM, rp, col, val, X, algorithm=alg)
+        assert _kernels(E.launch_log()) == ['spmm_classify_strict', 'spmm_fused_strict']
+        assert_bitexact(C0, ref, f'strict plan-free fma={fma}')
+        for name, pl in (('compact', plan), ('build buffer', (big, real)), ('provisional counts', (big, E.provisional_info(rp)))):
+            C1 = E.spmm_ex(E.SUM, rp, col, val, X, algorithm=alg, plan=pl)
+            assert _kernels(E.launch_log()) == ['spmm_fused_strict'], name
+            assert_bitexact(C1, ref, f'strict over the plan ({name}) fma={fma}')
+    refm, _ = oracle.spmm('mean', rp, col, None, X, fma=True)
+    assert_bitexact(E.spmm_ex(E.MEAN, rp, col, None, X, algorithm=E.ALG_STRICT_SUM, plan=plan), refm, 'mean, unit weights')
+    E.set_env(DGS_STRICT_HUB=4096)  # an experiment override of the class thresholds: the plan's table does not apply
+    E.launch_log()
+    C2 = E.spmm_ex(E.SUM, rp, col, val, X, algorithm=E.ALG_STRICT_SUM, plan=plan)
+    assert _kernels(E.launch_log()) == ['spmm_classify_strict', 'spmm_fused_strict']
+    assert_bitexact(C2, oracle.spmm('sum', rp, col, val, X, fma=True)[0], 'override: plan-free strict')
+    E.set_env(DGS_STRICT_HUB=None)

@@ -287,3 +287,29 @@ def test_single_launch_inputs_chain_their_hub_rows(capi, N):
     assert torch.equal(got, torch.relu(torch.from_numpy(C).to(d) * rs[:, None] + bias)), 'fused == unfused bit for bit'
 
 
+
+
+@pytest.mark.parametrize('N', [64, 128, 41])
+def test_strict_order_over_the_cached_plan(capi, N):
+    """Round 5 (VERDICT r3 #1b): a strict call over a plan takes the plan's strict table (rows > 64 nnz sorted longest first, class
+    sizes in its header) - no memset, no classify pass, one launch - and chains exactly what the plan-free strict call chains:
+    same bits, which are the oracle's; compact plan and the C entry with provisional counts; the public operator over a
+    Storage that has its plan."""
+    import dgsparse
+    rp, col, st = graphgen.powerlaw_csr(300000, 3000000, alpha=2.0, dmax=30000, seed=23)
+    val = graphgen.weights(col.shape[0], 'uniform', 5)
+    X = graphgen.features(st['K'], N, 6)
+    d = 'cuda'
+    drp, dcol, dval, dX = (torch.from_numpy(a).to(d) for a in (rp, col, val, X))
+    plan = capi.spmm_plan(drp, dcol, st['K'], N, force=True)
+    for alg, fma in ((capi.ALG_STRICT_SUM, True), (capi.ALG_STRICT_NOFMA, False)):
+        ref, _ = oracle.spmm('sum', rp, col, val, X, fma=fma, threads=oracle.max_threads())
+        C0, _ = capi.spmm(capi.SUM, drp, dcol, dval, dX, algorithm=alg)
+        C1, _ = capi.spmm(capi.SUM, drp, dcol, dval, dX, algorithm=alg, plan=plan)
+        assert_bitexact(C0.cpu().numpy(), ref, f'strict plan-free fma={fma}')
+        assert_bitexact(C1.cpu().numpy(), ref, f'strict over the plan fma={fma}')
+    A = dgsparse.SparseTensor(rowptr=drp, col=dcol, values=dval, has_value=True)
+    assert A.storage.spmm_plan('csr', N, wait=True)[0] is not None
+    out = dgsparse.spmm_sum(A, dX, dgsparse.ALG_STRICT_SUM)
+    assert_bitexact(out.cpu().numpy(), oracle.spmm('sum', rp, col, val, X, fma=True, threads=oracle.max_threads())[0],
+                    'public operator, strict bits, planned Storage')
