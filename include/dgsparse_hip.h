@@ -222,6 +222,10 @@ int dgs_spmm_csr_plan_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_
  * reference's GCN layer runs spmm_sum and torch.relu as two passes, dgsparse/nn/gcnconv.py:10-35).  DGS_EINVAL for max / min
  * and for the strict-order bits together with an epilogue.  workspace: dgs_spmm_csr_plan_workspace_bytes with a plan on the
  * row-stream schedule, dgs_spmm_csr_workspace_bytes otherwise.
+ * Strict-order bits WITH a plan (round 5): the plan also carries every row longer than 64 nnz sorted by length, which is all the
+ * strict schedule needs - the call is one launch (no memset, no classify pass), the chains and so the bits are those of the
+ * plan-free strict call.  (An experiment override of the strict class thresholds, DGS_STRICT_MID / _HUB, makes the call ignore
+ * the plan and want the plan-free workspace: pass the larger of the two sizes when such overrides are in play.)
  */
 int dgs_spmm_csr_ex_f32(int reduce_op, int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,
                         const int32_t *col, const float *val, const float *B, float *C, int32_t *E, int algorithm,
