@@ -91,6 +91,9 @@ def one_case(rng, it):
                 if rng.integers(0, 2):
                     Cs, _ = E.spmm(OPS[reduce], rp, col, val, X, algorithm=alg)
                     assert_bitexact(Cs, oracle.spmm(reduce, rp, col, val, X, fma=fma)[0], f'{tag} strict {reduce} fma={fma}')
+                    if plan is not None:  # round 5: the same chains over the plan's strict table (one launch)
+                        Cp = E.spmm_ex(OPS[reduce], rp, col, val, X, algorithm=alg, plan=plan)
+                        assert_bitexact(Cp, Cs, f'{tag} strict over the plan {reduce} fma={fma}')
     if rng.integers(0, 2):
         red = ('sum', 'mean')[int(rng.integers(0, 2))]
         kw = dict(plan=plan) if (plan is not None and rng.integers(0, 2)) else {}
