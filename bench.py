@@ -202,6 +202,18 @@ def cpu_baseline(rp, col, val, X, flops, C_gpu=None, C_strict=None):
     return out
 
 
+def parity_vs_sequential(C, rp, col, val, X):
+    """Every element of a GPU sum against the sequential fp32 chain of algorithm 0 (checker leg, outside any timed region)."""
+    import numpy as np
+    import oracle
+    Cseq = oracle.spmm('sum', rp, col, val, X, fma=False, threads=min(os.cpu_count() or 1, oracle.max_threads()))[0]
+    rel = np.abs(C.astype(np.float64) - Cseq) / np.maximum(np.abs(Cseq), 1e-6)
+    lens = np.diff(rp)
+    return dict(max_rel_err_vs_sequential=float(rel.max()), within_1e_5=bool(rel.max() <= 1e-5),
+                elements_beyond_1e_5=int((rel > 1e-5).sum()), elements=int(rel.size), longest_row_nnz=int(lens.max()),
+                rows_gt_hub_threshold=int((lens > 16384).sum()))
+
+
 def main():
     a = parse()
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
