@@ -20,6 +20,8 @@ __version__ = '0.1'
 ALG_SHARED_GPU = _capi.ALG_SHARED_GPU
 ALG_STRICT_SUM = _capi.ALG_STRICT_SUM      # sum / mean as ONE sequential fmaf chain per (row, feature), any row length
 ALG_STRICT_NOFMA = _capi.ALG_STRICT_NOFMA  # ... with the product rounded before the add (the reference's host loop)
+ALG_NO_HUB_ROWS = _capi.ALG_NO_HUB_ROWS    # the caller knows that no row is longer than the hub threshold (spmm_* add it themselves
+ALG_NO_HUB_COLS = _capi.ALG_NO_HUB_COLS    # from what the Storage knows: Storage.hub_hints()); ... no column (backward's product)
 
 cuda_version = _C.cuda_version()  # -1 on ROCm: the reference's CUDA-major check is skipped (__init__.py:29)
 
