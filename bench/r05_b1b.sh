@@ -1,0 +1,24 @@
+#!/bin/bash
+set -x
+cd "$(dirname "$0")/.."
+O=gpurun_out/r05b1
+mkdir -p $O
+export TMPDIR=/tmp PYTHONPATH=$PWD:$PWD/dgsparse-lib_amd
+for cfg in "hub_fold:" "hub_nofold:DGS_FOLD=0" "nohub_fold:DGS_HUB_CHAIN=0" "nohub_nofold:DGS_HUB_CHAIN=0 DGS_FOLD=0"; do
+  tag=${cfg%%:*}; envs=${cfg#*:}
+  env $envs timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$tag -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-dense --no-protocol > /dev/null 2>&1
+  cp $(ls $O/ks_$tag/*/*kernel_stats.csv | head -1) $O/kernel_stats_bench_feat64_sum_plan_$tag.csv; rm -rf $O/ks_$tag
+done
+timeout 400 bash bench/prof_pmc.sh $O/pmc_plan_hub_fold --no-dense --no-protocol > /dev/null 2>&1
+DGS_HUB_CHAIN=0 DGS_FOLD=0 timeout 400 bash bench/prof_pmc.sh $O/pmc_plan_nohub_nofold --no-dense --no-protocol > /dev/null 2>&1
+DGS_FOLD=0 timeout 400 bash bench/prof_pmc.sh $O/pmc_plan_hub_nofold --no-dense --no-protocol > /dev/null 2>&1
+timeout 600 python bench/strict_parts.py 64 > $O/strict_parts.txt 2>&1
+timeout 600 python bench/strict_time.py > $O/strict_time.txt 2>&1
+timeout 900 python bench/nocut_probe.py 64 > $O/nocut_probe.txt 2>&1
+make -C examples > /dev/null 2>&1
+timeout 900 python bench/mtx_bench.py --out $O/r05_mtx > $O/mtx_bench.txt 2>&1
+timeout 300 python bench/bench_configs.py > $O/configs.jsonl 2>/dev/null
+ls -la $O
+tail -n 12 $O/strict_parts.txt $O/nocut_probe.txt
+head -c 3000 $O/bench_line.json
+

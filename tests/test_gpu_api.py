@@ -650,6 +650,7 @@ def test_gin_cached_neighbourhood_is_keyed_on_the_graph():
     assert torch.equal(b, X + X[[1, 0, 3, 2]])
 
 
+@pytest.mark.first_contact
 def test_hub_self_test_passes_on_this_device_and_gates_the_default(monkeypatch):
     """The default sum / mean chain their hub rows only on a device where the library's self-test has compared that chain, bit
     for bit, with a one-thread-per-element sequential kernel (include/dgsparse_hip.h "Device gate").  On a healthy

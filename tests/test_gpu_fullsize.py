@@ -128,6 +128,7 @@ def sub_csr_np(rp, col, val, rows):
     return rp2, col[idx], (None if val is None else val[idx])
 
 
+@pytest.mark.first_contact
 @pytest.mark.parametrize('planned', [False, True], ids=['plan-free', 'plan'])
 @pytest.mark.parametrize('seed,N', [(0, 64), (1, 64), (2, 64), (3, 64), (4, 64), (0, 32), (0, 128), (3, 32), (4, 128)])
 def test_headline_sum_all_rows_vs_reference_host(capi, planned, seed, N):

@@ -434,6 +434,7 @@ def test_plan_build_with_the_csc_prefix_equals_the_counted_one(capi):
     assert (int(pinfo[0]), int(pinfo[1]), int(pinfo[2])) == (ci.n_units, ci.n_long, ci.n_pslots)
 
 
+@pytest.mark.first_contact
 @pytest.mark.parametrize('N', [64, 256, 33])
 def test_in_kernel_fold_equals_the_combine_launch(capi, N, monkeypatch):
     """Round 5: multi-unit rows are folded by the unit wave that completes them - arrival counter per

@@ -155,6 +155,7 @@ def _default(capi, op, rp, col, val, X, plan=False, **kw):
     return C.cpu().numpy(), pl
 
 
+@pytest.mark.first_contact
 @pytest.mark.parametrize('N', [16, 32, 64, 128, 256, 48, 384, 41, 100, 8, 4, 7, 1])
 @pytest.mark.parametrize('plan', [False, True], ids=['plan-free', 'plan'])
 def test_default_sum_chains_the_hub_rows(capi, monkeypatch, N, plan):
@@ -185,6 +186,7 @@ def test_default_sum_chains_the_hub_rows(capi, monkeypatch, N, plan):
     assert np.abs(Cm - refm).max() <= 1e-5 * np.abs(refm).max() + 1e-6
 
 
+@pytest.mark.first_contact
 def test_hub_chain_switch_and_other_reduces_share_the_plan(capi, monkeypatch):
     """DGS_HUB_CHAIN=0 brings the fixed tree back for every row; a plan built WITH hub rows still serves max / min (their
     units stay in the table, sorted behind the other units of each XCD's share) bit-exactly."""
@@ -217,6 +219,7 @@ def test_hub_chain_switch_and_other_reduces_share_the_plan(capi, monkeypatch):
         assert (np.abs(Cx - C64) <= 3e-6 * S64 + 1e-6).all(), name
 
 
+@pytest.mark.first_contact
 def test_hub_chain_with_the_fused_epilogue_and_the_panel_schedule(capi, monkeypatch):
     """The epilogue leaves with the hub rows' results as well (bit-identical to the unfused ops), and a dense graph on the
     column-panel sweep chains its rows above the hub threshold."""
@@ -254,6 +257,7 @@ def test_hub_chain_with_the_fused_epilogue_and_the_panel_schedule(capi, monkeypa
     assert (np.abs(C2 - ref2) <= 1e-5 * np.abs(ref2) + 2e-6).all()
 
 
+@pytest.mark.first_contact
 @pytest.mark.parametrize('N', [64, 128, 8, 41])
 def test_single_launch_inputs_chain_their_hub_rows(capi, N):
     """Inputs of <= 2^18 nnz / 2^16 rows are ONE launch; with more nnz than the hub threshold that launch is spmm_small_hub: rows
