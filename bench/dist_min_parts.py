@@ -1,6 +1,7 @@
 """Compute-side cost of the overlapped min of dgsparse.dist on ONE rank's shard (no exchange: standalone plan, halo rows
 filled with random features): the one-pass product that has to wait for the exchange, against the pieces of the overlapped
-schedule - local product (runs under the exchange), detector scans, the two accumulating halo products, the redo-only call.
+schedule - local product (runs under the exchange), detector scans, the two accumulating halo products (or, round 5, the ONE
+launch in which the local result is a virtual entry of its row), the redo-only call.
     python bench/dist_min_parts.py [rows_log2=20] [deg=16] [feat=64] [world=8] [locality=0.8]"""
 import os
 import sys
@@ -49,6 +50,10 @@ def main():
     (lo, lo_rows, _), (hi, hi_rows, _) = plan.min_parts()
     acc_lo = ms(lambda: ops.spmm_acc_min(lo[0], lo[1], lo[2], halo, C, E, lo_rows, nl, True))
     acc_hi = ms(lambda: ops.spmm_acc_min(hi[0], hi[1], hi[2], halo, C, E, hi_rows, nl, False))
+    # round 5: both sides in ONE accumulating launch, the local result a virtual entry of its row (dgs_spmm_csr_acc_min_around_f32).
+    # Repeated in place like the two folds above (a repeat re-folds a finished row: same work, the values no longer matter)
+    ar, ar_rows, _ = plan.min_around()
+    acc_around = ms(lambda: ops.spmm_acc_min_around(ar[0], ar[1], ar[2], halo, C, E, ar_rows, nl, plan.h_lo, nl))
     flag.zero_()
     redo = ms(lambda: ops.min_redo(plan.rem_rows, C, E, flag, p.rowptr, plan.col_ext, p.val, eng.B_ext))
     relabel = ms(lambda: ops.relabel(E, plan.ext2glob32))
@@ -59,6 +64,10 @@ def main():
           f'({int(lo[1].numel())} nnz, {int(lo_rows.numel())} rows) + higher halo behind {acc_hi:.4f} '
           f'({int(hi[1].numel())} nnz, {int(hi_rows.numel())} rows) + redo-if-flagged {redo:.4f} = {after:8.4f} ms')
     print(f'exposed after the exchange: {one:.4f} -> {after:.4f} ms; total GPU work {one:.4f} -> {loc + scan_loc + after:.4f} ms')
+    after1 = scan_halo + acc_around + redo
+    print(f'ONE accumulating launch (min_form around, the default): scan of the halo {scan_halo:.4f} + halo around the local result '
+          f'{acc_around:.4f} ({int(ar[1].numel())} entries incl. {int(ar[1].numel()) - int(lo[1].numel()) - int(hi[1].numel())} virtual, '
+          f'{int(ar_rows.numel())} rows) + redo-if-flagged {redo:.4f} = {after1:8.4f} ms exposed (two launches: {after:.4f})')
     print(f'global column ids of E on demand (DistSpMM.last_E): {relabel:.4f} ms')
 
 

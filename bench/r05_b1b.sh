@@ -18,7 +18,9 @@ timeout 900 python bench/nocut_probe.py 64 > $O/nocut_probe.txt 2>&1
 make -C examples > /dev/null 2>&1
 timeout 900 python bench/mtx_bench.py --out $O/r05_mtx > $O/mtx_bench.txt 2>&1
 timeout 300 python bench/bench_configs.py > $O/configs.jsonl 2>/dev/null
-ls -la $O
+
 tail -n 12 $O/strict_parts.txt $O/nocut_probe.txt
 head -c 3000 $O/bench_line.json
 
+timeout 300 python bench/dist_min_parts.py > $O/dist_min_parts.txt 2>&1
+ls -la $O; tail -n 6 $O/dist_min_parts.txt

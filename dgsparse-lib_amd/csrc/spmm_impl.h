@@ -310,11 +310,31 @@ __device__ __forceinline__ unsigned nan_flags(const float (&nf)[V]) {
   return m;
 }
 
+// Virtual columns (accumulating MIN, "around" form - AccArg below, dgsparse.dist): the column ids [lo, lo + n) of the
+// matrix do not name rows of the dense operand B but rows of C, the output the launch commits into - the pair (C, E)[row]
+// already holds rides through row `row`'s chain as ONE entry (column lo + row, weight 1), at the place its columns have in
+// the row; ids >= lo + n are the rows of B shifted by n.  n == 0: plain columns.
+struct VirtCols {
+  const float *C = nullptr;
+  int lo = INT_MAX, n = 0;
+};
+template <bool VIRT>
+__device__ __forceinline__ const float *dense_row(const float *B, const int c, const int N, const VirtCols &vc) {
+  if constexpr (!VIRT) {
+    return B + (int64_t)c * N;
+  } else {
+    const bool virt = (unsigned)(c - vc.lo) < (unsigned)vc.n;  // (c < lo wraps to a huge unsigned)
+    const float *base = virt ? vc.C : B;
+    const int r = virt ? c - vc.lo : (c >= vc.lo ? c - vc.n : c);
+    return base + (int64_t)r * N;
+  }
+}
+
 // Sequential algorithm-0 chain of row [rs,re) for the elements of this lane selected by `mask` (MIN fix-up, rare).
-template <int V, int OP>
+template <int V, int OP, bool VIRT = false>
 __device__ __forceinline__ void seq_redo(unsigned mask, int rs, int re, int N, int f0, const int *__restrict__ col,
                                          const float *__restrict__ val, const float *__restrict__ B, float (&acc)[V],
-                                         int (&ei)[V]) {
+                                         int (&ei)[V], const VirtCols vc = VirtCols{}) {
 #pragma unroll
   for (int v = 0; v < V; v++)
     if (mask >> v & 1) {
@@ -325,7 +345,7 @@ __device__ __forceinline__ void seq_redo(unsigned mask, int rs, int re, int N, i
     const int c = col[p];
     const float w = val ? val[p] : 1.0f;
     float x[V];
-    load_vec<V>(B + (int64_t)c * N + f0, x);
+    load_vec<V>(dense_row<VIRT>(B, c, N, vc) + f0, x);
 #pragma unroll
     for (int v = 0; v < V; v++)
       if (mask >> v & 1) reduce_step<OP>(acc[v], ei[v], w, x[v], c);
@@ -491,12 +511,12 @@ static __global__ __launch_bounds__(kBlock) void spmm_classify(int M, int ch, in
 // Wave-cooperative reduction of the nnz range [p0,p1) of one row: 64 (col,val) pairs at a time through the
 // wave's LDS tile, the NG groups take interleaved nnz (each B row is still one coalesced G-lane read), up to kU
 // gathers in flight per lane.  Leaves per-group partials in acc/ei/ep (combine with cross_group_reduce).
-template <int G, int V, int OP, bool HAS_VAL>
+template <int G, int V, int OP, bool HAS_VAL, bool VIRT = false>
 __device__ __forceinline__ void coop_accumulate(int p0, int p1, int lane, int g, int f0, bool fl, int N,
                                                 const int *__restrict__ col, const float *__restrict__ val,
                                                 const float *__restrict__ B, const int *__restrict__ Em, int orow,
                                                 int2 *tile, float (&acc)[V], int (&ei)[V], int (&ep)[V],
-                                                int (&el)[V], float (&nf)[V]) {
+                                                int (&el)[V], float (&nf)[V], const VirtCols vc = VirtCols{}) {
   constexpr int NG = kWave / G;
   for (int t0 = p0; t0 < p1; t0 += kWave) {
     const int cnt = min(kWave, p1 - t0);
@@ -524,7 +544,7 @@ __device__ __forceinline__ void coop_accumulate(int p0, int p1, int lane, int g,
       }
 #pragma unroll
       for (int q = 0; q < kU; q++) {
-        load_vec_gather<V>(B + (int64_t)c[q] * N + fo, x[q]);
+        load_vec_gather<V>(dense_row<VIRT>(B, c[q], N, vc) + fo, x[q]);
         if constexpr (OP == kOpMaskSum) load_vec<V>(Em + (int64_t)c[q] * N + fo, m[q]);
       }
 #pragma unroll
@@ -576,11 +596,21 @@ struct RowsLds {
 //        can only be the identity, so (arg < 0 and value != identity) marks it and the new pair simply replaces it.
 //        Exact unless a product is NaN (a NaN makes the chain forget what came before): dist_merge.hip has the detector
 //        and the sequential redo that go with it.
+//   min, "around" form (round 5; vc.n != 0) - both sides in ONE launch: the matrix is written in the row order of the whole
+//        shard, [columns that precede | ONE virtual entry | columns that follow], the virtual entry (column id vc.lo + output
+//        row, weight 1, only in rows whose output pair is not the empty row's) standing for everything (C, E)[output row]
+//        already cover: its "dense row" is that row of C (dense_row above), so the old value goes through the row's own
+//        chain / tree / partial rows at its place in the row - every tie rule is the row's own, nothing is merged by key -
+//        and the commit only has to write the result and, where the virtual entry won, keep the arg the output held.
+//        Every reader of C[row] belongs to row `row` and has consumed it before the row's commit (one wave; or the row's unit
+//        waves, whose partial rows the commit folds), so the launch works in place.  Real columns >= vc.lo + vc.n are
+//        B rows shifted by vc.n (the ids of a sorted shard row stay sorted: the plan can cut by column slice).
 struct AccArg {
   const int *rowmap;  // output row of every row of A (nullptr = identity)
   int col_off;        // added to this product's arg column ids (halo slot -> extended id)
   int nl, h_lo;       // max: extended-id layout: local columns [0, nl), h_lo of the halo slots precede them; min: see above
   Epi epi;            // plain (non-accumulating) sum / mean only: bias / row scale / relu at the row-end store
+  VirtCols vc;        // min, "around" form
 };
 template <int OP>
 constexpr bool epi_op() { return OP == DGS_SUM || OP == DGS_MEAN; }
@@ -621,19 +651,23 @@ __device__ __forceinline__ void acc_commit(float *__restrict__ C, int *__restric
     int eo[V];
     load_vec<V>(ep, eo);
     const bool first = aa.h_lo != 0;  // this product's columns precede the ones (old, eo) cover
+    const bool around = aa.vc.n != 0;  // the old pair went through the row as its virtual entry: (acc, ei) is the whole result
     float cv[V];
     int ev[V];
 #pragma unroll
     for (int v = 0; v < V; v++) {
-      const int en = ei[v] >= 0 ? ei[v] + aa.col_off : -1;
+      // (around: ids below vc.lo are the slots that precede, ids from vc.lo + vc.n on the slots that follow, shifted by vc.n)
+      const int es = (around & (ei[v] >= aa.vc.lo)) ? ei[v] - aa.vc.n : ei[v];
+      const int en = ei[v] >= 0 ? es + aa.col_off : -1;
+      const bool won_virt = around & ((unsigned)(ei[v] - aa.vc.lo) < (unsigned)aa.vc.n);
       const float a = first ? acc[v] : old[v], b = first ? old[v] : acc[v];  // a comes first in the row
       const int ea = first ? en : eo[v], eb = first ? eo[v] : en;
       const bool old_empty = (eo[v] < 0) & (old[v] != reduce_init<DGS_MIN>());
       // algorithm 0's step with res = a, t = b (branch-free, fresh arrays: see the max case)
       const float mv = (a < b) ? a : b;
       const int me = (a > b) ? eb : ea;
-      cv[v] = old_empty ? acc[v] : mv;
-      ev[v] = old_empty ? en : me;
+      cv[v] = (old_empty | around) ? acc[v] : mv;
+      ev[v] = won_virt ? eo[v] : ((old_empty | around) ? en : me);
     }
     if constexpr (HIDDEN) {
       store_vec_hidden<V>(ep, ev);
@@ -670,6 +704,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
   const int *rowmap = aa.rowmap;
   constexpr int NG = kWave / G;
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
+  constexpr bool VIRT = ACC && OP == DGS_MIN;  // the only instantiations that know virtual columns (AccArg, "around" form)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane / G, l = lane % G;
   const int r0 = (bid * (kBlock / kWave) + wave) * rpw;  // rpw <= 64 rows per wave (fewer on small inputs)
@@ -811,6 +846,8 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
       // with nnz (p+i+kU1).  Loads are unconditional (index clamped to the last nnz of the piece, feature lanes
       // beyond N read feature 0) so the compiler emits counted s_waitcnt vmcnt(kU1-1) instead of draining.
       const float *Bl = B + (fl ? f0 : 0);
+      VirtCols vcl = aa.vc;  // (the lane's feature offset folded into the base, like Bl)
+      if constexpr (VIRT) vcl.C = aa.vc.C + (fl ? f0 : 0);
       const int last = pe - 1;
       int2 cv[kU1];
       float x[kU1][V];
@@ -819,7 +856,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
 #pragma unroll
       for (int u = 0; u < kU1; u++) {
         cv[u] = tile[min(ps + u, last)];
-        load_vec_gather<V>(Bl + (int64_t)(cv[u].x & 0x7fffffff) * N, x[u]);
+        load_vec_gather<V>(dense_row<VIRT>(Bl, cv[u].x & 0x7fffffff, N, vcl), x[u]);
         if constexpr (OP == kOpMaskSum) load_vec<V>(El + (int64_t)(cv[u].x & 0x7fffffff) * N, mk[u]);
         // keep the fill in slot order: hipcc otherwise issues slot 0 LAST, and the loop's first wait - merged over the
         // entry edge and the back edge - becomes vmcnt(1), a drain of the whole window once per kU1 gathers
@@ -868,7 +905,7 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
           // (reading the tile entry one step ahead, so that its LDS latency runs under the wait for the oldest gather, was
           // built and measured late in round 3: no change anywhere - arxiv-shaped 48.0 us, headline 0.390 ms - and dropped)
           cv[u] = tile[min(p + u + kU1, last)];
-          load_vec_gather<V>(Bl + (int64_t)(cv[u].x & 0x7fffffff) * N, x[u]);
+          load_vec_gather<V>(dense_row<VIRT>(Bl, cv[u].x & 0x7fffffff, N, vcl), x[u]);
           if constexpr (OP == kOpMaskSum) load_vec<V>(El + (int64_t)(cv[u].x & 0x7fffffff) * N, mk[u]);
         }
       }
@@ -905,11 +942,11 @@ __device__ __forceinline__ void spmm_rows_body(int bid, int rpw, RowsLds &lds, i
       el[v] = -1;
     }
     float nf[V] = {};
-    coop_accumulate<G, V, OP, HAS_VAL>(rs, re, lane, g, f0, fl, N, col, val, B, E, r0 + r, tile, acc, ei, ep, el, nf);
+    coop_accumulate<G, V, OP, HAS_VAL, VIRT>(rs, re, lane, g, f0, fl, N, col, val, B, E, r0 + r, tile, acc, ei, ep, el, nf, aa.vc);
     cross_group_reduce<G, V, OP>(acc, ei, ep, el);
     if constexpr (OP == DGS_MIN) {
       const unsigned nm = nan_flags<G, V>(nf);
-      if (nm && g == 0 && fl) seq_redo<V, OP>(nm, rs, re, N, f0, col, HAS_VAL ? val : nullptr, B, acc, ei);
+      if (nm && g == 0 && fl) seq_redo<V, OP, VIRT>(nm, rs, re, N, f0, col, HAS_VAL ? val : nullptr, B, acc, ei, aa.vc);
     }
     if (g == 0 && fl) {
       if constexpr (OP == DGS_MEAN) {
@@ -1038,7 +1075,7 @@ __device__ __forceinline__ void fold_row(const int4 d, const int lane, const int
   if constexpr (OP == DGS_MIN) {
 #pragma unroll
     for (int dd = G; dd < 64; dd <<= 1) nm |= (unsigned)__shfl_xor((int)nm, dd, 64);
-    if (nm && g == 0 && fl) seq_redo<V, OP>(nm, rowptr[d.x], rowptr[d.x + 1], N, f0, col, val, B, acc, ei);
+    if (nm && g == 0 && fl) seq_redo<V, OP, ACC && OP == DGS_MIN>(nm, rowptr[d.x], rowptr[d.x + 1], N, f0, col, val, B, acc, ei, aa.vc);
   }
   if (g == 0 && fl) {
     if constexpr (OP == DGS_MEAN) {
@@ -1126,13 +1163,13 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
       el[v] = -1;
     }
     float nf[V] = {};
-    coop_accumulate<G, V, OP, HAS_VAL>(p0, p1, lane, g, f0, fl, N, col, val, B, E, d.x, tile, acc, ei, ep, el, nf);
+    coop_accumulate<G, V, OP, HAS_VAL, ACC && OP == DGS_MIN>(p0, p1, lane, g, f0, fl, N, col, val, B, E, d.x, tile, acc, ei, ep, el, nf, aa.vc);
     cross_group_reduce<G, V, OP>(acc, ei, ep, el);
     if constexpr (OP == DGS_MIN) {
       const unsigned nm = nan_flags<G, V>(nf);
       if (nm && g == 0 && fl) {
         if (whole) {
-          seq_redo<V, OP>(nm, p0, p1, N, f0, col, HAS_VAL ? val : nullptr, B, acc, ei);
+          seq_redo<V, OP, ACC && OP == DGS_MIN>(nm, p0, p1, N, f0, col, HAS_VAL ? val : nullptr, B, acc, ei, aa.vc);
         } else {  // tell the combine kernel to redo these elements of the row
 #pragma unroll
           for (int v = 0; v < V; v++)

@@ -413,11 +413,11 @@ extern "C" int dgs_spmm_csr_acc_max_f32(int64_t M, int64_t K, int64_t N, int64_t
 
 // (C, E)[rowmap[r], :] = algorithm 0's MIN step applied to what they hold and the min over row r of A, in row order:
 // precedes != 0 = this product's columns all come BEFORE the ones (C, E) cover, 0 = all AFTER (spmm_impl.h AccArg).
-extern "C" int dgs_spmm_csr_acc_min_f32(int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,
-                                        const int32_t *col, const float *val, const float *B, float *C, int32_t *E,
-                                        const int32_t *rowmap, int32_t col_off, int32_t precedes, const void *plan,
-                                        const dgsSpmmPlanInfo *info, void *workspace, size_t workspace_bytes,
-                                        dgsStream_t stream) {
+// virt_n != 0: the "around" form - both sides in one launch, the old pair a virtual entry of its row.
+static int acc_min_launch(int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                          const float *val, const float *B, float *C, int32_t *E, const int32_t *rowmap, int32_t col_off,
+                          int32_t precedes, int32_t virt_lo, int32_t virt_n, const void *plan, const dgsSpmmPlanInfo *info,
+                          void *workspace, size_t workspace_bytes, dgsStream_t stream) {
   if (M < 0 || K < 0 || N < 0 || nnz < 0) return DGS_EINVAL;
   if (M >= INT32_MAX || K >= INT32_MAX || N >= INT32_MAX || nnz >= INT32_MAX) return DGS_ERANGE;
   if (M == 0 || N == 0 || nnz == 0) return DGS_OK;
@@ -433,6 +433,7 @@ extern "C" int dgs_spmm_csr_acc_min_f32(int64_t M, int64_t K, int64_t N, int64_t
              static_cast<hipStream_t>(stream), DGS_MIN};
   a.accumulate = true;
   a.acc = AccArg{rowmap, col_off, 0, precedes ? 1 : 0};
+  if (virt_n) a.acc.vc = VirtCols{C, virt_lo, virt_n};
   if (planned) {
     a.plan = static_cast<const PlanHdr *>(plan);
     a.plan_units = info->n_units;
@@ -443,6 +444,31 @@ extern "C" int dgs_spmm_csr_acc_min_f32(int64_t M, int64_t K, int64_t N, int64_t
     a.plan_off_hub = info->off_hub;
   }
   return run(fm, a);
+}
+
+extern "C" int dgs_spmm_csr_acc_min_f32(int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,
+                                        const int32_t *col, const float *val, const float *B, float *C, int32_t *E,
+                                        const int32_t *rowmap, int32_t col_off, int32_t precedes, const void *plan,
+                                        const dgsSpmmPlanInfo *info, void *workspace, size_t workspace_bytes,
+                                        dgsStream_t stream) {
+  return acc_min_launch(M, K, N, nnz, rowptr, col, val, B, C, E, rowmap, col_off, precedes, 0, 0, plan, info, workspace,
+                        workspace_bytes, stream);
+}
+
+// The "around" form (spmm_impl.h AccArg): the matrix has K columns, of which [virt_lo, virt_lo + virt_n) are virtual - entry
+// (r, virt_lo + rowmap[r]) stands for what (C, E)[rowmap[r]] hold, at its place in the row - and B has K - virt_n rows: column
+// c < virt_lo is row c of B, c >= virt_lo + virt_n is row c - virt_n.  (C, E)[rowmap[r]] = the MIN over the whole row in row
+// order, E = the arg the output held where the virtual entry is the first minimum, else the winning column mapped like the rows
+// of B (c or c - virt_n) + col_off.  A row WITHOUT a virtual entry replaces its output pair.  Two rows must not share an
+// output row, and the only row that may name virtual column virt_lo + j is the one with rowmap[r] == j.
+extern "C" int dgs_spmm_csr_acc_min_around_f32(int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr,
+                                               const int32_t *col, const float *val, const float *B, float *C, int32_t *E,
+                                               const int32_t *rowmap, int32_t col_off, int32_t virt_lo, int32_t virt_n,
+                                               const void *plan, const dgsSpmmPlanInfo *info, void *workspace,
+                                               size_t workspace_bytes, dgsStream_t stream) {
+  if (virt_lo < 0 || virt_n <= 0 || (int64_t)virt_lo + virt_n > K) return DGS_EINVAL;
+  return acc_min_launch(M, K, N, nnz, rowptr, col, val, B, C, E, rowmap, col_off, 0, virt_lo, virt_n, plan, info, workspace,
+                        workspace_bytes, stream);
 }
 
 // Masked SpMM (max/min backward w.r.t. the dense operand) on the CSC arrays: same launcher, internal op kOpMaskSum.

@@ -94,6 +94,9 @@ _lib.dgs_spmm_csr_acc_max_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp,
 _lib.dgs_spmm_csr_acc_min_f32.restype = _int
 _lib.dgs_spmm_csr_acc_min_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp,
                                           ctypes.POINTER(PlanInfo), _vp, _sz, _vp]
+_lib.dgs_spmm_csr_acc_min_around_f32.restype = _int
+_lib.dgs_spmm_csr_acc_min_around_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp,
+                                                 ctypes.POINTER(PlanInfo), _vp, _sz, _vp]
 _lib.dgs_spmm_csr_mask_f32.restype = _int
 _lib.dgs_spmm_csr_mask_f32.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
 _lib.dgs_spmm_csr_mask_workspace_bytes.restype = _sz
@@ -134,7 +137,7 @@ EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_reload_tuning', 'dgs_
            'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes', 'dgs_spmm_plan_build', 'dgs_spmm_plan_build2',
            'dgs_spmm_plan_compact_bytes', 'dgs_spmm_plan_compact', 'dgs_spmm_plan_info_from_header',
            'dgs_spmm_plan_thresholds', 'dgs_spmm_plan_provisional_info', 'dgs_spmm_csr_ex_f32', 'dgs_spmm_csr_plan_workspace_bytes',
-           'dgs_spmm_csr_plan_f32', 'dgs_spmm_csr_acc_f32', 'dgs_spmm_csr_acc_max_f32', 'dgs_spmm_csr_acc_min_f32',
+           'dgs_spmm_csr_plan_f32', 'dgs_spmm_csr_acc_f32', 'dgs_spmm_csr_acc_max_f32', 'dgs_spmm_csr_acc_min_f32', 'dgs_spmm_csr_acc_min_around_f32',
            'dgs_spmm_csr_schedule', 'dgs_spmm_arg_backward_f32', 'dgs_sddmm_csr_schedule',
            'dgs_spmm_csr_mask_workspace_bytes', 'dgs_spmm_csr_mask_f32', 'dgs_sddmm_csr_f32', 'dgs_sddmm_csr_plan_f32', 'dgs_sddmm_csr_mask_f32', 'dgs_csr2csc_workspace_bytes',
            'dgs_csr2csc_i32', 'dgs_gather_rows_f32', 'dgs_scatter_add_rows_f32', 'dgs_relabel_i32', 'dgs_nonfinite_flag_f32', 'dgs_spmm_min_merge_f32', 'dgs_sddmm_coo_f32', 'dgs_gspmm_csr_workspace_bytes', 'dgs_gspmm_csr_f32', 'gespmmCsrSpMM',
@@ -565,6 +568,43 @@ def spmm_acc_min(rowptr, col, values, dense, C, E, rowmap=None, col_off=0, prece
                                              _p(plan.buf) if plan is not None else None,
                                              ctypes.byref(plan.info) if plan is not None else None, _p(ws), wsb,
                                              _stream(dev)), 'spmm_acc_min')
+    return C, E
+
+
+def spmm_acc_min_around(rowptr, col, values, dense, C, E, rowmap, col_off, virt_lo, virt_n, plan=None):
+    """(C, E)[rowmap[r], :] <- the MIN over row r of A in row order, where the entry with column ``virt_lo + rowmap[r]`` stands
+    for what (C, E)[rowmap[r]] hold (its dense row is that row of C), columns below ``virt_lo`` are rows of ``dense`` and columns
+    from ``virt_lo + virt_n`` on are rows of ``dense`` shifted by ``virt_n``; in place, ONE launch
+    (include/dgsparse_hip.h: dgs_spmm_csr_acc_min_around_f32)."""
+    dev = _need_gpu(rowptr, col, values, dense, C, E, rowmap)
+    rowptr = _i32(rowptr, 'rowptr')
+    col = _i32(col, 'col')
+    dense = _f32mat(dense, 'dense')
+    M, nnz, (Kb, N) = rowptr.numel() - 1, col.numel(), dense.shape
+    if C.dtype != torch.float32 or C.dim() != 2 or C.shape[1] != N or not C.is_contiguous():
+        raise TypeError('dgsparse: C must be a contiguous float32 [rows, N] tensor')
+    if E.dtype != torch.int32 or E.shape != C.shape or not E.is_contiguous():
+        raise TypeError('dgsparse: E must be a contiguous int32 tensor with the shape of C')
+    rowmap = _i32(rowmap, 'rowmap')
+    if rowmap.numel() != M:
+        raise ValueError('dgsparse: rowmap needs one entry per row of A')
+    if not (0 <= int(virt_lo) <= Kb) or int(virt_n) < C.shape[0] or Kb + int(virt_n) >= 2 ** 31:
+        raise ValueError('dgsparse: virtual columns [virt_lo, virt_lo + virt_n) must start inside the dense rows and cover the rows of C')
+    values = _f32vec(values, 'values', nnz)
+    if plan is not None and (plan.M != M or plan.nnz != nnz or plan.col_ptr != col.data_ptr() or
+                             plan.rowptr_ptr != rowptr.data_ptr()):
+        raise ValueError('dgsparse: the plan was built for other (rowptr, col) arrays')
+    with _on_device(dev):
+        if plan is not None:
+            wsb = _lib.dgs_spmm_csr_plan_workspace_bytes(MIN, M, N, nnz, ctypes.byref(plan.info))
+        else:
+            wsb = _lib.dgs_spmm_csr_workspace_bytes(MIN, M, N, nnz)
+        ws = _new(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        _check(_lib.dgs_spmm_csr_acc_min_around_f32(M, Kb + int(virt_n), N, nnz, _p(rowptr), _p(col), _p(values), _p(dense),
+                                                    _p(C), _p(E), _p(rowmap), int(col_off), int(virt_lo), int(virt_n),
+                                                    _p(plan.buf) if plan is not None else None,
+                                                    ctypes.byref(plan.info) if plan is not None else None, _p(ws), wsb,
+                                                    _stream(dev)), 'spmm_acc_min_around')
     return C, E
 
 

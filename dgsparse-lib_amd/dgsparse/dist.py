@@ -30,6 +30,7 @@ order of a row's entries is never changed.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -274,6 +275,41 @@ class HaloPlan:
         return self._min_parts
 
 
+    def min_around(self):
+        """For the overlapped min in ONE accumulating launch (round 5; include/dgsparse_hip.h
+        dgs_spmm_csr_acc_min_around_f32): the halo matrix once more, in the id space [slots of lower ranks | one VIRTUAL column
+        per shard row | slots of higher ranks] = the global column order of a sorted shard row, every row that also has local
+        entries carrying the virtual entry (h_lo + shard row, weight 1) that stands for its local result.
+        Returns ((rowptr, ids, values | None), shard rows it touches, pos) with pos[i] = position of entry i in the halo
+        matrix's arrays, -1 for a virtual entry (how a caller-supplied ``val`` finds its way in)."""
+        if getattr(self, '_min_around', None) is None:
+            assert self.rows_sorted
+            rp, slot, v = self.rem
+            dev = slot.device
+            R = int(self.rem_rows.numel())
+            nl = int(self.loc[0].numel()) - 1
+            rpl = rp.long()
+            rrow = torch.repeat_interleave(torch.arange(R, device=dev), rpl[1:] - rpl[:-1])
+            sl = slot.long()
+            ids = torch.where(sl < self.h_lo, sl, sl + nl)
+            lrp = self.loc[0].long()
+            has_loc = (lrp[1:] - lrp[:-1])[self.rem_rows.long()] > 0  # per compact row
+            vrow = torch.nonzero(has_loc).view(-1)
+            arow = torch.cat([rrow, vrow])
+            aid = torch.cat([ids, self.h_lo + self.rem_rows.long()[vrow]])
+            apos = torch.cat([torch.arange(sl.numel(), device=dev), torch.full((vrow.numel(),), -1, dtype=torch.long, device=dev)])
+            order = torch.argsort(arow * (self.n_halo + nl + 1) + aid)  # keys are unique: (row, id)
+            aid, apos = aid[order], apos[order]
+            cnt = torch.bincount(arow, minlength=R)
+            rp2 = torch.zeros(R + 1, dtype=torch.int64, device=dev)
+            rp2[1:] = torch.cumsum(cnt, 0)
+            vals = None
+            if v is not None:
+                vals = torch.where(apos >= 0, v[apos.clamp(min=0)], torch.ones((), dtype=v.dtype, device=dev)).contiguous()
+            self._min_around = ((rp2.to(torch.int32), aid.to(torch.int32).contiguous(), vals), self.rem_rows, apos)
+        return self._min_around
+
+
 class _HipOps:
     """The product compute path: the HIP kernels through the C ABI (with cached locality plans per matrix)."""
 
@@ -312,6 +348,12 @@ class _HipOps:
         return self._c.spmm_acc_min(rowptr, col, val, B, C, E, rowmap, col_off, precedes,
                                     plan=self._plan(rowptr, col, B.shape[0], B.shape[1]))
 
+    def spmm_acc_min_around(self, rowptr, col, val, B, C, E, rowmap, col_off, virt_lo, virt_n):
+        """(C, E)[rowmap[r]] <- MIN over row r in row order, the old pair riding through the row as its virtual entry
+        (dgs_spmm_csr_acc_min_around_f32), in place, one launch."""
+        return self._c.spmm_acc_min_around(rowptr, col, val, B, C, E, rowmap, col_off, virt_lo, virt_n,
+                                           plan=self._plan(rowptr, col, B.shape[0] + virt_n, B.shape[1]))
+
     def min_redo(self, rowmap, C, E, flag, rowptr, col, val, B):
         """Rows rowmap of (C, E) recomputed sequentially over the whole shard IF flag != 0 (stream-ordered; the redo-only
         form of dgs_spmm_min_merge_f32)."""
@@ -346,10 +388,17 @@ class DistSpMM:
     exchange logic can be exercised on CPU/gloo with a stand-in compute back end (tests only)."""
 
     def __init__(self, part: RowPartition, n_feat: int, ops=None, group=None, overlap: bool = True,
-                 standalone: bool = False):
+                 standalone: bool = False, min_form: Optional[str] = None):
         self.part, self.N, self.group, self.overlap = part, n_feat, group, overlap
         self.standalone = standalone
         self.ops = ops if ops is not None else _HipOps()
+        # overlapped min after the exchange: 'around' = ONE accumulating launch (the local result a virtual entry of its row),
+        # 'two' = the round-3 form (lower-rank slots folded in front of it, higher-rank ones behind: two launches)
+        self.min_form = min_form or os.environ.get('DGS_DIST_MIN_FORM', 'around')
+        if self.min_form not in ('around', 'two'):
+            raise ValueError("min_form must be 'around' or 'two'")
+        if not hasattr(self.ops, 'spmm_acc_min_around'):
+            self.min_form = 'two'
         self.plan = HaloPlan(part, group, standalone)
         self.n_halo = self.plan.n_halo
         dev = part.col.device
@@ -452,9 +501,10 @@ class DistSpMM:
             self._last_E = None
             return C
         if self.overlap and p.world > 1 and not self.standalone and reduce == 'min' and plan.rows_sorted:
-            # min: the local (value, arg) while the halo travels; then the lower-rank halo entries are folded in FRONT of
-            # it and the higher-rank ones BEHIND it (MIN keeps the later operand's bits on a tie, so only in-order folds
-            # are exact; two accumulating launches).  MIN cannot be folded across a NaN product at all, so features and
+            # min: the local (value, arg) while the halo travels; then ONE accumulating launch over the halo entries in which
+            # the local result rides through each row as a virtual entry at the place of the local columns (min_form
+            # 'around', round 5) - or, 'two', the lower-rank halo entries folded in FRONT of it and the higher-rank ones
+            # BEHIND it by two launches (MIN keeps the later operand's bits on a tie, so only in-order folds are exact).  MIN cannot be folded across a NaN product at all, so features and
             # edge values are scanned for NaN / inf on the way (stream-ordered flag, no host sync) and the rows that have
             # remote entries are recomputed sequentially when the flag is up.  Cost of that guard: one scan of the local
             # features (under the exchange), one of the arrived halo, one of a caller-supplied ``val`` (the engine's own edge
@@ -480,10 +530,17 @@ class DistSpMM:
                 halo = B_ext[p.n_local:]
                 self.ops.nonfinite_flag(halo, flag)
                 vr = None if val is None else val[plan.nnz_pos_rem]
-                for (sub, rows, pos), first in zip(plan.min_parts(), (True, False)):
-                    if rows.numel() > 0:
-                        self.ops.spmm_acc_min(sub[0], sub[1], sub[2] if vr is None else vr[pos], halo, C, E, rows,
-                                              p.n_local, first)
+                if self.min_form == 'around' and p.n_local + self.n_halo < 2 ** 31 - 1:
+                    sub, rows, pos = plan.min_around()
+                    va = sub[2]
+                    if vr is not None:
+                        va = torch.where(pos >= 0, vr[pos.clamp(min=0)], torch.ones((), dtype=vr.dtype, device=vr.device))
+                    self.ops.spmm_acc_min_around(sub[0], sub[1], va, halo, C, E, rows, p.n_local, plan.h_lo, p.n_local)
+                else:
+                    for (sub, rows, pos), first in zip(plan.min_parts(), (True, False)):
+                        if rows.numel() > 0:
+                            self.ops.spmm_acc_min(sub[0], sub[1], sub[2] if vr is None else vr[pos], halo, C, E, rows,
+                                                  p.n_local, first)
                 self.ops.min_redo(plan.rem_rows, C, E, flag, p.rowptr, plan.col_ext, v_all, B_ext)
             self.last_E_ext = E
             self._last_E = None

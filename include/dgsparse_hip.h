@@ -271,6 +271,23 @@ int dgs_spmm_csr_acc_min_f32(int64_t M, int64_t K, int64_t N, int64_t nnz, const
                              const float *val, const float *B, float *C, int32_t *E, const int32_t *rowmap,
                              int32_t col_off, int32_t precedes, const void *plan, const dgsSpmmPlanInfo *info,
                              void *workspace, size_t workspace_bytes, dgsStream_t stream);
+/* Both sides in ONE launch (round 5, "around" form; new, multi-GPU path - the reference is single-device).  The
+ * matrix is written in the row order of the undivided row: [columns that precede | ONE virtual entry | columns that follow].
+ * It has K columns, of which the ids [virt_lo, virt_lo + virt_n) are VIRTUAL: entry (r, virt_lo + rowmap[r]) - weight 1 if
+ * val is given - stands for everything (C, E)[rowmap[r]] already cover, its "dense row" is that row of C, so the old value
+ * goes through the row's own MIN chain at its place and every tie rule (value bits of the LAST minimum, arg of the FIRST:
+ * include/cuda/spmm_cuda.cuh:38-41 with the MIN macro of include/gspmm.h:133-146) is the undivided row's own.  B has
+ * K - virt_n rows: column c < virt_lo is row c of B, c >= virt_lo + virt_n is row c - virt_n (a sorted shard row stays
+ * sorted, so a plan cuts it by column slice like any other).  Result: (C, E)[rowmap[r]] = the MIN over the whole row; E keeps
+ * what it held where the virtual entry is the first minimum, else the winner's B row + col_off.  A row without a virtual
+ * entry (its output holds the empty-row 0 / -1) replaces its output pair.  No two rows may share an output row, and only
+ * row r may name the virtual column virt_lo + rowmap[r]; ids must stay below 2^31.  In place: C is read (as virtual rows)
+ * and written by the same launch.  Exact unless a product is NaN, like the two-launch form. */
+int dgs_spmm_csr_acc_min_around_f32(int64_t M, int64_t K, int64_t N, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                                    const float *val, const float *B, float *C, int32_t *E, const int32_t *rowmap,
+                                    int32_t col_off, int32_t virt_lo, int32_t virt_n, const void *plan,
+                                    const dgsSpmmPlanInfo *info, void *workspace, size_t workspace_bytes,
+                                    dgsStream_t stream);
 
 /*
  * Masked SpMM = backward of max/min w.r.t. the dense operand, run on the CSC arrays of A:

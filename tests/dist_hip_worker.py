@@ -97,12 +97,13 @@ def main():
                 pc = dd.partition_csr(rp, col, vc, world)[rank]
                 pc.rowptr, pc.col = pc.rowptr.to(dev), pc.col.to(dev)
                 pc.val = None if pc.val is None else pc.val.to(dev)
-                ec = dd.DistSpMM(pc, N, overlap=True)
-                assert ec.plan.rows_sorted
-                Cc = ec.spmm(torch.from_numpy(Xc[r0:r1].copy()).to(dev), 'min')
                 Cg, Eg = oracle.spmm('min', rp, col, vc, Xc, fma=True)
-                assert_bitexact(Cc.cpu().numpy(), Cg[r0:r1], f'rank {rank}/{world} overlapped min, {name}: values')
-                assert_bitexact(ec.last_E.cpu().numpy(), Eg[r0:r1], f'rank {rank}/{world} overlapped min, {name}: E')
+                for form in ('around', 'two'):  # ONE accumulating launch after the exchange (round 5, the default) / two
+                    ec = dd.DistSpMM(pc, N, overlap=True, min_form=form)
+                    assert ec.plan.rows_sorted and ec.min_form == form
+                    Cc = ec.spmm(torch.from_numpy(Xc[r0:r1].copy()).to(dev), 'min')
+                    assert_bitexact(Cc.cpu().numpy(), Cg[r0:r1], f'rank {rank}/{world} overlapped min ({form}), {name}: values')
+                    assert_bitexact(ec.last_E.cpu().numpy(), Eg[r0:r1], f'rank {rank}/{world} overlapped min ({form}), {name}: E')
         remote = np.unique(col[s0:s1][(col[s0:s1] < r0) | (col[s0:s1] >= r1)])
         assert eng.n_halo == remote.shape[0] and eng.global_nnz == col.shape[0]
     torch.cuda.synchronize()

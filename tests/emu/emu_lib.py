@@ -240,3 +240,20 @@ def spmm_acc_min(rp, col, val, X, C, Ei, rowmap, col_off, precedes, plan=None):
                                     i32(col_off), i32(1 if precedes else 0), _p(plan[0]) if plan is not None else None,
                                     ctypes.byref(plan[1]) if plan is not None else None, _p(ws), ctypes.c_size_t(wsb), None)
     assert rc == 0, f'emu spmm_acc_min rc={rc}'
+
+
+def spmm_acc_min_around(rp, col, val, X, C, Ei, rowmap, col_off, virt_lo, virt_n, plan=None):
+    """dgs_spmm_csr_acc_min_around_f32: X holds the real dense rows only (K - virt_n of them)."""
+    L = lib()
+    M, nnz, (Kb, N) = rp.size - 1, col.size, X.shape
+    i64, i32 = ctypes.c_int64, ctypes.c_int32
+    if plan is not None:
+        wsb = L.dgs_spmm_csr_plan_workspace_bytes(MIN, i64(M), i64(N), i64(nnz), ctypes.byref(plan[1]))
+    else:
+        wsb = L.dgs_spmm_csr_workspace_bytes(MIN, i64(M), i64(N), i64(nnz))
+    ws = _buf(wsb)
+    rc = L.dgs_spmm_csr_acc_min_around_f32(i64(M), i64(Kb + virt_n), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C),
+                                           _p(Ei), _p(rowmap), i32(col_off), i32(virt_lo), i32(virt_n),
+                                           _p(plan[0]) if plan is not None else None,
+                                           ctypes.byref(plan[1]) if plan is not None else None, _p(ws), ctypes.c_size_t(wsb), None)
+    assert rc == 0, f'emu spmm_acc_min_around rc={rc}'

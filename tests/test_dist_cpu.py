@@ -64,6 +64,27 @@ class OracleOps:
         E[rowmap.long()] = torch.from_numpy(np.where(empty, en, me).astype(np.int32))
         return C, E
 
+    def spmm_acc_min_around(self, rowptr, col, val, B, C, E, rowmap, col_off, virt_lo, virt_n):
+        """numpy restatement of dgs_spmm_csr_acc_min_around_f32 (include/dgsparse_hip.h): the virtual columns
+        [virt_lo, virt_lo + virt_n) are the rows of C, spliced into the dense operand where their ids say; the winner's id is
+        mapped back to a B row (+ col_off), a winning virtual entry keeps the arg the output held."""
+        import oracle
+        dense = np.concatenate([B.numpy()[:virt_lo], C.numpy()[:virt_n], B.numpy()[virt_lo:]])
+        assert C.shape[0] <= virt_n
+        if C.shape[0] < virt_n:
+            dense = np.concatenate([B.numpy()[:virt_lo], C.numpy(), np.zeros((virt_n - C.shape[0], B.shape[1]), np.float32), B.numpy()[virt_lo:]])
+        Cr, Er = oracle.spmm(2, rowptr.numpy(), col.numpy(), None if val is None else val.numpy(), np.ascontiguousarray(dense))
+        rm = rowmap.long().numpy()
+        Eo = E.numpy()[rm]
+        live = np.diff(rowptr.numpy()) > 0
+        virt = (Er >= virt_lo) & (Er < virt_lo + virt_n)
+        assert (Er[virt] == (virt_lo + rm[:, None] + 0 * Er)[virt]).all(), 'a row may only name its own virtual column'
+        en = np.where(Er < 0, -1, np.where(Er < virt_lo, Er, Er - virt_n) + col_off)
+        en = np.where(virt, Eo, en).astype(np.int32)
+        C[rowmap.long()[torch.from_numpy(live)]] = torch.from_numpy(Cr[live])
+        E[rowmap.long()[torch.from_numpy(live)]] = torch.from_numpy(en[live])
+        return C, E
+
     def min_redo(self, rowmap, C, E, flag, rowptr, col, val, B):
         import oracle
         if int(flag[0]):
@@ -148,6 +169,18 @@ def _worker(rank, world, port, cols, q):
                 Co = eng_ov.spmm(torch.from_numpy(X[r0:r1].copy()), red)
                 res[red + '_overlap'] = bool(np.array_equal(Co.numpy().view(np.int32), Cg[r0:r1].view(np.int32)) and
                                              np.array_equal(eng_ov.last_E.numpy(), Eg[r0:r1]))
+            if red == 'min':  # both forms of the overlapped min: ONE accumulating launch ('around', the default) / two
+                assert eng_ov.min_form == 'around'
+                e2 = dd.DistSpMM(part, N, ops=OracleOps(), overlap=True, min_form='two')
+                Co = e2.spmm(torch.from_numpy(X[r0:r1].copy()), red)
+                res['min_overlap_two_launches'] = bool(np.array_equal(Co.numpy().view(np.int32), Cg[r0:r1].view(np.int32)) and
+                                                       np.array_equal(e2.last_E.numpy(), Eg[r0:r1]))
+                # a caller-supplied ``val`` finds its way into the around matrix (virtual entries keep weight 1)
+                v2 = np.roll(val, 7)
+                Co = eng_ov.spmm(torch.from_numpy(X[r0:r1].copy()), red, val=torch.from_numpy(v2[int(rp[r0]):int(rp[r1])].copy()))
+                Cv, Ev = oracle.spmm(red, rp, col, v2, X)
+                res['min_overlap_val_override'] = bool(np.array_equal(Co.numpy().view(np.int32), Cv[r0:r1].view(np.int32)) and
+                                                       np.array_equal(eng_ov.last_E.numpy(), Ev[r0:r1]))
         # overlapped min in its corners: signed zeros (MIN keeps the LATER operand's bits on a tie, E the first arg) and
         # NaN / inf features (MIN forgets what came before a NaN product: the merge must give way to the sequential redo)
         rng = np.random.default_rng(11)
@@ -158,11 +191,12 @@ def _worker(rank, world, port, cols, q):
         Xn[rng.integers(0, M, 40), rng.integers(0, N, 40)] = -np.inf
         for name, Xc, vc in (('zeros', Xz, val), ('zeros_noval', Xz, None), ('nonfinite', Xn, val)):
             pc = dd.partition_csr(rp, col, vc, world)[rank]
-            ec = dd.DistSpMM(pc, N, ops=OracleOps(), overlap=True)
-            Co = ec.spmm(torch.from_numpy(Xc[r0:r1].copy()), 'min')
             Cg, Eg = oracle.spmm('min', rp, col, vc, Xc)
-            res['min_overlap_' + name] = bool(np.array_equal(Co.numpy().view(np.int32), Cg[r0:r1].view(np.int32)) and
-                                              np.array_equal(ec.last_E.numpy(), Eg[r0:r1]))
+            for form in ('around', 'two'):
+                ec = dd.DistSpMM(pc, N, ops=OracleOps(), overlap=True, min_form=form)
+                Co = ec.spmm(torch.from_numpy(Xc[r0:r1].copy()), 'min')
+                res[f'min_overlap_{name}_{form}'] = bool(np.array_equal(Co.numpy().view(np.int32), Cg[r0:r1].view(np.int32)) and
+                                                         np.array_equal(ec.last_E.numpy(), Eg[r0:r1]))
         # backward of sum w.r.t. B through the reversed exchange == rows [r0,r1) of A^T G on the whole graph
         G = (np.random.default_rng(2).integers(-2, 3, (M, N)) / 4).astype(np.float32)
         Bl = torch.from_numpy(X[r0:r1].copy()).requires_grad_()

@@ -242,6 +242,112 @@ def test_accumulating_max_and_min_merge_column_subsets_exactly(graph, planned):
     assert_bitexact(Ei, Eo, 'merged min arg ids')
 
 
+def around_matrix(rp, col, val, deg, a, b, n_out, compact=True):
+    """The "around" form of the halo matrix for local columns [a, b) (dgs_spmm_csr_acc_min_around_f32): per row with a halo
+    entry [slots of the columns < a | virtual entry a + row, weight 1, if the row has a local entry | slots of the columns >= b,
+    shifted by n_out virtual ids].  Returns (rowptr, col, val, rows it touches); compact=False keeps every row (rows without halo
+    entries then hold their virtual entry alone, or nothing)."""
+    M = rp.size - 1
+    rows = np.repeat(np.arange(M), deg)
+    is_loc = (col >= a) & (col < b)
+    has_loc = np.bincount(rows[is_loc], minlength=M) > 0
+    has_rem = np.bincount(rows[~is_loc], minlength=M) > 0
+    keep = np.nonzero(has_rem)[0] if compact else np.arange(M)
+    nl = b - a
+    # the halo entries in the around id space, and the virtual entries of the kept rows that have local columns
+    hr, hc, hv = rows[~is_loc], col[~is_loc], val[~is_loc]
+    hid = np.where(hc < a, hc, hc - nl + n_out)  # slot = column without the local block; ids >= a + n_out follow the virtual block
+    vr = keep[has_loc[keep]]
+    ar = np.concatenate([hr, vr])
+    ac = np.concatenate([hid, a + vr])
+    av = np.concatenate([hv, np.ones(vr.size, np.float32)])
+    order = np.lexsort((ac, ar))
+    ar, ac, av = ar[order], ac[order], av[order]
+    cnt = np.bincount(ar, minlength=M)[keep]
+    rpp = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    return rpp, np.ascontiguousarray(ac.astype(np.int32)), np.ascontiguousarray(av.astype(np.float32)), keep.astype(np.int32)
+
+
+@pytest.mark.parametrize('planned', [False, True], ids=['plan-free', 'plan'])
+@pytest.mark.parametrize('data', ['ties', 'inf'])
+def test_accumulating_min_around_is_one_launch_and_exact(graph, planned, data):
+    """the multi-GPU min's halo part in ONE accumulating launch (dgs_spmm_csr_acc_min_around_f32).  The
+    local result rides through each row as a virtual entry at the place of the local columns, so rows of every class - short,
+    wave-cooperative, cut into units and folded (in the launch or by the combine kernel), with and without a plan - reproduce
+    algorithm 0 on the undivided row bit for bit: values (the LAST minimum's bits: +-0 ties) and arg ids (the FIRST minimum),
+    ties everywhere; 'inf': +inf features send elements through the in-kernel sequential redo, which walks the virtual entry
+    too.  Rows without local columns replace the empty-row pair, rows without halo entries are not touched."""
+    rp, col, _, K, deg = graph
+    M, N = rp.size - 1, 16
+    a, b = K // 3, K // 3 + K // 4
+    nl = b - a
+    rng = np.random.default_rng(3)
+    if data == 'ties':
+        val = (rng.integers(0, 3, col.size) / 10).astype(np.float32)
+        X = (np.random.default_rng(9).integers(-2, 3, (K, N)) / 4).astype(np.float32)
+        X[X == 0] = np.where(np.random.default_rng(10).random((X == 0).sum()) < 0.5, np.float32(-0.0), np.float32(0.0))
+    else:
+        val = (rng.integers(1, 3, col.size) / 10).astype(np.float32)
+        X = (np.random.default_rng(9).integers(-2, 3, (K, N)) / 4).astype(np.float32)
+        X[np.random.default_rng(11).random(X.shape) < 0.002] = np.inf
+    ext = np.where((col >= a) & (col < b), col - a, np.where(col < a, nl + col, col)).astype(np.int32)
+    Xe = np.ascontiguousarray(np.concatenate([X[a:b], X[:a], X[b:]]))
+    Co, Eo = oracle.spmm('min', rp, ext, val, Xe)
+    rows = np.repeat(np.arange(M), deg)
+    is_loc = (col >= a) & (col < b)
+    cnt = np.bincount(rows[is_loc], minlength=M)
+    lrp = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    C, Ei = E.spmm(E.MIN, lrp, np.ascontiguousarray(ext[is_loc]), np.ascontiguousarray(val[is_loc]), np.ascontiguousarray(Xe[:nl]))
+    arp, acol, aval, arows = around_matrix(rp, col, val, deg, a, b, M, compact=False)  # (all 66 000 rows: the general schedule)
+    Xh = np.ascontiguousarray(Xe[nl:])
+    assert E.schedule(E.MIN, arp.size - 1, Xh.shape[0] + M, N, acol.size) == 'rows'
+    assert acol.max() < Xh.shape[0] + M and (np.diff(acol)[np.diff(np.repeat(np.arange(arows.size), np.diff(arp))) == 0] > 0).all(), \
+        'around rows stay sorted'
+    plan = None
+    if planned:
+        plan = E.spmm_plan(arp, acol, Xh.shape[0] + M)
+        assert plan[1].n_long > 0
+    untouched = np.diff(arp) == 0
+    before = C.copy(), Ei.copy()
+    E.launch_log()
+    E.spmm_acc_min_around(arp, acol, aval, Xh, C, Ei, arows, nl, a, M, plan=plan)
+    log = [k for k, _, _ in E.launch_log()]
+    assert sum('spmm_fused' in k for k in log) == 1 and not any('spmm_small' in k for k in log), log
+    assert_bitexact(C, Co, 'min values, around form')
+    assert_bitexact(Ei, Eo, 'min arg ids, around form')
+    assert np.array_equal(C[untouched].view(np.int32), before[0][untouched].view(np.int32)) and np.array_equal(Ei[untouched], before[1][untouched])
+
+
+def test_accumulating_min_around_on_the_single_launch_kernel():
+    """The same through spmm_small (<= 2^16 rows and 2^18 nnz): long rows are wave-cooperative there, nothing is cut."""
+    rng = np.random.default_rng(5)
+    M, K, N = 3000, 900, 20
+    deg = rng.integers(0, 6, M)
+    deg[7], deg[1500], deg[2999] = 700, 300, 90
+    rp = np.zeros(M + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    col = np.concatenate([np.sort(rng.choice(K, d, replace=False)) for d in deg]).astype(np.int32)
+    val = (rng.integers(0, 3, col.size) / 10).astype(np.float32)
+    X = (rng.integers(-2, 3, (K, N)) / 4).astype(np.float32)
+    for a, b in ((300, 600), (0, 400), (500, 900), (0, 900), (450, 450)):  # halo on both sides / only behind / only in front / none / no local columns
+        nl = b - a
+        ext = np.where((col >= a) & (col < b), col - a, np.where(col < a, nl + col, col)).astype(np.int32)
+        Xe = np.ascontiguousarray(np.concatenate([X[a:b], X[:a], X[b:]]))
+        Co, Eo = oracle.spmm('min', rp, ext, val, Xe)
+        rows = np.repeat(np.arange(M), deg)
+        is_loc = (col >= a) & (col < b)
+        lrp = np.concatenate([[0], np.cumsum(np.bincount(rows[is_loc], minlength=M))]).astype(np.int32)
+        if nl:
+            C, Ei = E.spmm(E.MIN, lrp, np.ascontiguousarray(ext[is_loc]), np.ascontiguousarray(val[is_loc]), np.ascontiguousarray(Xe[:nl]))
+        else:
+            C, Ei = np.zeros((M, N), np.float32), np.full((M, N), -1, np.int32)
+        arp, acol, aval, arows = around_matrix(rp, col, val, deg, a, b, M)
+        if acol.size:
+            E.spmm_acc_min_around(arp, acol, aval, np.ascontiguousarray(Xe[nl:]), C, Ei, arows, nl, a, M)
+        assert_bitexact(C, Co, f'min values, around form, local columns [{a}, {b})')
+        assert_bitexact(Ei, Eo, f'min arg ids, around form, local columns [{a}, {b})')
+
+
 @pytest.mark.parametrize('order', ['rev', 'rand:7'])
 def test_hub_rows_under_other_fiber_schedules(order):
     """Between two barriers a fiber runs undisturbed, so ONE fixed fiber order can hide a missing barrier between waves (the

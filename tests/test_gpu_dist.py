@@ -168,7 +168,7 @@ def test_bench_partitioned_path_under_the_launcher():
                                                (3000, 8, 1200, 1200, True), (3000, 64, 0, 3000, True),
                                                (70000, 32, 20000, 50000, True), (70000, 12, 30000, 45000, False)])
 def test_min_merge_and_nonfinite_flag_through_the_c_abi(M, N, lo, hi, has_val):
-    """dgs_spmm_csr_acc_min_f32 / dgs_spmm_min_merge_f32 / dgs_nonfinite_flag_f32 on their own: a matrix whose columns are
+    """dgs_spmm_csr_acc_min_f32 / _acc_min_around_f32 / dgs_spmm_min_merge_f32 / dgs_nonfinite_flag_f32 on their own: a matrix whose columns are
     cut in three ranges [lower | local | higher] the way a shard of dgsparse.dist is, every row's min put together from
     the three products - (a) lower folded in front of and higher behind the local result by the accumulating kernels, (b)
     the two halo halves computed apart and folded by the merge kernel - and compared bit for bit with the one-pass kernel
@@ -253,6 +253,31 @@ def test_min_merge_and_nonfinite_flag_through_the_c_abi(M, N, lo, hi, has_val):
             _capi.spmm_min_merge(t(rem_rows), None, None, None, 0, None, C, E, flag, full_rp, full_col, full_val, Bd)
         assert_bitexact(C.cpu().numpy(), Cref, f'accumulated min values (flag {force})')
         assert_bitexact(E.cpu().numpy(), Eref, f'accumulated min E (flag {force})')
+    # (c) round 5, dgsparse.dist's default: ONE accumulating launch, the local result a virtual entry of its row
+    # (dgs_spmm_csr_acc_min_around_f32; ids: lower slots | lo + shard row | higher slots + M), plan-free and over a plan
+    if R:
+        hr, hs = rows[~is_loc], ext[~is_loc] - nl  # halo entries: row, slot (lower ranks' slots are [0, lo))
+        has_loc = np.diff(lrp)[rem_rows] > 0
+        vr = rem_rows[has_loc].astype(np.int64)
+        ar = np.concatenate([hr, vr])
+        ac = np.concatenate([np.where(hs < lo, hs, hs + M), lo + vr])
+        order = np.lexsort((ac, ar))
+        arp = np.zeros(R + 1, np.int32)
+        arp[1:] = np.cumsum(np.bincount(ar, minlength=M)[rem_rows])
+        acol = ac[order].astype(np.int32)
+        aval = None if val is None else np.concatenate([val[~is_loc], np.ones(vr.shape[0], np.float32)])[order]
+        arp_d, acol_d = t(arp), t(acol)
+        for force in (0, 1):
+            flag = torch.full((1,), force, dtype=torch.int32, device=dev)
+            if nl > 0:
+                C, E = _capi.spmm(_capi.MIN, t(lrp), t(lcol), t(lval), Bd[:nl])
+            else:
+                C, E = torch.zeros((M, N), device=dev), torch.full((M, N), -1, dtype=torch.int32, device=dev)
+            plan = _capi.spmm_plan(arp_d, acol_d, K - nl + M, N) if (M > 3000 and force) else None
+            _capi.spmm_acc_min_around(arp_d, acol_d, t(aval), Bd[nl:], C, E, t(rem_rows), nl, lo, M, plan=plan)
+            _capi.spmm_min_merge(t(rem_rows), None, None, None, 0, None, C, E, flag, full_rp, full_col, full_val, Bd)
+            assert_bitexact(C.cpu().numpy(), Cref, f'around-form min values (flag {force})')
+            assert_bitexact(E.cpu().numpy(), Eref, f'around-form min E (flag {force})')
     # the detector: clean data leaves the flag alone; one NaN / inf anywhere (any alignment, head, tail) raises it
     for off in (0, 1, 3):
         x = torch.rand(100003, device=dev)[off:].contiguous() if off == 0 else torch.rand(100003 + off, device=dev)[off:]
