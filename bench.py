@@ -358,7 +358,9 @@ def main():
                 step, planned = make_step(rp, col, val, X)
                 C, _ = step()
                 worst = self_check(C)
-            assert worst < 1e-5, f'bench self-check failed: rel err {worst} (in units of the bar: 1e-5, 4e-5 on chained rows)'
+            if not worst < 1e-5:  # wrong results are REPORTED with the number, loudly - a line beats a traceback for whoever reads the run
+                extra['parity_failed'] = f'bench self-check FAILED: scaled rel err {worst} (in units of the bar: 1e-5, 4e-5 on chained rows); the value below is of a WRONG result'
+                print('bench.py: ' + extra['parity_failed'], file=sys.stderr)
             extra['self_check_max_rel_err_vs_fp64'] = worst
             extra['self_check_bar'] = ('value above is in units of the bar per row: rel. error vs an fp64 gather-sum / 1.0 for rows the '
                                        'schedule folds with a tree (bar 1e-5), / 4.0 for rows it CHAINS sequentially (hub rows, strict '
@@ -479,126 +481,132 @@ def main():
         except Exception:
             pass
 
-    if not a.no_protocol and not use_dist:
-        # median of 5 repeats of K launches between HIP events; unit weights; seeds 1..4
-        reps = sorted(event_ms(step, a.steps) for _ in range(5))
-        prot = {'repeats_ms': [round(x, 5) for x in reps], 'median_ms': round(reps[2], 5),
-                'median_frac': round(b_alg / (reps[2] / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
-        ones = torch.ones_like(val)
-        step1, _ = make_step(rp, col, ones, X)
-        step1()
-        prot['unit_weights_ms'] = round(sorted(event_ms(step1, max(10, a.steps // 5)) for _ in range(3))[1], 5)
-        del ones, step1
-        seeds = {}
-        for s in range(5):
-            if s == a.seed:
-                seeds[str(s)] = dict(ms=prot['median_ms'], nnz=int(nnz_total))
-                continue
-            rp2, col2, st2, val2, X2 = make_graph(s)
-            st2p, _ = make_step(rp2, col2, val2, X2)
-            C2, _ = st2p()
-            seeds[str(s)] = dict(ms=round(sorted(event_ms(st2p, max(10, a.steps // 5)) for _ in range(3))[1], 5),
-                                 nnz=int(st2['nnz']))
-            if a.reduce == 'sum' and not a.no_cpu_baseline:
-                # the 1e-5 claim is a property of the schedule, not of seed 0 (VERDICT r4 #2a): every element of every seed
-                # against the reference's sequential chain (the oracle's mul-add chain, pinned bit for bit to
-                # spmm_reference_host by tests/test_oracle_pin.py, on all host cores)
-                seeds[str(s)]['parity'] = parity_vs_sequential(C2.cpu().numpy(), rp2.cpu().numpy(), col2.cpu().numpy(),
-                                                               val2.cpu().numpy(), X2.cpu().numpy())
-            del rp2, col2, val2, X2, st2p, C2
-        prot['seeds'] = seeds
-        res['protocol'] = prot
-        if planned:
-            # the in-kernel fold of partial rows (round 5; on where the device self-test passed) next to the combine launch it
-            # replaces, on the same tensors: DGS_FOLD = 1 / 0 for one measurement each, then back to the process's own setting
-            had = os.environ.get('DGS_FOLD')
-            fd = dict(gate=_capi.fold_gate(), default_on=bool((had not in (None, '')) and had != '0') if had not in (None, '') else _capi.fold_gate() > 0)
-            for name, v in (('on_ms', '1'), ('off_ms', '0')):
-                os.environ['DGS_FOLD'] = v
+    try:  # a side leg must never lose the line (first hardware contact of a schedule may be this very run)
+        if not a.no_protocol and not use_dist:
+            # median of 5 repeats of K launches between HIP events; unit weights; seeds 1..4
+            reps = sorted(event_ms(step, a.steps) for _ in range(5))
+            prot = {'repeats_ms': [round(x, 5) for x in reps], 'median_ms': round(reps[2], 5),
+                    'median_frac': round(b_alg / (reps[2] / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
+            ones = torch.ones_like(val)
+            step1, _ = make_step(rp, col, ones, X)
+            step1()
+            prot['unit_weights_ms'] = round(sorted(event_ms(step1, max(10, a.steps // 5)) for _ in range(3))[1], 5)
+            del ones, step1
+            seeds = {}
+            for s in range(5):
+                if s == a.seed:
+                    seeds[str(s)] = dict(ms=prot['median_ms'], nnz=int(nnz_total))
+                    continue
+                rp2, col2, st2, val2, X2 = make_graph(s)
+                st2p, _ = make_step(rp2, col2, val2, X2)
+                C2, _ = st2p()
+                seeds[str(s)] = dict(ms=round(sorted(event_ms(st2p, max(10, a.steps // 5)) for _ in range(3))[1], 5),
+                                     nnz=int(st2['nnz']))
+                if a.reduce == 'sum' and not a.no_cpu_baseline:
+                    # the 1e-5 claim is a property of the schedule, not of seed 0 (VERDICT r4 #2a): every element of every seed
+                    # against the reference's sequential chain (the oracle's mul-add chain, pinned bit for bit to
+                    # spmm_reference_host by tests/test_oracle_pin.py, on all host cores)
+                    seeds[str(s)]['parity'] = parity_vs_sequential(C2.cpu().numpy(), rp2.cpu().numpy(), col2.cpu().numpy(),
+                                                                   val2.cpu().numpy(), X2.cpu().numpy())
+                del rp2, col2, val2, X2, st2p, C2
+            prot['seeds'] = seeds
+            res['protocol'] = prot
+            if planned:
+                # the in-kernel fold of partial rows (round 5; on where the device self-test passed) next to the combine launch it
+                # replaces, on the same tensors: DGS_FOLD = 1 / 0 for one measurement each, then back to the process's own setting
+                had = os.environ.get('DGS_FOLD')
+                fd = dict(gate=_capi.fold_gate(), default_on=bool((had not in (None, '')) and had != '0') if had not in (None, '') else _capi.fold_gate() > 0)
+                for name, v in (('on_ms', '1'), ('off_ms', '0')):
+                    os.environ['DGS_FOLD'] = v
+                    _capi.reload_tuning()
+                    stepf, _ = make_step(rp, col, val, X)
+                    stepf()
+                    fd[name] = round(sorted(event_ms(stepf, max(10, a.steps // 5)) for _ in range(3))[1], 5)
+                    del stepf
+                if had is None:
+                    os.environ.pop('DGS_FOLD')
+                else:
+                    os.environ['DGS_FOLD'] = had
                 _capi.reload_tuning()
-                stepf, _ = make_step(rp, col, val, X)
-                stepf()
-                fd[name] = round(sorted(event_ms(stepf, max(10, a.steps // 5)) for _ in range(3))[1], 5)
-                del stepf
-            if had is None:
-                os.environ.pop('DGS_FOLD')
-            else:
-                os.environ['DGS_FOLD'] = had
-            _capi.reload_tuning()
-            fd['note'] = 'fold on: one kernel launch per planned call (+ a memset of 4 B per long row); off: fused + combine'
-            res['fold'] = fd
-        if '+hub' in res.get('schedule', ''):
-            # what the hub chains cost next to the tree on the same tensors (the decision rule needs both numbers
-            # in every line): DGS_HUB_CHAIN=0 for one measurement, then back to what this process was started with
-            had = os.environ.get('DGS_HUB_CHAIN')
-            os.environ['DGS_HUB_CHAIN'] = '0'
-            _capi.reload_tuning()
-            step0, _ = make_step(rp, col, val, X)
-            step0()
-            off_ms = sorted(event_ms(step0, max(10, a.steps // 5)) for _ in range(3))[1]
-            del step0
-            if had is None:
-                os.environ.pop('DGS_HUB_CHAIN')
-            else:
-                os.environ['DGS_HUB_CHAIN'] = had
-            _capi.reload_tuning()
-            res['hub_chain'].update(on_ms=prot['median_ms'], off_ms=round(off_ms, 5),
-                                    cost_frac=round(prot['median_ms'] / off_ms - 1.0, 4),
-                                    rule='chains stay the default while they cost <= 5 % over the tree (DESIGN.md 4.1g)')
+                fd['note'] = 'fold on: one kernel launch per planned call (+ a memset of 4 B per long row); off: fused + combine'
+                res['fold'] = fd
+            if '+hub' in res.get('schedule', ''):
+                # what the hub chains cost next to the tree on the same tensors (the decision rule needs both numbers
+                # in every line): DGS_HUB_CHAIN=0 for one measurement, then back to what this process was started with
+                had = os.environ.get('DGS_HUB_CHAIN')
+                os.environ['DGS_HUB_CHAIN'] = '0'
+                _capi.reload_tuning()
+                step0, _ = make_step(rp, col, val, X)
+                step0()
+                off_ms = sorted(event_ms(step0, max(10, a.steps // 5)) for _ in range(3))[1]
+                del step0
+                if had is None:
+                    os.environ.pop('DGS_HUB_CHAIN')
+                else:
+                    os.environ['DGS_HUB_CHAIN'] = had
+                _capi.reload_tuning()
+                res['hub_chain'].update(on_ms=prot['median_ms'], off_ms=round(off_ms, 5),
+                                        cost_frac=round(prot['median_ms'] / off_ms - 1.0, 4),
+                                        rule='chains stay the default while they cost <= 5 % over the tree (DESIGN.md 4.1g)')
+    except Exception as e:  # noqa: BLE001
+        res.setdefault('leg_errors', {})['protocol_fold_hub'] = repr(e)
 
     C_strict = {}
-    if not a.no_protocol and not use_dist:
-        # what the plan costs and what it buys: blocking C-ABI build incl. compaction, and the plan-free step
-        if planned:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            _capi.spmm_plan(rp, col, K, N, force=(a.plan == 1))
-            torch.cuda.synchronize()
-            build_ms = (time.perf_counter() - t0) * 1e3
-            pfree = sorted(event_ms(lambda: _capi.spmm(op, rp, col, val, X), max(10, a.steps // 5)) for _ in range(3))[1]
-            res['plan'] = dict(build_ms_blocking=round(build_ms, 3), planfree_ms_per_step=round(pfree, 5),
-                               planned_ms_per_step=res['protocol']['median_ms'],
-                               calls_to_break_even_blocking=round(build_ms / max(pfree - res['protocol']['median_ms'], 1e-6), 1),
-                               note='dgsparse.Storage queues the build on the caller\'s stream at the 4th use of a matrix '
-                                    '(DGS_PLAN_AFTER), with provisional counts and no host synchronisation (DESIGN.md 4.1d)')
-        # the strict-order schedule on the same tensors (opt-in `algorithm` bits): time + full parity in cpu_baseline
-        if a.reduce in ('sum', 'mean'):
-            sd = {}
-            plan_s = _capi.spmm_plan(rp, col, K, N, force=(a.plan == 1)) if planned else None
-            for mode, alg in (('fma', _capi.ALG_STRICT_SUM), ('nofma', _capi.ALG_STRICT_NOFMA)):
-                fn = (lambda alg=alg: _capi.spmm(op, rp, col, val, X, algorithm=alg, plan=plan_s))
-                Cs, _ = fn()
-                if a.reduce == 'sum' and not a.no_cpu_baseline:
-                    C_strict[mode] = Cs.cpu().numpy()
-                del Cs
-                ms_s = sorted(event_ms(fn, max(10, a.steps // 5)) for _ in range(3))[1]
-                sd[mode] = dict(ms_per_step=round(ms_s, 5), gflops=round(flops / (ms_s / 1e3) / 1e9, 1),
-                                frac=round(b_alg / (ms_s / 1e3) / 1e9 / HBM_PEAK_GBS, 4))
-            sd['algorithm_bits'] = dict(fma=hex(_capi.ALG_STRICT_SUM), nofma=hex(_capi.ALG_STRICT_NOFMA))
-            sd['over_the_plan'] = plan_s is not None
-            res['strict'] = sd
-        # the PUBLIC operator on the same graph (reference harness times this: benchmark/bench_spmm_time.py:35-45)
-        try:
-            fnp = {'sum': dgsparse.spmm_sum, 'mean': dgsparse.spmm_mean, 'max': dgsparse.spmm_max, 'min': dgsparse.spmm_min}[a.reduce]
-            A_pub = dgsparse.SparseTensor(rowptr=rp, col=col, values=val, has_value=True)
-            A_pub.storage.spmm_plan('csr', N, wait=True)
-            A_pub.storage.spmm_plan('csc', N, wait=True)
-            with torch.no_grad():
-                fnp(A_pub, X, 0)
-                pub_ng = sorted(event_ms(lambda: fnp(A_pub, X, 0), max(10, a.steps // 5)) for _ in range(3))[1]
-            Xg = X.clone().requires_grad_()
+    try:  # a side leg must never lose the line (first hardware contact of a schedule may be this very run)
+        if not a.no_protocol and not use_dist:
+            # what the plan costs and what it buys: blocking C-ABI build incl. compaction, and the plan-free step
+            if planned:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _capi.spmm_plan(rp, col, K, N, force=(a.plan == 1))
+                torch.cuda.synchronize()
+                build_ms = (time.perf_counter() - t0) * 1e3
+                pfree = sorted(event_ms(lambda: _capi.spmm(op, rp, col, val, X), max(10, a.steps // 5)) for _ in range(3))[1]
+                res['plan'] = dict(build_ms_blocking=round(build_ms, 3), planfree_ms_per_step=round(pfree, 5),
+                                   planned_ms_per_step=res['protocol']['median_ms'],
+                                   calls_to_break_even_blocking=round(build_ms / max(pfree - res['protocol']['median_ms'], 1e-6), 1),
+                                   note='dgsparse.Storage queues the build on the caller\'s stream at the 4th use of a matrix '
+                                        '(DGS_PLAN_AFTER), with provisional counts and no host synchronisation (DESIGN.md 4.1d)')
+            # the strict-order schedule on the same tensors (opt-in `algorithm` bits): time + full parity in cpu_baseline
+            if a.reduce in ('sum', 'mean'):
+                sd = {}
+                plan_s = _capi.spmm_plan(rp, col, K, N, force=(a.plan == 1)) if planned else None
+                for mode, alg in (('fma', _capi.ALG_STRICT_SUM), ('nofma', _capi.ALG_STRICT_NOFMA)):
+                    fn = (lambda alg=alg: _capi.spmm(op, rp, col, val, X, algorithm=alg, plan=plan_s))
+                    Cs, _ = fn()
+                    if a.reduce == 'sum' and not a.no_cpu_baseline:
+                        C_strict[mode] = Cs.cpu().numpy()
+                    del Cs
+                    ms_s = sorted(event_ms(fn, max(10, a.steps // 5)) for _ in range(3))[1]
+                    sd[mode] = dict(ms_per_step=round(ms_s, 5), gflops=round(flops / (ms_s / 1e3) / 1e9, 1),
+                                    frac=round(b_alg / (ms_s / 1e3) / 1e9 / HBM_PEAK_GBS, 4))
+                sd['algorithm_bits'] = dict(fma=hex(_capi.ALG_STRICT_SUM), nofma=hex(_capi.ALG_STRICT_NOFMA))
+                sd['over_the_plan'] = plan_s is not None
+                res['strict'] = sd
+            # the PUBLIC operator on the same graph (reference harness times this: benchmark/bench_spmm_time.py:35-45)
+            try:
+                fnp = {'sum': dgsparse.spmm_sum, 'mean': dgsparse.spmm_mean, 'max': dgsparse.spmm_max, 'min': dgsparse.spmm_min}[a.reduce]
+                A_pub = dgsparse.SparseTensor(rowptr=rp, col=col, values=val, has_value=True)
+                A_pub.storage.spmm_plan('csr', N, wait=True)
+                A_pub.storage.spmm_plan('csc', N, wait=True)
+                with torch.no_grad():
+                    fnp(A_pub, X, 0)
+                    pub_ng = sorted(event_ms(lambda: fnp(A_pub, X, 0), max(10, a.steps // 5)) for _ in range(3))[1]
+                Xg = X.clone().requires_grad_()
 
-            def fb():
-                o = fnp(A_pub, Xg, 0)
-                o.backward(o)
-                Xg.grad = None
-            fb()
-            pub_fb = sorted(event_ms(fb, max(5, a.steps // 10)) for _ in range(3))[1]
-            res['public_api_ms'] = dict(op=f'dgsparse.spmm_{a.reduce}', no_grad=round(pub_ng, 5), fwd_bwd_dense_grad=round(pub_fb, 5),
-                                        c_abi_step=res['protocol']['median_ms'])
-            del A_pub, Xg
-        except Exception as e:  # noqa: BLE001
-            res['public_api_ms'] = dict(error=repr(e))
+                def fb():
+                    o = fnp(A_pub, Xg, 0)
+                    o.backward(o)
+                    Xg.grad = None
+                fb()
+                pub_fb = sorted(event_ms(fb, max(5, a.steps // 10)) for _ in range(3))[1]
+                res['public_api_ms'] = dict(op=f'dgsparse.spmm_{a.reduce}', no_grad=round(pub_ng, 5), fwd_bwd_dense_grad=round(pub_fb, 5),
+                                            c_abi_step=res['protocol']['median_ms'])
+                del A_pub, Xg
+            except Exception as e:  # noqa: BLE001
+                res['public_api_ms'] = dict(error=repr(e))
+    except Exception as e:  # noqa: BLE001
+        res.setdefault('leg_errors', {})['plan_strict_public_api'] = repr(e)
 
     if pg and use_dist and not a.no_worst_case:
         # the same step on the exchange's worst case: uniform random columns, no locality (every edge leaves its
@@ -624,18 +632,21 @@ def main():
         except Exception as e:  # noqa: BLE001
             res['worst_case'] = dict(error=repr(e))
 
-    if a.sweep and not use_dist and rank == 0:
-        sw = {}
-        for n2, red in ((32, 'sum'), (128, 'sum'), (64, 'max'), (64, 'mean')):
-            X2 = torch.rand((K, n2), device=dev)
-            o2 = {'sum': _capi.SUM, 'max': _capi.MAX, 'mean': _capi.MEAN}[red]
-            plan2 = _capi.spmm_plan(rp, col, K, n2) if (a.plan != 0 and hasattr(_capi, 'spmm_plan')) else None
-            kw = dict(plan=plan2) if plan2 is not None else {}
-            w2, e2 = time_steps(lambda: _capi.spmm(o2, rp, col, val, X2, **kw), 50, 10, False)  # 20 + 3 read 4 % slow (fresh operand, short run)
-            b2 = alg_bytes_spmm(Mloc, K, n2, nnz_total, True, red == 'max')
-            sw[f'{red}_feat{n2}'] = dict(gflops=round(2.0 * nnz_total * n2 / (w2 / 50) / 1e9, 1),
-                                         gbs=round(b2 / (e2 / 50) / 1e9, 1), frac=round(b2 / (e2 / 50) / 1e9 / HBM_PEAK_GBS, 4))
-        res['sweep'] = sw
+    try:  # a side leg must never lose the line (first hardware contact of a schedule may be this very run)
+        if a.sweep and not use_dist and rank == 0:
+            sw = {}
+            for n2, red in ((32, 'sum'), (128, 'sum'), (64, 'max'), (64, 'mean')):
+                X2 = torch.rand((K, n2), device=dev)
+                o2 = {'sum': _capi.SUM, 'max': _capi.MAX, 'mean': _capi.MEAN}[red]
+                plan2 = _capi.spmm_plan(rp, col, K, n2) if (a.plan != 0 and hasattr(_capi, 'spmm_plan')) else None
+                kw = dict(plan=plan2) if plan2 is not None else {}
+                w2, e2 = time_steps(lambda: _capi.spmm(o2, rp, col, val, X2, **kw), 50, 10, False)  # 20 + 3 read 4 % slow (fresh operand, short run)
+                b2 = alg_bytes_spmm(Mloc, K, n2, nnz_total, True, red == 'max')
+                sw[f'{red}_feat{n2}'] = dict(gflops=round(2.0 * nnz_total * n2 / (w2 / 50) / 1e9, 1),
+                                             gbs=round(b2 / (e2 / 50) / 1e9, 1), frac=round(b2 / (e2 / 50) / 1e9 / HBM_PEAK_GBS, 4))
+            res['sweep'] = sw
+    except Exception as e:  # noqa: BLE001
+        res.setdefault('leg_errors', {})['sweep'] = repr(e)
 
     if rank == 0 and not use_dist and not a.no_dense:
         # side figure (extra key, not the metric): the dense-graph configuration of BASELINE.json (C3), which takes the

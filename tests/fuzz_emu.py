@@ -16,7 +16,7 @@ for p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'emu'))
 import emu_lib as E  # noqa: E402
 import oracle  # noqa: E402
 from bench import graphgen  # noqa: E402
-from util import assert_bitexact, assert_sum_parity  # noqa: E402
+from util import around_matrix, assert_bitexact, assert_sum_parity  # noqa: E402
 
 OPS = {'sum': E.SUM, 'max': E.MAX, 'min': E.MIN, 'mean': E.MEAN}
 
@@ -49,7 +49,9 @@ def one_case(rng, it):
         rp = np.zeros(M + 1, np.int32)
         rp[1:] = np.cumsum(lens0)
         st = dict(st, max_deg=int(lens0.max()))
+    shuffled = False
     if rng.integers(0, 3) == 0 and col.shape[0]:
+        shuffled = True
         col = col.copy()
         for r in rng.integers(0, M, 8):
             rng.shuffle(col[rp[r]:rp[r + 1]])
@@ -94,6 +96,31 @@ def one_case(rng, it):
                     if plan is not None:  # round 5: the same chains over the plan's strict table (one launch)
                         Cp = E.spmm_ex(OPS[reduce], rp, col, val, X, algorithm=alg, plan=plan)
                         assert_bitexact(Cp, Cs, f'{tag} strict over the plan {reduce} fma={fma}')
+    if not shuffled and K >= 2 and col.shape[0] and val is not None and rng.integers(0, 2):
+        # round 5: the multi-GPU min's halo part in ONE accumulating launch (dgs_spmm_csr_acc_min_around_f32): columns cut in
+        # [lower | local | higher] at random, the local result a virtual entry of its row; == algorithm 0 on the undivided row
+        a = int(rng.integers(0, K))
+        b = int(rng.integers(a, K + 1))
+        nl = b - a
+        ext = np.where((col >= a) & (col < b), col - a, np.where(col < a, nl + col, col)).astype(np.int32)
+        Xe = np.ascontiguousarray(np.concatenate([X[a:b], X[:a], X[b:]]))
+        Co, Eo = oracle.spmm('min', rp, ext, val, Xe, fma=True)
+        is_loc = (col >= a) & (col < b)
+        rows_of = np.repeat(np.arange(M), lens)
+        lrp = np.concatenate([[0], np.cumsum(np.bincount(rows_of[is_loc], minlength=M))]).astype(np.int32)
+        if nl and is_loc.any():
+            C, Ee = E.spmm(E.MIN, lrp, np.ascontiguousarray(ext[is_loc]), np.ascontiguousarray(val[is_loc]), np.ascontiguousarray(Xe[:nl]))
+        else:
+            C, Ee = np.zeros((M, N), np.float32), np.full((M, N), -1, np.int32)
+        arp, acol, aval, arows = around_matrix(rp, col, val, lens, a, b, M, compact=bool(rng.integers(0, 2)))
+        if acol.size:
+            Xh = np.ascontiguousarray(Xe[nl:]) if K - nl else np.zeros((1, N), np.float32)
+            aplan = None
+            if E.schedule(E.MIN, arp.size - 1, Xh.shape[0] + M, N, acol.size) == 'rows' and rng.integers(0, 2):
+                aplan = E.spmm_plan(arp, acol, Xh.shape[0] + M)
+            E.spmm_acc_min_around(arp, acol, aval, Xh, C, Ee, arows, nl, a, M, plan=aplan)
+        assert_bitexact(C, Co, f'{tag} min around [{a}, {b}) values')
+        assert_bitexact(Ee, Eo, f'{tag} min around [{a}, {b}) E')
     if rng.integers(0, 2):
         red = ('sum', 'mean')[int(rng.integers(0, 2))]
         kw = dict(plan=plan) if (plan is not None and rng.integers(0, 2)) else {}

@@ -129,6 +129,7 @@ def test_bench_line_over_the_emulation(monkeypatch, argv):
     assert set(res['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
     assert set(res['cpu_baseline']) >= {'value', 'unit', 'cores', 'kind', 'sample'} and res['cpu_baseline']['value']
     assert 'workload' in res['config']
+    assert 'leg_errors' not in res and 'parity_failed' not in res, (res.get('leg_errors'), res.get('parity_failed'))
     assert res['device_gate']['hub_chains'] == 1 and res['device_gate']['in_kernel_fold'] == 1
     if '--strict' in argv:
         assert res['schedule'].endswith('+strict-fma') and 'rows+plan' in res['schedule']

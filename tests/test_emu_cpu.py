@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import oracle
-from util import assert_bitexact
+from util import around_matrix, assert_bitexact
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
 import emu_lib as E  # noqa: E402
@@ -240,32 +240,6 @@ def test_accumulating_max_and_min_merge_column_subsets_exactly(graph, planned):
             E.spmm_acc_min(prp, pcol, pval, Xh, C, Ei, prow, nl, first)
     assert_bitexact(C, Co, 'merged min values')
     assert_bitexact(Ei, Eo, 'merged min arg ids')
-
-
-def around_matrix(rp, col, val, deg, a, b, n_out, compact=True):
-    """The "around" form of the halo matrix for local columns [a, b) (dgs_spmm_csr_acc_min_around_f32): per row with a halo
-    entry [slots of the columns < a | virtual entry a + row, weight 1, if the row has a local entry | slots of the columns >= b,
-    shifted by n_out virtual ids].  Returns (rowptr, col, val, rows it touches); compact=False keeps every row (rows without halo
-    entries then hold their virtual entry alone, or nothing)."""
-    M = rp.size - 1
-    rows = np.repeat(np.arange(M), deg)
-    is_loc = (col >= a) & (col < b)
-    has_loc = np.bincount(rows[is_loc], minlength=M) > 0
-    has_rem = np.bincount(rows[~is_loc], minlength=M) > 0
-    keep = np.nonzero(has_rem)[0] if compact else np.arange(M)
-    nl = b - a
-    # the halo entries in the around id space, and the virtual entries of the kept rows that have local columns
-    hr, hc, hv = rows[~is_loc], col[~is_loc], val[~is_loc]
-    hid = np.where(hc < a, hc, hc - nl + n_out)  # slot = column without the local block; ids >= a + n_out follow the virtual block
-    vr = keep[has_loc[keep]]
-    ar = np.concatenate([hr, vr])
-    ac = np.concatenate([hid, a + vr])
-    av = np.concatenate([hv, np.ones(vr.size, np.float32)])
-    order = np.lexsort((ac, ar))
-    ar, ac, av = ar[order], ac[order], av[order]
-    cnt = np.bincount(ar, minlength=M)[keep]
-    rpp = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
-    return rpp, np.ascontiguousarray(ac.astype(np.int32)), np.ascontiguousarray(av.astype(np.float32)), keep.astype(np.int32)
 
 
 @pytest.mark.parametrize('planned', [False, True], ids=['plan-free', 'plan'])

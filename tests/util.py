@@ -77,3 +77,29 @@ def assert_sum_parity(C, Cseq, C64, S64=None, rtol=1e-5, atol=2e-6, what='', len
         i = tuple(np.argwhere(~ok)[0])
         raise AssertionError(f'{what}: {(~ok).sum()} / {ok.size} outside the sum bar; first at {i}: gpu {C[i]!r} '
                              f'seq {Cseq[i]!r} exact {C64[i]!r}')
+
+
+def around_matrix(rp, col, val, deg, a, b, n_out, compact=True):
+    """The "around" form of the halo matrix for local columns [a, b) (dgs_spmm_csr_acc_min_around_f32): per row with a halo
+    entry [slots of the columns < a | virtual entry a + row, weight 1, if the row has a local entry | slots of the columns >= b,
+    shifted by n_out virtual ids].  Returns (rowptr, col, val, rows it touches); compact=False keeps every row (rows without halo
+    entries then hold their virtual entry alone, or nothing)."""
+    M = rp.size - 1
+    rows = np.repeat(np.arange(M), deg)
+    is_loc = (col >= a) & (col < b)
+    has_loc = np.bincount(rows[is_loc], minlength=M) > 0
+    has_rem = np.bincount(rows[~is_loc], minlength=M) > 0
+    keep = np.nonzero(has_rem)[0] if compact else np.arange(M)
+    nl = b - a
+    # the halo entries in the around id space, and the virtual entries of the kept rows that have local columns
+    hr, hc, hv = rows[~is_loc], col[~is_loc], val[~is_loc]
+    hid = np.where(hc < a, hc, hc - nl + n_out)  # slot = column without the local block; ids >= a + n_out follow the virtual block
+    vr = keep[has_loc[keep]]
+    ar = np.concatenate([hr, vr])
+    ac = np.concatenate([hid, a + vr])
+    av = np.concatenate([hv, np.ones(vr.size, np.float32)])
+    order = np.lexsort((ac, ar))
+    ar, ac, av = ar[order], ac[order], av[order]
+    cnt = np.bincount(ar, minlength=M)[keep]
+    rpp = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    return rpp, np.ascontiguousarray(ac.astype(np.int32)), np.ascontiguousarray(av.astype(np.float32)), keep.astype(np.int32)
