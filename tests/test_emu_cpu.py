@@ -464,7 +464,9 @@ rp = np.zeros(M + 1, np.int32); rp[1:] = np.cumsum(deg)
 col = np.concatenate([np.sort(rng.choice(K, d, replace=False)) for d in deg]).astype(np.int32)
 val = (rng.random(col.size, dtype=np.float32) - 0.3).astype(np.float32)
 bad = 0
-for N, ops in ((64, (E.SUM, E.MEAN, E.MAX, E.MIN)), (256, (E.SUM, E.MAX)), (7, (E.SUM, E.MIN))):
+CASES = {'full': ((64, (E.SUM, E.MEAN, E.MAX, E.MIN)), (256, (E.SUM, E.MAX)), (7, (E.SUM, E.MIN))),
+         'a': ((64, (E.SUM, E.MEAN, E.MAX, E.MIN)),), 'b': ((64, (E.MIN,)), (256, (E.SUM, E.MAX)), (7, (E.SUM,)))}[os.environ.get('FOLD_CASES', 'full')]
+for N, ops in CASES:
     X = rng.random((K, N), dtype=np.float32)
     for op in ops:
         out = {}
@@ -496,20 +498,23 @@ print('BAD', bad)
 '''
 
 
-@pytest.mark.parametrize('blocks,order', [('1', 'fwd'), ('40', 'rand:1')] + ([('40', 'rev'), ('64', 'rand:5')] if os.environ.get('DGS_TEST_LONG') else []))
-def test_in_kernel_fold_equals_the_combine_launch(blocks, order):
+@pytest.mark.parametrize('blocks,order,cases', [('1', 'fwd', 'a'), ('40', 'rand:1', 'b')] +
+                         ([('1', 'fwd', 'full'), ('40', 'rand:1', 'full'), ('40', 'rev', 'full'), ('64', 'rand:5', 'full')] if os.environ.get('DGS_TEST_LONG') else []))
+def test_in_kernel_fold_equals_the_combine_launch(blocks, order, cases):
     """the partial rows of multi-unit rows are folded by the unit wave that completes the row (arrival
     counter per row and feature tile) inside the fused launch instead of by a combine launch behind it - a planned call is ONE
     kernel launch.  The fold order is the fixed unit order either way, so fold on == fold off bit for bit: sum / mean / max / min
     (values and arg ids), plan-free and planned, one and several feature tiles, scalar lanes, signed data.  With resident
     workgroups taking turns in random / reverse dispatch order (DGS_EMU_BLOCKS / DGS_EMU_BLOCK_ORDER, read once per process:
-    hence the subprocess) the LAST arriver is a different unit every time - the result must not care who folds."""
+    hence the subprocess) the LAST arriver is a different unit every time - the result must not care who folds.  By default the
+    (feature width, reduce) cells are split over the two dispatch modes (the CPU suite has to stay at a few minutes);
+    DGS_TEST_LONG=1 runs every cell under four modes."""
     import subprocess
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     E.lib()  # built
     env = {k: v for k, v in os.environ.items() if not k.startswith('DGS_')}
-    env.update(DGS_EMU_BLOCKS=blocks, DGS_EMU_BLOCK_ORDER=order)
+    env.update(DGS_EMU_BLOCKS=blocks, DGS_EMU_BLOCK_ORDER=order, FOLD_CASES=cases)
     p = subprocess.run([sys.executable, '-c', FOLD_CASE % dict(root=root, here=here)], capture_output=True, text=True, env=env,
                        timeout=2400)
     assert p.returncode == 0 and 'BAD 0' in p.stdout, (p.stdout[-500:], p.stderr[-2500:])
