@@ -16,7 +16,7 @@ for p in (ROOT, os.path.join(ROOT, 'dgsparse-lib_amd'), os.path.join(ROOT, 'test
 import oracle  # noqa: E402
 from bench import graphgen  # noqa: E402
 from dgsparse import _capi as capi  # noqa: E402
-from util import assert_bitexact, assert_close, assert_sum_parity  # noqa: E402
+from util import around_matrix, assert_bitexact, assert_close, assert_sum_parity  # noqa: E402
 
 
 def dev(a):
@@ -177,6 +177,25 @@ def one_case(rng, it):
                 capi.spmm_min_merge(dev(rrows), None, None, None, 0, None, Cq, Eq, flag, drp, dev(ext), dev(vv), Xzd)
             assert_bitexact(Cq.cpu().numpy(), Cn, tag + f' acc min values (poisoned={poisoned})')
             assert_bitexact(Eq.cpu().numpy(), En, tag + f' acc min E (poisoned={poisoned})')
+            # round 5: the same in ONE accumulating launch (dgs_spmm_csr_acc_min_around_f32): the local result a virtual entry
+            # of its row; then the same redo-only call
+            if lcol.shape[0]:
+                Cq, Eq = capi.spmm(oracle.MIN, dev(lrp), dev(lcol), dev(lval), Xzd[:nl].contiguous())
+            else:
+                Cq = torch.zeros((M, N), device='cuda')
+                Eq = torch.full((M, N), -1, dtype=torch.int32, device='cuda')
+            arp, acol, aval, arows = around_matrix(rp, col, vv, np.diff(rp), a, b, M, compact=bool(rng.integers(0, 2)))
+            if acol.shape[0]:
+                darp, dacol = dev(arp), dev(acol)
+                halo2 = halo if halo.shape[0] else torch.zeros((1, N), device='cuda')
+                aplan = None
+                if rng.integers(0, 2) and capi.spmm_schedule(oracle.MIN, arp.shape[0] - 1, halo2.shape[0] + M, N, acol.shape[0]) == 'rows':
+                    aplan = capi.spmm_plan(darp, dacol, halo2.shape[0] + M, N, force=True)
+                capi.spmm_acc_min_around(darp, dacol, dev(aval), halo2, Cq, Eq, dev(arows), nl, a, M, plan=aplan)
+            if rrows.shape[0]:
+                capi.spmm_min_merge(dev(rrows), None, None, None, 0, None, Cq, Eq, flag, drp, dev(ext), dev(vv), Xzd)
+            assert_bitexact(Cq.cpu().numpy(), Cn, tag + f' acc min around values (poisoned={poisoned})')
+            assert_bitexact(Eq.cpu().numpy(), En, tag + f' acc min around E (poisoned={poisoned})')
     if col.shape[0]:
         D1 = (rng.integers(-3, 4, (M, N)) / 8).astype(np.float32)
         dD1 = dev(D1)
