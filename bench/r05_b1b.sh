@@ -23,4 +23,7 @@ tail -n 12 $O/strict_parts.txt $O/nocut_probe.txt
 head -c 3000 $O/bench_line.json
 
 timeout 300 python bench/dist_min_parts.py > $O/dist_min_parts.txt 2>&1
+# VERDICT r4 #6, the decision data: the LDS-landing window against the VGPR window on an arxiv-like hit mix at the product's LDS footprint (part 1b)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 experiments/lds_dma_gather.cpp -o /tmp/ldg > /dev/null 2>&1 && timeout 400 /tmp/ldg part1 > $O/lds_dma_gather_part1.txt 2>&1
+tail -n 12 $O/lds_dma_gather_part1.txt
 ls -la $O; tail -n 6 $O/dist_min_parts.txt

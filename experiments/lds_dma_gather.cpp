@@ -314,6 +314,45 @@ static double run_glds(const float *table, const int *idx, long total, int block
   return (double)per_wave * blocks * 4 * G * 16 / (best * 1e-3) / 1e12;
 }
 
+// Part 1b helpers (round 5): the same kernels with the LDS footprint the PRODUCT row stream would have - `pad` bytes of dynamic
+// LDS on top of the kernel's own (spmm_fused holds 20 544 B per workgroup; hipcc lets a launch reserve dynamic LDS the kernel
+// never declares) - so the occupancy per CU is the product's, not the microbenchmark's.  Returns microseconds per launch.
+template <int G, int U>
+static double us_vgpr(const float *table, const int *idx, int per_wave, int blocks, float *out, size_t pad) {
+  auto kern = gather_vgpr<G, U>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 6; rep++) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), pad, 0, table, idx, per_wave, out);
+    CK(hipEventRecord(e1));
+    const float ms = time_ms(e0, e1);
+    if (rep && ms < best) best = ms;
+  }
+  return best * 1e3;
+}
+template <int G, int D>
+static double us_glds(const float *table, const int *idx, int per_wave, int blocks, float *out, size_t pad) {
+  const size_t lds = 4 * (D * 1024 + 2048) + pad;
+  auto kern = gather_glds<G, D>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 6; rep++) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, table, idx, per_wave, out);
+    CK(hipEventRecord(e1));
+    const float ms = time_ms(e0, e1);
+    if (rep && ms < best) best = ms;
+  }
+  return best * 1e3;
+}
+
 static double checksum(const float *d_out, long n) {
   std::vector<float> h(n);
   CK(hipMemcpy(h.data(), d_out, n * 4, hipMemcpyDeviceToHost));
@@ -394,6 +433,43 @@ int main(int argc, char **argv) {
     ROW("512B glds D=8 (16 rows)", (run_glds<32, 8>(table, idx_cold512, total, blocks, out)), (run_glds<32, 8>(table, idx_hot512, total, blocks, out)));
     ROW("512B glds D=16 (32 rows)", (run_glds<32, 16>(table, idx_cold512, total, blocks, out)), (run_glds<32, 16>(table, idx_hot512, total, blocks, out)));
     ROW("512B glds D=32 (64 rows)", (run_glds<32, 32>(table, idx_cold512, total, blocks, out)), (run_glds<32, 32>(table, idx_hot512, total, blocks, out)));
+  }
+
+  if (!only2) {
+    // Part 1b (round 5): would an LDS-landing window pay IN THE ROW STREAM of a mid-size launch?  The arxiv-shaped
+    // configuration (C2) hits L2 on 54 % of its gathers, runs ~660 workgroups of 4 waves for ~45 us, and spmm_fused sits at 5
+    // workgroups per CU (20.5 KB of LDS, 96 VGPRs).  An LDS ring costs occupancy: 4 waves x D KB on top of those 20.5 KB.
+    // So: the two kernels of part 1 on a list that is hot (2 MB table) with probability 0.54, else cold, in a C2-sized grid (664
+    // workgroups x 4 waves x 256 or 512 rows) and in a grid that fills the chip for a while (16 per CU), each with the LDS the
+    // product would carry.  What to read: glds must beat 'vgpr U=8, 20.5 KB pad' (the product's window) by >= 10 % in the first two
+    // columns to be worth a kernel variant; if it does not, the item is closed with these numbers.
+    std::vector<int> t(total);
+    std::mt19937 r2(11);
+    for (long i = 0; i < total; i++) t[i] = ((r2() % 100) < 54) ? (hidx[i] & 8191) : hidx[i];
+    int *idx_mix;
+    CK(hipMalloc(&idx_mix, total * 4));
+    CK(hipMemcpy(idx_mix, t.data(), total * 4, hipMemcpyHostToDevice));
+    const size_t prod = 20544;
+    printf("\nPart 1b: 54 %% hot / 46 %% cold list, product-sized LDS per workgroup; microseconds per launch (lower is better)\n");
+    printf("%-44s %12s %12s %12s\n", "variant (LDS per workgroup)", "664wg x 256", "664wg x 512", "16/CU x 512");
+#define ROWB(name, call)                                                                        \
+  {                                                                                             \
+    double a, b, c;                                                                             \
+    { const int blocks = 664, pw = 256; a = call; }                                             \
+    { const int blocks = 664, pw = 512; b = call; }                                             \
+    { const int blocks = cus * 16, pw = 512; c = call; }                                        \
+    printf("%-44s %12.2f %12.2f %12.2f\n", name, a, b, c);                                      \
+    fflush(stdout);                                                                             \
+  }
+    ROWB("vgpr U=4, 4 KB + 20.5 KB pad (5-6 wg/CU)", (us_vgpr<16, 4>(table, idx_mix, pw, blocks, out, prod)));
+    ROWB("vgpr U=8, 4 KB + 20.5 KB pad (product)", (us_vgpr<16, 8>(table, idx_mix, pw, blocks, out, prod)));
+    ROWB("vgpr U=16, 4 KB + 20.5 KB pad", (us_vgpr<16, 16>(table, idx_mix, pw, blocks, out, prod)));
+    ROWB("glds D=4, 24 KB + 20.5 KB (3 wg/CU)", (us_glds<16, 4>(table, idx_mix, pw, blocks, out, prod)));
+    ROWB("glds D=8, 40 KB + 20.5 KB (2 wg/CU)", (us_glds<16, 8>(table, idx_mix, pw, blocks, out, prod)));
+    ROWB("glds D=16, 72 KB + 20.5 KB (1 wg/CU)", (us_glds<16, 16>(table, idx_mix, pw, blocks, out, prod)));
+    ROWB("glds D=4, 24 KB, no pad (6 wg/CU)", (us_glds<16, 4>(table, idx_mix, pw, blocks, out, 0)));
+    ROWB("glds D=8, 40 KB, no pad (4 wg/CU)", (us_glds<16, 8>(table, idx_mix, pw, blocks, out, 0)));
+    CK(hipFree(idx_mix));
   }
 
   if (!only1) {
