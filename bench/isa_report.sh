@@ -29,6 +29,6 @@ echo
 echo "== spmm_fused<16,4,0,true,false,true>: every s_barrier / s_waitcnt vmcnt / global load-store class / atomic, in program order"
 echo "   (hub gather waves: the phase loop is the run of [vmcnt(18) .. vmcnt(8) -> s_barrier -> 4 x dword nt + 8 x dwordx4 -> s_barrier] pairs: the"
 echo "    gathers of two register sets stay in flight across the barriers, which wait for lgkmcnt only;"
-echo "    in-kernel fold: 'global_store_dword sc1' x 4, later 's_waitcnt vmcnt(0)' + 'global_atomic_add', 'global_load_dword sc1' in the fold)"
+echo "    in-kernel fold: 'buffer_store_dwordx4 sc1' (one 16-byte write-through store per lane), later 's_waitcnt vmcnt(0)' + 'global_atomic_add', then '8 x buffer_load_dwordx4 sc1' back to back and counted waits in the fold)"
 grep -nE "s_barrier|s_waitcnt vmcnt|global_atomic|sc1|s_setprio|buffer_wbl2|buffer_inv" $T/f16.dis | awk '{ $1=$1; print }' | sed -E 's/v\[[0-9:]+\]|v[0-9]+|s\[[0-9:]+\]//g' | awk '{k=$0; sub(/^[0-9]+: */,"",k); if (k==last) {c++} else { if (last!="") print (c>1? c" x ":"") last; last=k; c=1 } } END { print (c>1? c" x ":"") last }' | head -150
 rm -rf $T

@@ -15,6 +15,7 @@
 #include <limits.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -199,3 +200,33 @@ static inline T atomicMin(T *p, T v) { const T o = *p; *p = o < v ? o : v; retur
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #endif
 // (__hip_atomic_load / _store / _fetch_add are clang builtins on the host as well)
+
+// raw buffer loads / stores through a descriptor (the in-kernel fold's 16-byte sc1 accesses): base + byte offset, and - where the
+// hardware silently drops an out-of-range access - an abort, because in the product an out-of-range partial-row access is a bug
+namespace emu {
+struct BufRsrc {
+  char *base;
+  unsigned bytes;
+};
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+static inline void buf_check(const BufRsrc &r, long off, const char *what) {
+  if (off < 0 || (unsigned long)off + 16 > r.bytes) {
+    fprintf(stderr, "emu: raw buffer %s out of range: byte offset %ld, descriptor covers %u bytes\n", what, off, r.bytes);
+    abort();
+  }
+}
+static inline u4_t buf_load128(const BufRsrc &r, int voff, int soff) {
+  buf_check(r, (long)(unsigned)voff + soff, "load");
+  u4_t v;
+  memcpy(&v, r.base + (unsigned)voff + soff, 16);
+  return v;
+}
+static inline void buf_store128(u4_t v, const BufRsrc &r, int voff, int soff) {
+  buf_check(r, (long)(unsigned)voff + soff, "store");
+  memcpy(r.base + (unsigned)voff + soff, &v, 16);
+}
+}  // namespace emu
+#define __amdgpu_buffer_rsrc_t ::emu::BufRsrc
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, n, flags) (::emu::BufRsrc{(char *)(p), (unsigned)(n)})
+#define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) ::emu::buf_load128(r, voff, soff)
+#define __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, aux) ::emu::buf_store128(v, r, voff, soff)
