@@ -15,7 +15,7 @@ namespace dgs {
 constexpr int kOpMaskSum = 4;
 
 // Dynamic LDS of the column-panel kernels.  (The only two hooks for tests/emu - the host-side wave64 emulation the CPU test
-// suite runs the kernels' control logic on: this declaration and store_vec_hidden below.  DGS_HOST_EMU is never defined in a
+// suite runs the kernels' control logic on: this declaration and the inline-asm block below - store_vec_hidden, drain_vmem.  DGS_HOST_EMU is never defined in a
 // product build.)
 #ifndef DGS_HOST_EMU
 #define DGS_DYN_SHARED(name) extern __shared__ __align__(16) char name[]
@@ -258,7 +258,12 @@ __device__ __forceinline__ void store_vec_hidden(int *p, const int (&o)[V]) {
     asm volatile("global_store_dword %0, %1, off" DGS_NT_SUFFIX "\n\ts_nop 1" ::"v"(p), "v"(o[0]) : "memory");
   }
 }
-#else  // host emulation (tests/emu): a store is a store
+// Drain of this wave's vector-memory queue in front of a cross-workgroup publish (the in-kernel fold's arrival counter): written as
+// inline asm because hipcc's waitcnt pass never sees - hence never weakens or drops - it (MI355X guide, inter-workgroup visibility,
+// "compiler hazard"); the memory clobber pins the stores before it and the atomic behind it.
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#else  // host emulation (tests/emu): a store is a store, and every access completes at once
+__device__ __forceinline__ void drain_vmem() {}
 template <int V>
 __device__ __forceinline__ void store_vec_hidden(float *p, const float (&o)[V]) { store_vec<V>(p, o); }
 template <int V>

@@ -1166,9 +1166,7 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
   const CohBuf cbp = coh_buf(part, folding ? ut.part_bytes : 0), cbe = coh_buf(ARG ? (void *)parte : (void *)part, folding ? ut.part_bytes : 0);
   int pend = -1;  // long-row index of the partial row this wave wrote last and has not counted in yet
   auto arrive = [&](int li) {
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's partial-row stores have been performed
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    drain_vmem();  // s_waitcnt vmcnt(0), as inline asm: this wave's partial-row stores have been performed (written through)
     int old = 0;
     // (one counter per long row AND feature tile: the tiles of a launch fold independently)
     if (lane == 0)
