@@ -1161,19 +1161,30 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
   // wave has waited for that unit's gathers anyway, so the stores are long complete and the wait below is free - the wave counts
   // the unit in on its row's arrival counter; whoever brings the count to the row's number of units folds the row right here
   // (fold_row: fixed unit order, so the result does not depend on who that is).  Ordering: stores performed at agent scope
-  // (s_waitcnt vmcnt(0)) -> atomic add on the counter -> the last arriver's loads, issued after its own add has returned.
+  // (s_waitcnt vmcnt(0)) -> atomic add on the counter -> the last arriver's loads, issued after its own add has returned (and
+  // been looked at: one more unit later, see count_in / settle).
   const bool folding = ut.arrive != nullptr;
   const CohBuf cbp = coh_buf(part, folding ? ut.part_bytes : 0), cbe = coh_buf(ARG ? (void *)parte : (void *)part, folding ? ut.part_bytes : 0);
   int pend = -1;  // long-row index of the partial row this wave wrote last and has not counted in yet
-  auto arrive = [&](int li) {
+  // ... and one step further down the pipeline: the row whose counter this wave has incremented WITHOUT having looked at the
+  // returned count yet.  A returning device-scope atomic takes ~0.25 us on an idle chip and ~1.1 us under streaming load (MI355X
+  // guide, hand-off price list: "dequeue"); waited for on the spot, that is 5 - 10 % of a unit's life with the wave issuing
+  // nothing.  So the count is read ONE UNIT LATER (settle), when it has long returned - like the partial-row stores, whose drain
+  // in front of the atomic is free because they are a unit old.  At most one ticket per wave is in flight.
+  int tick_row = -1, tick_old = 0;
+  auto count_in = [&](int li) {
     drain_vmem();  // s_waitcnt vmcnt(0), as inline asm: this wave's partial-row stores have been performed (written through)
-    int old = 0;
     // (one counter per long row AND feature tile: the tiles of a launch fold independently)
     if (lane == 0)
-      old = __hip_atomic_fetch_add(ut.arrive + (int64_t)li * gridDim.y + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    old = __shfl(old, 0, 64);
-    const int4 lr = ut.longrows[li];  // {row, first partial slot, units in the row, -}
-    if (old == lr.z - 1) {
+      tick_old = __hip_atomic_fetch_add(ut.arrive + (int64_t)li * gridDim.y + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tick_row = li;
+  };
+  auto settle = [&]() {
+    if (tick_row < 0) return;  // wave-uniform
+    const int old = __shfl(tick_old, 0, 64);
+    const int4 lr = ut.longrows[tick_row];  // {row, first partial slot, units in the row, -}
+    tick_row = -1;
+    if (old == lr.z - 1) {  // this wave brought the count to the row's number of units: every partial row has been written through
       __atomic_signal_fence(__ATOMIC_SEQ_CST);
       fold_row<G, V, OP, ACC, true>(lr, lane, N, rowptr, col, HAS_VAL ? val : nullptr, B, C, E, part, parte, aa, ut.part_bytes);
     }
@@ -1206,9 +1217,12 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
         }
       }
     }
-    if (folding && pend >= 0) {  // the previous partial row of this wave: its stores are a whole unit old, the wait is free
-      arrive(pend);
-      pend = -1;
+    if (folding) {
+      settle();         // the ticket drawn one unit ago: its count has long returned
+      if (pend >= 0) {  // the previous partial row of this wave: its stores are a whole unit old, the drain is free
+        count_in(pend);
+        pend = -1;
+      }
     }
     if (g == 0 && fl) {
       if (whole) {  // the whole row was this unit: final result
@@ -1237,7 +1251,11 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
     }
     if (folding && !whole) pend = ut.slot_long[d.w];
   }
-  if (folding && pend >= 0) arrive(pend);
+  if (folding) {  // drain the pipeline: the ticket in flight, then the last partial row
+    settle();
+    if (pend >= 0) count_in(pend);
+    settle();
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
