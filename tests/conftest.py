@@ -11,9 +11,10 @@ for p in (ROOT, os.path.join(ROOT, 'dgsparse-lib_amd')):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
-    config.addinivalue_line('markers', 'first_contact: forces or asserts a schedule that rests on hardware behaviour no CPU test sees '
-                            '(hub chains, in-kernel fold, the device gate) - collected LAST, so that under `-x` a failure there '
-                            'cannot hide the parity suite of the gate-protected default')
+    config.addinivalue_line('markers', 'first_contact: written in rounds 4 / 5 while the GPU pool was closed - never run on hardware: '
+                            'tests that force or assert a schedule resting on hardware behaviour no CPU test sees (hub chains, '
+                            'in-kernel fold, the device gate) and the other tests added since the last green GPU run (round 3) - '
+                            'collected LAST, so that under `-x` a failure there cannot hide the suite that has run green before')
 
 
 def _has_gpu():

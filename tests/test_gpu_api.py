@@ -488,6 +488,7 @@ def test_plan_lifecycle_lazy_async_shared(monkeypatch):
     assert torch.allclose(y, ref, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.first_contact
 def test_second_tensor_over_the_same_arrays_while_the_plan_is_provisional(monkeypatch):
     """a new SparseTensor per layer / iteration over the same graph lands inside the ~1.5 ms window in which
     the shared plan is still provisional; it must get the build buffer (same stream) like the first one, never a KeyError."""
@@ -525,6 +526,7 @@ def test_second_tensor_over_the_same_arrays_while_the_plan_is_provisional(monkey
     assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.first_contact
 def test_schedule_switch_is_a_function_of_the_use_count_and_reproducible_mode(monkeypatch):
     """the plan-free and the planned schedule fold rows of 65 .. 8192 nnz with different trees, so WHEN a matrix
     switches must not depend on timing.  (i) Two fresh tensors over clones of the same arrays, one driven in a tight loop and
@@ -578,6 +580,7 @@ def test_schedule_switch_is_a_function_of_the_use_count_and_reproducible_mode(mo
         torch.use_deterministic_algorithms(False)
 
 
+@pytest.mark.first_contact
 def test_two_host_threads_two_streams_two_plans():
     """the launchers keep no mutable global state (the tuning snapshot is immutable, per-device facts are
     atomics), so two host threads may launch concurrently, each on its own stream with its own plan and workspace: every
@@ -674,6 +677,7 @@ def test_hub_self_test_passes_on_this_device_and_gates_the_default(monkeypatch):
     assert _capi._lib.dgs_spmm_hub_selftest(scratch.data_ptr(), nb - 1, torch.cuda.current_stream().cuda_stream) == -2
 
 
+@pytest.mark.first_contact
 def test_storage_tells_the_launches_its_longest_row_and_column(monkeypatch):
     """single-launch inputs are routed by the longest ROW, not by nnz.  The Storage learns the longest row in the
     one sync its construction already has and the longest column without another one; spmm_sum / spmm_mean pass the hints on

@@ -163,11 +163,14 @@ def test_bench_partitioned_path_under_the_launcher():
     assert j['roofline']['frac'] > 0 and j['scaling'] == 'weak'
 
 
+# ('around': round 5, never run on hardware when written - collected last, so that a failure there cannot hide the forms that
+# round 3 ran green: tests/conftest.py, marker first_contact)
+@pytest.mark.parametrize('forms', ['merge+two', pytest.param('around', marks=pytest.mark.first_contact)])
 @pytest.mark.parametrize('M,N,lo,hi,has_val', [(3000, 32, 900, 2100, True), (3000, 7, 900, 2100, True),
                                                (3000, 16, 0, 1500, True), (3000, 16, 1500, 3000, False),
                                                (3000, 8, 1200, 1200, True), (3000, 64, 0, 3000, True),
                                                (70000, 32, 20000, 50000, True), (70000, 12, 30000, 45000, False)])
-def test_min_merge_and_nonfinite_flag_through_the_c_abi(M, N, lo, hi, has_val):
+def test_min_merge_and_nonfinite_flag_through_the_c_abi(M, N, lo, hi, has_val, forms):
     """dgs_spmm_csr_acc_min_f32 / _acc_min_around_f32 / dgs_spmm_min_merge_f32 / dgs_nonfinite_flag_f32 on their own: a matrix whose columns are
     cut in three ranges [lower | local | higher] the way a shard of dgsparse.dist is, every row's min put together from
     the three products - (a) lower folded in front of and higher behind the local result by the accumulating kernels, (b)
@@ -214,7 +217,7 @@ def test_min_merge_and_nonfinite_flag_through_the_c_abi(M, N, lo, hi, has_val):
     Cref, Eref = oracle.spmm('min', rp, ext, val, Bext, fma=True)
     C1, E1 = _capi.spmm(_capi.MIN, full_rp, full_col, full_val, Bd)
     assert_bitexact(C1.cpu().numpy(), Cref, 'one-pass min')
-    for force in (0, 1):
+    for force in ((0, 1) if forms == 'merge+two' else ()):
         flag = torch.full((1,), force, dtype=torch.int32, device=dev)
         if nl > 0:
             C, E = _capi.spmm(_capi.MIN, t(lrp), t(lcol), t(lval), Bd[:nl])
@@ -236,7 +239,7 @@ def test_min_merge_and_nonfinite_flag_through_the_c_abi(M, N, lo, hi, has_val):
         r = np.zeros(keep.shape[0] + 1, np.int32)
         r[1:] = np.cumsum(cnt[keep])
         return r, (ext[mask] - nl).astype(np.int32), (None if val is None else val[mask]), keep
-    for force in (0, 1):
+    for force in ((0, 1) if forms == 'merge+two' else ()):
         flag = torch.full((1,), force, dtype=torch.int32, device=dev)
         if nl > 0:
             C, E = _capi.spmm(_capi.MIN, t(lrp), t(lcol), t(lval), Bd[:nl])
@@ -255,7 +258,7 @@ def test_min_merge_and_nonfinite_flag_through_the_c_abi(M, N, lo, hi, has_val):
         assert_bitexact(E.cpu().numpy(), Eref, f'accumulated min E (flag {force})')
     # (c) round 5, dgsparse.dist's default: ONE accumulating launch, the local result a virtual entry of its row
     # (dgs_spmm_csr_acc_min_around_f32; ids: lower slots | lo + shard row | higher slots + M), plan-free and over a plan
-    if R:
+    if R and forms == 'around':
         hr, hs = rows[~is_loc], ext[~is_loc] - nl  # halo entries: row, slot (lower ranks' slots are [0, lo))
         has_loc = np.diff(lrp)[rem_rows] > 0
         vr = rem_rows[has_loc].astype(np.int64)
@@ -279,7 +282,7 @@ def test_min_merge_and_nonfinite_flag_through_the_c_abi(M, N, lo, hi, has_val):
             assert_bitexact(C.cpu().numpy(), Cref, f'around-form min values (flag {force})')
             assert_bitexact(E.cpu().numpy(), Eref, f'around-form min E (flag {force})')
     # the detector: clean data leaves the flag alone; one NaN / inf anywhere (any alignment, head, tail) raises it
-    for off in (0, 1, 3):
+    for off in ((0, 1, 3) if forms == 'merge+two' else ()):
         x = torch.rand(100003, device=dev)[off:].contiguous() if off == 0 else torch.rand(100003 + off, device=dev)[off:]
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         _capi.nonfinite_flag(x.contiguous() if off == 0 else x, flag)

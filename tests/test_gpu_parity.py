@@ -82,6 +82,7 @@ def test_csr2csc_reference_fixture(capi):
     assert_bitexact(cscval.cpu().numpy(), g['csc_val'])
 
 
+@pytest.mark.first_contact
 @pytest.mark.parametrize('name', ['p2p_gnutella31_csr2csc', 'ca_condmat_csr'])
 @pytest.mark.parametrize('N', [32, 64])
 def test_real_graphs_all_reduces_and_sddmm(capi, name, N):

@@ -293,6 +293,7 @@ def test_single_launch_inputs_chain_their_hub_rows(capi, N):
 
 
 
+@pytest.mark.first_contact
 @pytest.mark.parametrize('N', [64, 128, 41])
 def test_strict_order_over_the_cached_plan(capi, N):
     """Round 5 (VERDICT r3 #1b): a strict call over a plan takes the plan's strict table (rows > 64 nnz sorted longest first, class
