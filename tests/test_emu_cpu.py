@@ -292,6 +292,49 @@ def test_accumulating_min_around_is_one_launch_and_exact(graph, planned, data):
     assert np.array_equal(C[untouched].view(np.int32), before[0][untouched].view(np.int32)) and np.array_equal(Ei[untouched], before[1][untouched])
 
 
+@pytest.mark.parametrize('world', [2, 3])
+def test_dist_halo_plan_feeds_the_around_launch(world):
+    """dgsparse.dist's own builder of the around matrix (HaloPlan.min_around: id space [lower slots | one virtual column per shard
+    row | higher slots], values with weight-1 virtual entries) driven through the emulated kernels with the arguments
+    DistSpMM.spmm passes (col_off = n_local, virt_lo = h_lo, virt_n = n_local, dense = the halo rows): every rank's rows of the
+    min - values and global arg ids - equal algorithm 0 on the whole graph.  (tests/test_dist_cpu.py runs the same builder over
+    gloo with a numpy restatement of the launch; this test ties it to the kernel code.)"""
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for q in (root, os.path.join(root, 'dgsparse-lib_amd')):
+        if q not in sys.path:
+            sys.path.insert(0, q)
+    from bench import graphgen
+    from dgsparse import dist as dd
+    M, N = 700 * world, 12
+    rp, col, st = graphgen.powerlaw_csr(M, 11000 * world, alpha=2.0, dmax=M // 2, cols='powerlaw', seed=5)
+    val = graphgen.weights(col.shape[0], 'tied', 5)
+    X = (np.random.default_rng(1).integers(-2, 3, (M, N)) / 4).astype(np.float32)
+    X[X == 0] = np.where(np.random.default_rng(2).random(int((X == 0).sum())) < 0.5, np.float32(-0.0), np.float32(0.0))
+    Cg, Eg = oracle.spmm('min', rp, col, val, X, fma=True)
+    for rank in range(world):
+        part = dd.partition_csr(rp, col, val, world)[rank]
+        plan = dd.HaloPlan(part, standalone=True)
+        assert plan.rows_sorted
+        nl, r0 = part.n_local, part.r0
+        Xl = np.ascontiguousarray(X[r0:r0 + nl])
+        halo = np.ascontiguousarray(X[plan.recv_ids.numpy()]) if plan.n_halo else np.zeros((1, N), np.float32)
+        lrp, lcol, lval = (t.numpy() for t in plan.loc)
+        if lcol.size:
+            C, Ei = E.spmm(E.MIN, np.ascontiguousarray(lrp), np.ascontiguousarray(lcol), np.ascontiguousarray(lval), Xl)
+        else:
+            C, Ei = np.zeros((nl, N), np.float32), np.full((nl, N), -1, np.int32)
+        sub, rows, pos = plan.min_around()
+        arp, acol, aval = (np.ascontiguousarray(t.numpy()) for t in sub)
+        assert int((pos < 0).sum()) == int((np.diff(lrp)[rows.numpy()] > 0).sum()), 'one virtual entry per row with local columns'
+        if acol.size:
+            E.spmm_acc_min_around(arp, acol, aval, halo, C, Ei, np.ascontiguousarray(rows.numpy()), nl, plan.h_lo, nl)
+        glob = plan.ext2glob32.numpy()
+        Eglob = np.where(Ei >= 0, glob[np.clip(Ei, 0, None)], -1)
+        assert_bitexact(C, Cg[r0:r0 + nl], f'rank {rank}/{world}: min values through the around launch')
+        assert_bitexact(Eglob.astype(np.int32), Eg[r0:r0 + nl], f'rank {rank}/{world}: global arg ids')
+
+
 def test_accumulating_min_around_on_the_single_launch_kernel():
     """The same through spmm_small (<= 2^16 rows and 2^18 nnz): long rows are wave-cooperative there, nothing is cut."""
     rng = np.random.default_rng(5)
