@@ -333,6 +333,21 @@ def test_dist_halo_plan_feeds_the_around_launch(world):
         Eglob = np.where(Ei >= 0, glob[np.clip(Ei, 0, None)], -1)
         assert_bitexact(C, Cg[r0:r0 + nl], f'rank {rank}/{world}: min values through the around launch')
         assert_bitexact(Eglob.astype(np.int32), Eg[r0:r0 + nl], f'rank {rank}/{world}: global arg ids')
+        # ... and the same plan's halo matrix through the accumulating max (ties to the smaller global column) and sum
+        rrp, rcol, rval = (np.ascontiguousarray(t.numpy()) for t in plan.rem)
+        rrows = np.ascontiguousarray(plan.rem_rows.numpy())
+        Cm, Em = (E.spmm(E.MAX, np.ascontiguousarray(lrp), np.ascontiguousarray(lcol), np.ascontiguousarray(lval), Xl) if lcol.size
+                  else (np.zeros((nl, N), np.float32), np.full((nl, N), -1, np.int32)))
+        Cs, _ = (E.spmm(E.SUM, np.ascontiguousarray(lrp), np.ascontiguousarray(lcol), np.ascontiguousarray(lval), Xl) if lcol.size
+                 else (np.zeros((nl, N), np.float32), None))
+        if rcol.size:
+            E.spmm_acc_max(rrp, rcol, rval, halo, Cm, Em, rrows, nl, nl, plan.h_lo)
+            E.spmm_acc(rrp, rcol, rval, halo, Cs, rowmap=rrows)
+        Cgm, Egm = oracle.spmm('max', rp, col, val, X, fma=True)
+        assert_bitexact(Cm, Cgm[r0:r0 + nl], f'rank {rank}/{world}: max values through the accumulating launch')
+        assert_bitexact(np.where(Em >= 0, glob[np.clip(Em, 0, None)], -1).astype(np.int32), Egm[r0:r0 + nl], f'rank {rank}/{world}: max arg ids')
+        Cgs, _ = oracle.spmm('sum', rp, col, val, X, fma=True)
+        assert np.allclose(Cs, Cgs[r0:r0 + nl], rtol=1e-5, atol=2e-6), f'rank {rank}/{world}: local + halo sum'
 
 
 def test_accumulating_min_around_on_the_single_launch_kernel():
