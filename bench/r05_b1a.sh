@@ -18,6 +18,12 @@ if grep -q "rc=124" $O/selftest.txt; then echo "self-test hung: stopping"; exit 
 timeout 300 python bench/hub_smoke.py > $O/hub_smoke.txt 2>&1; echo "hub_smoke rc=$?" >> $O/hub_smoke.txt
 tail -n 30 $O/hub_smoke.txt
 if grep -q "rc=124" $O/hub_smoke.txt; then echo "hub smoke hung: stopping"; exit 1; fi
+# the two pieces of evidence the round cannot do without come first: a bench line of the default schedule, and the kernel stats of the same command
+timeout 600 python bench.py --no-dense > $O/bench_line_default.json 2> $O/bench_default_err.txt; echo "bench (default) rc=$?"
+head -c 2500 $O/bench_line_default.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_first -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-dense --no-protocol > /dev/null 2>&1
+cp $(ls $O/ks_first/*/*kernel_stats.csv | head -1) $O/kernel_stats_bench_feat64_sum_plan_default.csv; rm -rf $O/ks_first
+head -n 6 $O/kernel_stats_bench_feat64_sum_plan_default.csv
 timeout 1800 python -m pytest tests -q -m gpu > $O/pytest_all.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_all.txt
 tail -n 25 $O/pytest_all.txt
 timeout 900 python bench.py --sweep > $O/bench_line.json 2> $O/bench_err.txt; echo "bench rc=$?"
