@@ -62,6 +62,8 @@ def parse():
                          'strict schedule is still measured and checked beside the headline (key "strict")')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-protocol', action='store_true', help='skip median-of-5 / unit-weight / seeds 1..4 extras')
+    ap.add_argument('--protocol-seeds', type=int, default=5, help='graph seeds 0 .. n-1 timed and parity-checked by the protocol leg '
+                    '(SURVEY 8(d): five; the CPU dry run of tests/ walks the code with two)')
     ap.add_argument('--settle', type=int, default=50, help='untimed launches before the W warm-ups: an idle MI355X needs '
                     '~25 launches (10 ms) before the step time settles (0.404 -> 0.393 ms); reported as settle_steps')
     ap.add_argument('--no-worst-case', action='store_true', help='N>1: skip the uniform-columns, locality-0 second run')
@@ -493,7 +495,7 @@ def main():
             prot['unit_weights_ms'] = round(sorted(event_ms(step1, max(10, a.steps // 5)) for _ in range(3))[1], 5)
             del ones, step1
             seeds = {}
-            for s in range(5):
+            for s in range(max(1, a.protocol_seeds)):
                 if s == a.seed:
                     seeds[str(s)] = dict(ms=prot['median_ms'], nnz=int(nnz_total))
                     continue
