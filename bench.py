@@ -514,23 +514,38 @@ def main():
             prot['seeds'] = seeds
             res['protocol'] = prot
             if planned:
-                # the in-kernel fold of partial rows (round 5; on where the device self-test passed) next to the combine launch it
-                # replaces, on the same tensors: DGS_FOLD = 1 / 0 for one measurement each, then back to the process's own setting
+                # the in-kernel fold of partial rows (opt-in: DGS_FOLD=1 | 2) next to the combine launch it replaces, on the same
+                # tensors: first the device's own verdict on the hand-over (dgs_spmm_fold_selftest: every family of partial row,
+                # 3 rounds, the last under a streaming load), then DGS_FOLD = 1 / 0 for one measurement each and a bit compare
+                # of the two results, then back to the process's own setting.  Decision rule: the fold becomes a
+                # default only with on_ms < off_ms on hardware
                 had = os.environ.get('DGS_FOLD')
-                fd = dict(gate=_capi.fold_gate(), default_on=bool((had not in (None, '')) and had != '0') if had not in (None, '') else _capi.fold_gate() > 0)
+                try:
+                    verdict, fam = _capi.fold_selftest(rounds=3, load=True)
+                except Exception as e:
+                    verdict, fam = -2, str(e)
+                fd = dict(selftest=verdict, selftest_mismatches_per_family=fam, gate=_capi.fold_gate(),
+                          default_on=bool(had == '1' or (had == '2' and _capi.fold_gate() > 0)))
+                outs = {}
                 for name, v in (('on_ms', '1'), ('off_ms', '0')):
+                    if v == '1' and verdict != 1:
+                        fd[name] = None  # a hand-over the device got wrong is not timed
+                        continue
                     os.environ['DGS_FOLD'] = v
                     _capi.reload_tuning()
                     stepf, _ = make_step(rp, col, val, X)
-                    stepf()
+                    outs[v] = stepf()[0].clone()
                     fd[name] = round(sorted(event_ms(stepf, max(10, a.steps // 5)) for _ in range(3))[1], 5)
                     del stepf
+                if len(outs) == 2:
+                    fd['same_bits'] = bool(torch.equal(outs['1'].view(torch.int32), outs['0'].view(torch.int32)))
+                del outs
                 if had is None:
                     os.environ.pop('DGS_FOLD')
                 else:
                     os.environ['DGS_FOLD'] = had
                 _capi.reload_tuning()
-                fd['note'] = 'fold on: one kernel launch per planned call (+ a memset of 4 B per long row); off: fused + combine'
+                fd['note'] = 'fold on: one kernel launch per planned call (+ a memset of 4 B per long row); off (the default): fused + combine'
                 res['fold'] = fd
             if '+hub' in res.get('schedule', ''):
                 # what the hub chains cost next to the tree on the same tensors (the decision rule needs both numbers
@@ -688,10 +703,21 @@ def main():
                                     C_check, C_strict))
         except Exception as e:  # the baseline is a reported side figure; never lose the GPU line over it
             res['cpu_baseline'] = dict(value=None, unit='GFLOP/s', cores=0, kind='port', sample=f'failed: {e}')
+    # A result that failed the self-check or the contract check must not be scoreable: the timing moves to
+    # `unscored`, `value` and the roofline figures become null, and the process exits non-zero after the line is out.
+    wrong = res.get('parity_failed') is not None
+    if wrong:
+        res['unscored'] = dict(value=res['value'], ms_per_step=res['ms_per_step'], roofline_achieved=res['roofline']['achieved'],
+                               roofline_frac=res['roofline']['frac'], note='timing of a result that FAILED its parity check')
+        res['value'] = None
+        res['roofline']['achieved'] = None
+        res['roofline']['frac'] = None
     if rank == 0:
         print(json.dumps(res))
     if pg:
         torch.distributed.destroy_process_group()
+    if wrong:
+        sys.exit(3)
 
 
 if __name__ == '__main__':

@@ -14,13 +14,23 @@ namespace dgs {
 // kernel's stale-variable behaviour).  Same schedule as the forward; the E pointer carries the saved arg ids (input).
 constexpr int kOpMaskSum = 4;
 
-// Dynamic LDS of the column-panel kernels.  (The only two hooks for tests/emu - the host-side wave64 emulation the CPU test
-// suite runs the kernels' control logic on: this declaration and the inline-asm block below - store_vec_hidden, drain_vmem.  DGS_HOST_EMU is never defined in a
-// product build.)
+// Dynamic LDS of the column-panel kernels.  (The hooks for tests/emu - the host-side wave64 emulation the CPU test suite runs the
+// kernels' control logic on: this declaration, the inline-asm block below - store_vec_hidden, drain_vmem - and DGS_EMU_LD / _ST in
+// load_vec / store_vec, through which the emulation's relaxed-memory mode sees the plain vector accesses (tests/emu/emu_rt.cpp:
+// per-wave store queues, per-XCD dirty lines, per-CU L1 - what the in-kernel fold's hand-over has to be right about).
+// DGS_HOST_EMU is never defined in a product build: the two macros are empty there.)
 #ifndef DGS_HOST_EMU
 #define DGS_DYN_SHARED(name) extern __shared__ __align__(16) char name[]
 #else
 #define DGS_DYN_SHARED(name) extern char name[]
+#endif
+
+#ifdef DGS_HOST_EMU
+#define DGS_EMU_LD(p, o, bytes) do { if (::emu::mem_on()) { ::emu::mem_load((p), (o), (bytes), 0); return; } } while (0)
+#define DGS_EMU_ST(p, o, bytes) do { if (::emu::mem_on()) { ::emu::mem_store((p), (o), (bytes), 0); return; } } while (0)
+#else
+#define DGS_EMU_LD(p, o, bytes) ((void)0)
+#define DGS_EMU_ST(p, o, bytes) ((void)0)
 #endif
 
 constexpr int kWave = 64;    // CDNA wavefront
@@ -99,6 +109,7 @@ __device__ __forceinline__ void epi_apply(float (&o)[V], int64_t row, int f0, co
 // V consecutive floats / ints at p (p is 4*V-byte aligned by construction of the dispatch).
 template <int V>
 __device__ __forceinline__ void load_vec(const float *p, float (&o)[V]) {
+  DGS_EMU_LD(p, o, 4 * V);
   if constexpr (V == 4) {
     const float4 t = *reinterpret_cast<const float4 *>(p);
     o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
@@ -111,6 +122,7 @@ __device__ __forceinline__ void load_vec(const float *p, float (&o)[V]) {
 }
 template <int V>
 __device__ __forceinline__ void load_vec(const int *p, int (&o)[V]) {
+  DGS_EMU_LD(p, o, 4 * V);
   if constexpr (V == 4) {
     const int4 t = *reinterpret_cast<const int4 *>(p);
     o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
@@ -123,6 +135,7 @@ __device__ __forceinline__ void load_vec(const int *p, int (&o)[V]) {
 }
 template <int V>
 __device__ __forceinline__ void store_vec(float *p, const float (&o)[V]) {
+  DGS_EMU_ST(p, o, 4 * V);
   if constexpr (V == 4) {
     *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
   } else if constexpr (V == 2) {
@@ -133,6 +146,7 @@ __device__ __forceinline__ void store_vec(float *p, const float (&o)[V]) {
 }
 template <int V>
 __device__ __forceinline__ void store_vec(int *p, const int (&o)[V]) {
+  DGS_EMU_ST(p, o, 4 * V);
   if constexpr (V == 4) {
     *reinterpret_cast<int4 *>(p) = make_int4(o[0], o[1], o[2], o[3]);
   } else if constexpr (V == 2) {
@@ -262,8 +276,8 @@ __device__ __forceinline__ void store_vec_hidden(int *p, const int (&o)[V]) {
 // inline asm because hipcc's waitcnt pass never sees - hence never weakens or drops - it (MI355X guide, inter-workgroup visibility,
 // "compiler hazard"); the memory clobber pins the stores before it and the atomic behind it.
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#else  // host emulation (tests/emu): a store is a store, and every access completes at once
-__device__ __forceinline__ void drain_vmem() {}
+#else  // host emulation (tests/emu): a store is a store; accesses complete at once unless the relaxed-memory mode is on
+__device__ __forceinline__ void drain_vmem() { ::emu::mem_drain(); }
 template <int V>
 __device__ __forceinline__ void store_vec_hidden(float *p, const float (&o)[V]) { store_vec<V>(p, o); }
 template <int V>

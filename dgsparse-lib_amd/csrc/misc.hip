@@ -161,7 +161,7 @@ extern "C" int dgs_relabel_i32(int64_t n, int32_t *ids, const int32_t *map, dgsS
   return check_launch();
 }
 
-extern "C" int dgs_version(void) { return 1004; }  // 1.1: cached plans, accumulating SpMM, scheduling hints, relabel; 1.2: strict-order bits, dgs_spmm_csr_ex_f32 (epilogue), dgs_sddmm_csr_plan_f32, non-blocking plan helpers; 1.3: accumulating min, min merge / redo, non-finite detector; 1.4 (rounds 4 / 5): hub threshold / tuning reload, the device gate (dgs_spmm_hub_selftest*, _hub_gate, _fold_gate), DGS_ALG_NO_HUB_ROWS / _COLS, strict bits over a plan, dgs_spmm_csr_acc_min_around_f32
+extern "C" int dgs_version(void) { return 1005; }  // 1.1: cached plans, accumulating SpMM, scheduling hints, relabel; 1.2: strict-order bits, dgs_spmm_csr_ex_f32 (epilogue), dgs_sddmm_csr_plan_f32, non-blocking plan helpers; 1.3: accumulating min, min merge / redo, non-finite detector; 1.4 (rounds 4 / 5): hub threshold / tuning reload, the device gate (dgs_spmm_hub_selftest*, _hub_gate, _fold_gate), DGS_ALG_NO_HUB_ROWS / _COLS, strict bits over a plan, dgs_spmm_csr_acc_min_around_f32; 1.5 (round 6): dgs_spmm_fold_selftest / _selftest_detail / _selftest_families, the in-kernel fold opt-in (DGS_FOLD=1 | 2)
 extern "C" const char *dgs_arch(void) { return "gfx950"; }
 extern "C" const char *dgs_strerror(int code) {
   switch (code) {

@@ -1163,7 +1163,11 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
   // (fold_row: fixed unit order, so the result does not depend on who that is).  Ordering: stores performed at agent scope
   // (s_waitcnt vmcnt(0)) -> atomic add on the counter -> the last arriver's loads, issued after its own add has returned (and
   // been looked at: one more unit later, see count_in / settle).
-  const bool folding = ut.arrive != nullptr;
+  // (the masked sum - backward of max / min w.r.t. the dense operand - never folds in the kernel: its unit body already carries the
+  // gradient AND the arg-id gather windows, and the fold's ticket state on top of them spilled 61 VGPRs; the launchers
+  // leave ut.arrive null for it, and this makes the fold code dead at compile time)
+  constexpr bool CAN_FOLD = (OP != kOpMaskSum);
+  const bool folding = CAN_FOLD && ut.arrive != nullptr;
   const CohBuf cbp = coh_buf(part, folding ? ut.part_bytes : 0), cbe = coh_buf(ARG ? (void *)parte : (void *)part, folding ? ut.part_bytes : 0);
   int pend = -1;  // long-row index of the partial row this wave wrote last and has not counted in yet
   // ... and one step further down the pipeline: the row whose counter this wave has incremented WITHOUT having looked at the
@@ -1529,14 +1533,22 @@ static inline PanelPlan panel_plan(const SpmmArgs &a, int tiles, int G) {
 constexpr int kHintForceHub = 0x40000000;  // internal (the self-test itself): default threshold whatever the gate says
 constexpr int kHintForceFold = 0x20000000;  // internal (the self-test): fold inside the fused launch whatever the gate says
 constexpr int kHintNoFold = 0x10000000;     // internal (the self-test's hub pass): separate combine launch
+// What an extern "C" entry lets through from its caller's `algorithm` argument: the documented DGS_ALG_* bits and nothing else -
+// the three internal bits above override the device gate, which only the self-test may do.
+constexpr int kPublicHints = DGS_ALG_SHARED_GPU | DGS_ALG_STRICT_SUM | DGS_ALG_STRICT_NOFMA | DGS_ALG_NO_HUB_ROWS | DGS_ALG_NO_HUB_COLS;
+static inline int public_hints(int algorithm) { return algorithm & kPublicHints; }
 int hub_gate();                            // misc.hip: 1 = self-test passed on the current device, 0 = not run, -1 = failed
 void hub_gate_set(int state);
 int fold_gate();                           // the same for the in-kernel fold of partial rows
 void fold_gate_set(int state);
 // Fold the partial rows of multi-unit rows INSIDE the fused launch (last-arriving unit wave, spmm_units_body) instead of in a
-// combine launch behind it: DGS_FOLD=0 | 1 decides; unset, the device self-test does (the hand-over of partial rows between
-// workgroups on different XCDs rests on agent-scope stores / loads around an atomic counter - memory-system behaviour the CPU
-// emulation cannot see, so like the hub chains it is on only where dgs_spmm_hub_selftest has seen it produce the right bits).
+// combine launch behind it.  OFF unless asked for (round 6, ADVICE r5 / the decision rule of VERDICT r5 #1: the fold stays a default
+// only with a hardware measurement fold.on_ms < fold.off_ms, and there is none): DGS_FOLD unset or 0 = the combine launch (the path
+// every hardware-verified result of this repo took), DGS_FOLD=1 = fold in the kernel, DGS_FOLD=2 ("auto") = fold in the kernel on a
+// device where dgs_spmm_fold_selftest has seen it produce the combine launch's bits - every (G, V) family of partial rows, repeated,
+// with the fabric loaded by a streaming kernel.  The hand-over of partial rows between workgroups on different XCDs rests on
+// agent-scope stores / loads around an atomic counter (the MI355X guide's R1 form) - memory-system behaviour the plain CPU emulation
+// cannot see (tests/emu's relaxed-memory mode models it: sc1 write-through, per-wave store queues, per-XCD dirty lines, per-CU L1).
 // The fold's buffer descriptors reach a partial row through a 32-bit byte offset: in-kernel fold only below 2^31 bytes of partial
 // rows (20 MB on the headline graph; beyond, the combine launch folds - nothing else changes).
 static inline bool fold_fits(int64_t pslots, int64_t N) { return pslots * N * 4 < (int64_t(1) << 31); }
@@ -1544,7 +1556,8 @@ static inline bool fold_enabled(int hints) {
   if (hints & kHintNoFold) return false;
   if (hints & kHintForceFold) return true;
   const int e = tuning().fold;
-  return e == kTuneUnset ? fold_gate() > 0 : e != 0;
+  if (e == kTuneUnset || e == 0) return false;
+  return e == 2 ? fold_gate() > 0 : true;
 }
 static inline int hub_threshold(int hints = 0) {
   if (hints & DGS_ALG_NO_HUB_ROWS) return INT_MAX;
@@ -1552,6 +1565,16 @@ static inline int hub_threshold(int hints = 0) {
   const int e = tuning().hub_chain;
   if (e == kTuneUnset) return hub_gate() > 0 ? kHubChain : INT_MAX;
   if (e <= 0 || e > (1 << 24)) return INT_MAX;  // (the class bounds thub << c must stay inside an int)
+  return e < kHubChainMin ? kHubChainMin : e;
+}
+// Threshold a PLAN's hub table is cut with: the compiled-in default (or the explicit DGS_HUB_CHAIN), whatever the device gate says
+// at build time - a plan built before the self-test has run (a C caller that never runs it, a build queued during stream capture)
+// would otherwise carry n_hub = 0 for good and its planned sums would keep the tree on rows the plan-free calls chain once the gate
+// is up.  Whether a LAUNCH uses the table is still decided per call by hub_threshold(a.hints).
+static inline int plan_hub_threshold() {
+  const int e = tuning().hub_chain;
+  if (e == kTuneUnset) return kHubChain;
+  if (e <= 0 || e > (1 << 24)) return INT_MAX;
   return e < kHubChainMin ? kHubChainMin : e;
 }
 // Hub blocks of a launch: a multiple of 8 (XCD mapping), one per task up to four per CU (they come first in the grid: every hub
@@ -1598,7 +1621,7 @@ static int launch_impl(const SpmmArgs &a) {
       int thub = hub_ok<OP, V, G, ACC>() ? hub_threshold(a.hints) : INT_MAX;
       if (thub < tl) thub = tl;  // rows up to tl belong to the panel sweep (one sequential chain per row already)
       const HubTab ht = hub_tab(a.nnz, thub < INT_MAX ? thub : kHubChainMin, a.nnz / kT1 + 2);
-      const bool fold = fold_enabled(a.hints) && fold_fits(L.max_pslots, a.N);
+      const bool fold = OP != kOpMaskSum && fold_enabled(a.hints) && fold_fits(L.max_pslots, a.N);
       if (fold) {
         ut.slot_long = reinterpret_cast<const int *>(w + L.off_slot);
         ut.arrive = reinterpret_cast<int *>(w + L.off_arrive);
@@ -1691,7 +1714,7 @@ static int launch_impl(const SpmmArgs &a) {
     if (use_hub) ut.xcd_end = ph->xcd_hub;  // the hub rows' units (behind the others of each share) are not walked
     // in-kernel fold: the slot -> long-row map is part of the plan (behind the hub table), the arrival counters are the one piece
     // of the workspace a planned call has to zero (4 bytes per long row: 0.1 MB on the headline graph)
-    const bool fold = a.plan_long > 0 && fold_enabled(a.hints) && fold_fits(L.max_pslots, a.N);
+    const bool fold = OP != kOpMaskSum && a.plan_long > 0 && fold_enabled(a.hints) && fold_fits(L.max_pslots, a.N);
     if (fold) {
       ut.part_bytes = (unsigned)(L.max_pslots * a.N * 4);
       ut.slot_long = reinterpret_cast<const int *>(pb + (a.plan_off_hub ? plan_off_slot((size_t)a.plan_off_hub, a.plan_hub) : PL.off_slot));
@@ -1719,7 +1742,7 @@ static int launch_impl(const SpmmArgs &a) {
   const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
   const int thub = hub_ok<OP, V, G, ACC>() ? hub_threshold(a.hints) : INT_MAX;
   const HubTab ht = hub_tab(a.nnz, thub < INT_MAX ? thub : kHubChainMin, a.nnz / kT1 + 2);
-  const bool fold = fold_enabled(a.hints) && fold_fits(L.max_pslots, a.N);  // (the classify pass fills the slot map and zeroes the counters of the rows it lists)
+  const bool fold = OP != kOpMaskSum && fold_enabled(a.hints) && fold_fits(L.max_pslots, a.N);  // (the classify pass fills the slot map and zeroes the counters of the rows it lists)
   if (fold) {
     ut.slot_long = reinterpret_cast<const int *>(w + L.off_slot);
     ut.arrive = reinterpret_cast<int *>(w + L.off_arrive);

@@ -421,7 +421,7 @@ extern "C" int dgs_spmm_plan_build2(int64_t M, int64_t K, int64_t nnz, const int
   ch = ch < kPlanChMin ? kPlanChMin : (ch > (1 << 20) ? (1 << 20) : ch);  // the table capacities assume ch >= kPlanChMin
   const int tslice = plan_tslice(), unit = plan_unit();
   // hub rows (dgs_common.h Tuning::hub_chain; spmm_impl.h hub_threshold): listed longest first for the sum / mean launches
-  const int thub = hub_threshold();
+  const int thub = plan_hub_threshold();
 
   if (hipMemsetAsync(hdr, 0, PL.off_units, st) != hipSuccess) return DGS_ELAUNCH;
   if (hipMemsetAsync(ws, 0, WL.off_list, st) != hipSuccess) return DGS_ELAUNCH;           // counters, cnt, cum
@@ -537,7 +537,7 @@ extern "C" int dgs_spmm_plan_provisional_info(int64_t nnz, int64_t rows_gt_t1, i
   {  // hub rows, an UPPER bound (it sizes the hub grid, and 0 must mean "no hub row"): every row longer than the threshold is
     // longer than tslice when thub >= tslice, and in any case longer than t1 (thub >= kHubChainMin > t1); no more than fit
     // the nnz of those rows (with DGS_PLAN_TSLICE above DGS_HUB_CHAIN the tslice sums under-counted)
-    const int thub = hub_threshold();
+    const int thub = plan_hub_threshold();
     const bool above = thub >= info->tslice;
     const int64_t rows = above ? rows_gt_tslice : rows_gt_t1, nz = above ? nnz_gt_tslice : nnz_gt_t1;
     const int64_t hb = thub == INT_MAX ? 0 : (rows < nz / thub ? rows : nz / thub);

@@ -44,6 +44,12 @@ _lib.dgs_spmm_hub_selftest_bytes.restype = _sz
 _lib.dgs_spmm_hub_selftest_bytes.argtypes = []
 _lib.dgs_spmm_hub_selftest.restype = _int
 _lib.dgs_spmm_hub_selftest.argtypes = [_vp, _sz, _vp]
+_lib.dgs_spmm_fold_selftest.restype = _int
+_lib.dgs_spmm_fold_selftest.argtypes = [_vp, _sz, _int, _int, _vp]
+_lib.dgs_spmm_selftest_families.restype = _int
+_lib.dgs_spmm_selftest_families.argtypes = []
+_lib.dgs_spmm_selftest_detail.restype = _int
+_lib.dgs_spmm_selftest_detail.argtypes = [_vp, _int]
 _lib.dgs_reload_tuning.restype = None
 _lib.dgs_reload_tuning.argtypes = []
 _lib.dgs_spmm_csr_workspace_bytes.restype = _sz
@@ -133,7 +139,7 @@ _lib.dgs_scatter_add_rows_f32.restype = _int
 _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
 EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_reload_tuning', 'dgs_spmm_hub_threshold', 'dgs_spmm_hub_gate', 'dgs_spmm_fold_gate',
-           'dgs_spmm_hub_selftest_bytes', 'dgs_spmm_hub_selftest', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
+           'dgs_spmm_hub_selftest_bytes', 'dgs_spmm_hub_selftest', 'dgs_spmm_fold_selftest', 'dgs_spmm_selftest_families', 'dgs_spmm_selftest_detail', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
            'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes', 'dgs_spmm_plan_build', 'dgs_spmm_plan_build2',
            'dgs_spmm_plan_compact_bytes', 'dgs_spmm_plan_compact', 'dgs_spmm_plan_info_from_header',
            'dgs_spmm_plan_thresholds', 'dgs_spmm_plan_provisional_info', 'dgs_spmm_csr_ex_f32', 'dgs_spmm_csr_plan_workspace_bytes',
@@ -208,10 +214,15 @@ _selftested = set()  # device indices whose hub self-test has run in this proces
 def ensure_hub_selftest(dev) -> None:
     """Runs the library's device self-test of the hub chains once per device and process (include/dgsparse_hip.h, "Device
     gate": the default sum / mean chain their hub rows only on a device where that chain has been compared, bit for bit, with a
-    one-thread-per-element sequential kernel).  ~45 MB of scratch for a few milliseconds and ONE stream synchronisation, at the
-    first use of the device; skipped (and retried later) while a stream capture is in progress."""
+    one-thread-per-element sequential kernel - eight shapes, every lane family).  ~38 MB of scratch for a few milliseconds and ONE
+    stream synchronisation, at the first use of the device; skipped (and retried later) while a stream capture is in progress;
+    skipped for good - no scratch, no launch, no sync - in a process that pins DGS_HUB_CHAIN (and does not ask for DGS_FOLD=2: the
+    in-kernel fold is off unless asked for, and only "2" leaves the decision to the device)."""
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     if idx in _selftested:
+        return
+    if os.environ.get('DGS_HUB_CHAIN', '') != '' and os.environ.get('DGS_FOLD', '') != '2':
+        _selftested.add(idx)  # the library would return at once as well (dgs_spmm_hub_selftest): spare the allocation
         return
     if torch.cuda.is_current_stream_capturing():
         return
@@ -226,13 +237,38 @@ def ensure_hub_selftest(dev) -> None:
         _check(rc, 'spmm_hub_selftest')
     if fold_gate() < 0:
         import warnings
-        warnings.warn(f'dgsparse: the in-kernel fold self-test FAILED on cuda:{idx}: multi-unit rows are folded by a separate '
+        warnings.warn(f'dgsparse: the in-kernel fold self-test FAILED on cuda:{idx} (DGS_FOLD=2): multi-unit rows are folded by the '
                       'combine launch on this device (same results).  Please report this.', RuntimeWarning)
     if rc == 0:
         import warnings
         warnings.warn(f'dgsparse: the hub-chain self-test FAILED on cuda:{idx} ({torch.cuda.get_device_name(idx)}): sum / mean '
                       'fold rows above 64 nnz with the fixed tree on this device (within 1e-5 of the sequential reference except '
                       'on rows of several 10^4 nnz; DGS_ALG_STRICT_SUM is unaffected).  Please report this.', RuntimeWarning)
+
+
+def fold_selftest(dev=None, rounds: int = 3, load: bool = True, families=None):
+    """dgs_spmm_fold_selftest on `dev` (default: the current device): the in-kernel fold against the combine launch, sum / max / min,
+    every family of partial row, `rounds` times each, the last round under a streaming load from a second stream.  Returns
+    (verdict 1 | 0, [mismatches per family]); a full run (families=None) moves dgs_spmm_fold_gate().  What `bench.py`, `smoke()` and
+    the first_contact GPU tests call; a process gets it by itself only with DGS_FOLD=2."""
+    d = dev if dev is not None else torch.device('cuda', torch.cuda.current_device())
+    idx = d.index if d.index is not None else torch.cuda.current_device()
+    d = torch.device('cuda', idx)
+    flags = (1 if load else 0) | (sum(1 << (8 + int(f)) for f in families) if families is not None else 0)
+    with _on_device(d):
+        nb = int(_lib.dgs_spmm_hub_selftest_bytes())
+        scratch = torch.empty(nb, dtype=torch.uint8, device=d)
+        rc = int(_lib.dgs_spmm_fold_selftest(_p(scratch), nb, int(rounds), int(flags), _stream(d)))
+    if rc < 0:
+        _check(rc, 'spmm_fold_selftest')
+    return rc, selftest_detail()[2:2 + int(_lib.dgs_spmm_selftest_families())]
+
+
+def selftest_detail():
+    """Mismatch counters of the last self-tests of this process: [0] hub, [1] fold, [2 + f] fold family f, [16 + h] hub shape h."""
+    out = (ctypes.c_int32 * 64)()
+    _lib.dgs_spmm_selftest_detail(out, 64)
+    return list(out)
 
 
 def hub_gate() -> int:
@@ -242,7 +278,8 @@ def hub_gate() -> int:
 
 def fold_gate() -> int:
     """1 / 0 / -1: the self-test of the in-kernel fold (partial rows folded by the last-arriving unit wave instead of a combine
-    launch) passed / has not run / failed on the current device; DGS_FOLD=0 | 1 overrides."""
+    launch) passed / has not run / failed on the current device (fold_selftest runs it; the fold itself is off unless DGS_FOLD=1, or
+    DGS_FOLD=2 on a device where it passed)."""
     return int(_lib.dgs_spmm_fold_gate())
 
 

@@ -535,7 +535,8 @@ class DistSpMM:
                     va = sub[2]
                     if vr is not None:
                         va = torch.where(pos >= 0, vr[pos.clamp(min=0)], torch.ones((), dtype=vr.dtype, device=vr.device))
-                    self.ops.spmm_acc_min_around(sub[0], sub[1], va, halo, C, E, rows, p.n_local, plan.h_lo, p.n_local)
+                    if rows.numel() > 0:  # (like the two-launch form: an empty part is no launch)
+                        self.ops.spmm_acc_min_around(sub[0], sub[1], va, halo, C, E, rows, p.n_local, plan.h_lo, p.n_local)
                 else:
                     for (sub, rows, pos), first in zip(plan.min_parts(), (True, False)):
                         if rows.numel() > 0:

@@ -125,24 +125,33 @@ int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_
  * Device gate.  The hub workgroup keeps two register sets of gathers in flight across workgroup barriers while one wave chains
  * out of LDS - behaviour of the compiler's wait counts and of the memory system that only the hardware can confirm.  So without
  * an explicit DGS_HUB_CHAIN the chains are ON only on a device where dgs_spmm_hub_selftest() has passed in this process: it runs
- * the default sum on two generated matrices with hub rows (general and single-launch schedule) against a one-thread-per-element
- * sequential fmaf kernel and demands identical bits on the hub rows (and 1e-5 elsewhere).  It is the ONE entry point of this
- * library that synchronises (`stream`, once) - call it once per device at start-up (dgsparse's Python layer and torch binding
+ * the default sum on generated matrices with hub rows - every lane family of the hub workgroup (feature tiles of 16 / 8 / 4 / 2
+ * 16-byte lanes, scalar lanes), the general and the single-launch schedule, eight shapes - against a one-thread-per-element
+ * sequential fmaf kernel and demands identical bits on the hub rows (and 1e-5 elsewhere).  It is one of the TWO entry points of
+ * this library that synchronise (`stream`, once) - call it once per device at start-up (dgsparse's Python layer and torch binding
  * do, at the first use of a device); until it has passed, rows above 64 nnz take the fixed tree on that device (the round-3
  * schedule).  Returns 1 = passed (chains on from now on), 0 = FAILED (chains stay off on this device; results of the tree are
  * still within the contract's 1e-5 except on rows of > ~3 10^4 nnz), < 0 = DGS_E* (state unchanged).  DGS_HUB_CHAIN=n in the
- * environment bypasses the gate both ways (n = 0: off, n > 0: on at that threshold, self-test or not).
- *   scratch: dgs_spmm_hub_selftest_bytes() bytes of device memory, 256-B aligned, contents undefined on entry and exit.
+ * environment bypasses the gate both ways (n = 0: off, n > 0: on at that threshold) and the test is then skipped (returns 1, no
+ * launch, no synchronisation).
+ *   scratch: dgs_spmm_hub_selftest_bytes() bytes of device memory (~38 MB), 256-B aligned, contents undefined on entry and exit.
  * dgs_spmm_hub_gate(): 1 / 0 / -1 = passed / not run / failed on the current device.
  *
- * The same self-test has a second part with its own verdict (dgs_spmm_fold_gate(), same three values): the IN-KERNEL FOLD.  Rows
- * that are cut into several units leave partial rows in the workspace; by default a combine launch behind the fused launch folds
- * them.  With the fold on, the unit wave that completes a row (an arrival counter per row, zeroed per call) folds it inside
- * the fused launch - one launch less per call, and the fold overlaps the rest of the launch.  The partial rows then cross from
- * one workgroup to another - possibly on another XCD, behind another L2 - through agent-scope stores and loads ordered around
- * the counter's atomic: the self-test runs sum and max over a generated matrix with ~400 multi-unit rows both ways and demands
- * identical bits (values and arg ids).  DGS_FOLD=0 | 1 in the environment overrides the gate.  Same results either way: the
- * fold order is the fixed unit order in both.
+ * The IN-KERNEL FOLD (off by default).  Rows that are cut into several units leave partial rows in the workspace; a combine launch
+ * behind the fused launch folds them.  With DGS_FOLD=1 the unit wave that completes a row (an arrival counter per row and feature
+ * tile, zeroed per call) folds it inside the fused launch - one launch less per call, the fold overlapping the rest of the launch.
+ * The partial rows then cross from one workgroup to another - possibly on another XCD, behind another L2 - through agent-scope
+ * (sc1, write-through) stores and sc1 loads ordered around the counter's atomic.  Same results either way: the fold order is the
+ * fixed unit order in both.  It is not a default because no hardware measurement says it is faster (round 6), and because only the
+ * hardware can confirm the hand-over: dgs_spmm_fold_selftest() runs sum, max and min over generated matrices with ~600 multi-unit
+ * rows (2 .. 59 units) both ways - for every family of partial row the launchers can pick (whole-line slots; slots that share a
+ * 128-byte line two, four, eight to a line; scalar-lane slots; two feature tiles), `rounds` times each, the last round with a
+ * streaming kernel loading the fabric from a second stream (flags bit 0) - and demands identical bits (values and arg ids).
+ * flags bits 8 .. : run only these families (diagnosis; only a full run raises the gate).  Returns 1 / 0 / < 0 like the hub test;
+ * synchronises `stream` once; same scratch.  DGS_FOLD=2 ("auto") makes dgs_spmm_hub_selftest() run it (3 rounds, loaded) and
+ * folds in the kernel exactly where it passed (dgs_spmm_fold_gate(): 1 / 0 / -1).
+ * dgs_spmm_selftest_detail(out, n): the mismatch counters of the last tests of this process - [0] hub total, [1] fold total,
+ * [2 + f] fold family f (dgs_spmm_selftest_families() of them), [16 + h] hub shape h.
  * No reference counterpart (the reference has one kernel per algorithm id and no self-checks).
  */
 int dgs_spmm_hub_threshold(void);
@@ -150,6 +159,9 @@ size_t dgs_spmm_hub_selftest_bytes(void);
 int dgs_spmm_hub_selftest(void *scratch, size_t scratch_bytes, dgsStream_t stream);
 int dgs_spmm_hub_gate(void);
 int dgs_spmm_fold_gate(void);
+int dgs_spmm_fold_selftest(void *scratch, size_t scratch_bytes, int rounds, int flags, dgsStream_t stream);
+int dgs_spmm_selftest_families(void);
+int dgs_spmm_selftest_detail(int32_t *out, int n);
 
 /*
  * Cached locality plan of the row-stream schedule (new; the reference keeps no per-matrix state - the closest thing is

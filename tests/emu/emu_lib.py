@@ -62,7 +62,35 @@ def hub_selftest():
     a GPU, run here when the emulated library is loaded.  1 = passed (hub chains on by default), 0 = failed (off)."""
     nb = _lib.dgs_spmm_hub_selftest_bytes()
     scratch = _buf(nb)
-    return _lib.dgs_spmm_hub_selftest(_p(scratch), ctypes.c_size_t(nb), None)
+    # (a process that pins DGS_HUB_CHAIN skips the test - include/dgsparse_hip.h; the emulation wants the verdict whatever a test
+    # has set at load time)
+    had = {k: os.environ.pop(k, None) for k in ('DGS_HUB_CHAIN', 'DGS_FOLD')}
+    _lib.dgs_reload_tuning()
+    try:
+        return _lib.dgs_spmm_hub_selftest(_p(scratch), ctypes.c_size_t(nb), None)
+    finally:
+        for k, v in had.items():
+            if v is not None:
+                os.environ[k] = v
+        _lib.dgs_reload_tuning()
+
+
+def fold_selftest(rounds=1, load=False, families=None):
+    """dgs_spmm_fold_selftest on the emulation: (verdict, mismatch count per family).  families: indices to run (None = all; only a
+    full run moves the fold gate)."""
+    L = lib()
+    nb = L.dgs_spmm_hub_selftest_bytes()
+    scratch = _buf(nb)
+    flags = (1 if load else 0) | (sum(1 << (8 + f) for f in families) if families is not None else 0)
+    rc = L.dgs_spmm_fold_selftest(_p(scratch), ctypes.c_size_t(nb), int(rounds), int(flags), None)
+    return rc, selftest_detail()[2:2 + L.dgs_spmm_selftest_families()]
+
+
+def selftest_detail():
+    """The mismatch counters of the last self-tests: [0] hub, [1] fold, [2 + f] fold family f, [16 + h] hub shape h."""
+    out = (ctypes.c_int32 * 64)()
+    lib().dgs_spmm_selftest_detail(out, 64)
+    return list(out)
 
 
 def _p(a):
@@ -85,6 +113,24 @@ def set_env(**kw):
 last_ws = None  # the workspace of the last spmm() call (tests look at what a launch left in it)
 
 
+def mem_watch(buf=None):
+    """Relaxed-memory mode (DGS_EMU_MEM=relaxed in the environment BEFORE the library's first launch): watch this numpy buffer -
+    the accesses the kernels make to it through load_vec / store_vec, the raw-buffer builtins and the agent-scope atomics go through
+    the emulator's memory model (tests/emu/emu_rt.cpp).  None: forget every range."""
+    if buf is None:
+        lib().emu_mem_watch(None, ctypes.c_size_t(0))
+    else:
+        lib().emu_mem_watch(_p(buf), ctypes.c_size_t(buf.nbytes))
+
+
+def mem_report(clear=True):
+    """dict(unperformed=reads that missed a store still queued in another workgroup / dirty in another XCD's L2, l1_stale=plain
+    loads served from a line pinned before a newer write-through, loads, stores) since the counters were last cleared."""
+    out = (ctypes.c_ulonglong * 4)()
+    lib().emu_mem_report(out, int(clear))
+    return dict(unperformed=int(out[0]), l1_stale=int(out[1]), loads=int(out[2]), stores=int(out[3]))
+
+
 def spmm(op, rp, col, val, X, algorithm=0, plan=None):
     L = lib()
     M, nnz, (K, N) = rp.size - 1, col.size, X.shape
@@ -95,11 +141,15 @@ def spmm(op, rp, col, val, X, algorithm=0, plan=None):
         pbuf, info = plan
         wsb = L.dgs_spmm_csr_plan_workspace_bytes(op, i64(M), i64(N), i64(nnz), ctypes.byref(info))
         ws = _buf(wsb)
+        if os.environ.get('DGS_EMU_MEM') == 'relaxed':
+            mem_watch(None), mem_watch(ws)
         rc = L.dgs_spmm_csr_plan_f32(op, i64(M), i64(K), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C), _p(E), _p(pbuf),
                                      ctypes.byref(info), _p(ws), ctypes.c_size_t(wsb), None)
     else:
         wsb = L.dgs_spmm_csr_workspace_bytes(op, i64(M), i64(N), i64(nnz))
         ws = _buf(wsb) if wsb else None
+        if os.environ.get('DGS_EMU_MEM') == 'relaxed' and ws is not None:
+            mem_watch(None), mem_watch(ws)
         rc = L.dgs_spmm_csr_f32(op, i64(M), i64(K), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C), _p(E), int(algorithm),
                                 _p(ws), ctypes.c_size_t(wsb), None)
     assert rc == 0, f'emu spmm rc={rc}'

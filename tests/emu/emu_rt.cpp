@@ -67,6 +67,13 @@ namespace emu {
 Item *cur = nullptr;
 
 namespace {
+struct Block;
+}
+void mem_wave_end(Block *b, int wave);  // relaxed-memory mode (below)
+void mem_kernel_end();
+void mem_init();
+
+namespace {
 constexpr size_t kStack = 512 * 1024;
 enum State { RUN, WAIT_WAVE, WAIT_WSYNC, WAIT_BLOCK, DONE };
 struct Fiber {
@@ -95,6 +102,7 @@ struct Block {
   std::vector<Wave> waves;
   std::vector<char> lds;  // the section's contents while another workgroup owns it
   dim3 bid;
+  size_t dispatch = 0;    // position in the launch's dispatch order: CU = dispatch % CUs, XCD = dispatch % 8 (memory model)
   int live = 0, arrived = 0, remaining = 0;
   bool fresh = true;      // has not run yet: its LDS is whatever the previous owner left (as on the hardware)
 };
@@ -115,7 +123,8 @@ std::vector<char *> stack_pool;
 enum Order { FWD, REV, RAND };
 Order order_mode = FWD, block_order = FWD;
 unsigned long long order_state = 1, block_state = 1;
-int max_resident = 1;
+int max_resident = 1, preempt_n = 0;
+unsigned long long preempt_state = 0x9e3779b97f4a7c15ull;
 bool order_read = false;
 std::vector<unsigned> order_buf;
 unsigned xs_next(unsigned long long &st, unsigned n) {  // xorshift64*: deterministic for a seed
@@ -143,6 +152,8 @@ void order_init() {
   parse_order("DGS_EMU_ORDER", order_mode, order_state);
   parse_order("DGS_EMU_BLOCK_ORDER", block_order, block_state);
   if (const char *e = getenv("DGS_EMU_BLOCKS")) max_resident = atoi(e) > 1 ? atoi(e) : 1;
+  if (const char *e = getenv("DGS_EMU_PREEMPT")) preempt_n = atoi(e) > 0 ? atoi(e) : 0;
+  mem_init();
 }
 const std::vector<unsigned> &sweep_order(unsigned nthr) {
   if (order_buf.size() != nthr || order_mode == RAND) {
@@ -292,8 +303,9 @@ bool release_partial_collectives() {
   abort();
 }
 
-void init_block(Block &b, dim3 bid, dim3 block, dim3 grid, unsigned nthr) {
+void init_block(Block &b, dim3 bid, dim3 block, dim3 grid, unsigned nthr, size_t dispatch = 0) {
   b.bid = bid;
+  b.dispatch = dispatch;
   b.fibers.resize(nthr);
   b.waves.assign((nthr + 63) / 64, Wave{});
   b.live = b.remaining = (int)nthr;
@@ -341,6 +353,7 @@ bool run_block() {
       if (f.st == DONE) {
         blk->remaining--;
         finished_any = true;
+        if (!blk->waves[f.wave].live) mem_wave_end(blk, f.wave);  // a wave's outstanding stores complete when it ends
       }
       if (f.relaxed) {
         f.relaxes++;
@@ -351,6 +364,10 @@ bool run_block() {
     }
     if (!ran && !release_partial_collectives()) deadlock("no work-item can run");
     if (!ran) continue;
+    // DGS_EMU_PREEMPT=n: a resident workgroup loses its turn after a sweep with probability 1/n - workgroups then interleave at the
+    // granularity of rendezvous points instead of running to completion one after the other (hand-overs BETWEEN workgroups that
+    // never spin - the in-kernel fold's arrival tickets - see no interleaving otherwise)
+    if (max_resident > 1 && preempt_n > 0 && blk->remaining > 0 && xs_next(preempt_state, (unsigned)preempt_n) == 0) return true;
     bool all_spun = relaxed_now;
     if (all_spun && worked)
       for (auto &f : blk->fibers)
@@ -368,6 +385,204 @@ bool run_block() {
   return finished_any || !relaxed_any;
 }
 }  // namespace
+
+// ---- relaxed-memory mode (DGS_EMU_MEM=relaxed) ---------------------------------------------------------------------------------
+// What the plain emulation cannot get wrong: the ORDER and VISIBILITY of global-memory accesses between workgroups.  Every access
+// completes at once there, so a hand-over that drops its write-through bit, its drain or its L1 bypass still "works".  This mode
+// models what MI355X_MICROARCH.md ("Workgroup dispatch, XCD placement & inter-workgroup visibility") states about the hardware,
+// for the accesses the kernels make through load_vec / store_vec, the raw-buffer builtins, __hip_atomic_load / _store and the atomic
+// read-modify-writes, inside WATCHED address ranges (emu_mem_watch: the SpMM workspace - partial rows, tables, counters):
+//   * a wave's stores sit in the wave's queue until the wave drains it (`s_waitcnt vmcnt(0)`: drain_vmem) or ends; a read-modify-
+//     write atomic goes to memory at once - it can overtake the stores in front of it (why the fold drains before it counts in);
+//   * a performed sc1 store is written through to memory (visible everywhere); a performed PLAIN store stays dirty in the L2 of
+//     its workgroup's XCD (dispatch index % 8) - other XCDs read the old memory until the kernel ends (no release fence in these
+//     kernels);
+//   * a PLAIN load goes through the L1 of its workgroup's CU (dispatch index % CUs): the first plain load of a 128-byte line pins
+//     the moment, later plain loads of the line see memory as of that moment - never refreshed by other CUs' stores, for the whole
+//     launch (no acquire in these kernels); an sc1 load (buffer load with the sc1 bit, agent-scope atomic load) bypasses L1 and
+//     reads the XCD's L2 / memory as of now;
+//   * a wave sees its own queued stores; the waves of one CU see each other's performed stores.
+// Besides returning the (possibly stale) value the model COUNTS the reads that were served stale data although a newer value
+// existed (emu_mem_report): "unperformed" - the newest store to the word was still in another workgroup's queue or dirty in another
+// XCD's L2 - and "l1_stale" - a plain load that hit a line pinned before another workgroup's newer write-through.  A correct
+// hand-over has zero of both; tests/emu/mutation_check.py shows that dropping sc1 on the stores, the drain, or sc1 on the loads
+// of the in-kernel fold gives wrong bits or a non-zero count.
+}  // namespace emu
+#include <algorithm>
+#include <unordered_map>
+namespace emu {
+namespace {
+bool g_mem_on = false;
+struct Range { uintptr_t lo, hi; };
+std::vector<Range> g_watch;
+struct Perf { unsigned long long t; unsigned val; int cu; size_t wg; };
+struct WordHist { unsigned orig; std::vector<Perf> w; };
+struct Pending { uintptr_t word; unsigned val; int sc1; };
+struct Dirty { unsigned long long t; unsigned val; int cu; size_t wg; };
+std::unordered_map<uintptr_t, WordHist> g_hist;                 // performed write-throughs of this launch, per watched word
+std::unordered_map<uintptr_t, Dirty> g_dirty[8];                // performed plain stores, per XCD (dirty L2 lines)
+std::unordered_map<uintptr_t, unsigned long long> g_l1[1024];  // per CU: line -> moment of the first plain load
+std::unordered_map<unsigned long long, std::vector<Pending>> g_queue;  // per (workgroup, wave)
+std::unordered_map<uintptr_t, int> g_unperf;                   // watched word -> number of queued stores to it (any wave)
+unsigned long long g_now = 1;
+unsigned long long g_cnt_unperformed = 0, g_cnt_l1stale = 0, g_cnt_loads = 0, g_cnt_stores = 0;
+int g_ncu = 256;
+bool watched(uintptr_t a) {
+  for (const Range &r : g_watch)
+    if (a >= r.lo && a < r.hi) return true;
+  return false;
+}
+unsigned long long wave_key_of(const Block *b, int wave) { return ((unsigned long long)b->dispatch << 8) | (unsigned)wave; }  // (<= 16 waves per workgroup)
+unsigned long long wave_key() { return wave_key_of(blk, me->wave); }
+int cur_cu() { return (int)(blk->dispatch % (size_t)g_ncu); }
+int cur_xcd() { return (int)(blk->dispatch % 8); }
+void perform(const Block *b, const Pending &p) {
+  const int cu = (int)(b->dispatch % (size_t)g_ncu), xcd = (int)(b->dispatch % 8);
+  const unsigned long long t = ++g_now;
+  auto u = g_unperf.find(p.word);
+  if (u != g_unperf.end() && --u->second <= 0) g_unperf.erase(u);
+  if (p.sc1) {
+    WordHist &h = g_hist[p.word];
+    if (h.w.empty()) memcpy(&h.orig, reinterpret_cast<void *>(p.word), 4);
+    h.w.push_back(Perf{t, p.val, cu, b->dispatch});
+    memcpy(reinterpret_cast<void *>(p.word), &p.val, 4);
+    g_dirty[xcd].erase(p.word);  // write-through drops the line from the XCD's L2
+  } else {
+    g_dirty[xcd][p.word] = Dirty{t, p.val, cu, b->dispatch};
+  }
+}
+void drain_queue(const Block *b, int wave) {
+  auto it = g_queue.find(wave_key_of(b, wave));
+  if (it == g_queue.end()) return;
+  for (const Pending &p : it->second) perform(b, p);
+  g_queue.erase(it);
+}
+unsigned load_word(uintptr_t a, int sc1) {
+  g_cnt_loads++;
+  // 1. the wave's own queued stores
+  auto q = g_queue.find(wave_key());
+  if (q != g_queue.end())
+    for (size_t i = q->second.size(); i-- > 0;)
+      if (q->second[i].word == a) return q->second[i].val;
+  const int cu = cur_cu(), xcd = cur_xcd();
+  unsigned long long T = g_now;
+  if (!sc1) {
+    auto &l1 = g_l1[cu];
+    auto ins = l1.emplace(a >> 7, g_now);
+    T = ins.first->second;
+  }
+  // 2. value as of T: this XCD's dirty line, else memory's history
+  unsigned val;
+  bool newer_elsewhere = false, stale_l1 = false;
+  auto d = g_dirty[xcd].find(a);
+  auto h = g_hist.find(a);
+  bool have = false;
+  unsigned long long tv = 0;
+  if (d != g_dirty[xcd].end() && (d->second.t <= T || d->second.cu == cu)) {
+    val = d->second.val;
+    tv = d->second.t;
+    have = true;
+  }
+  if (h != g_hist.end()) {
+    const WordHist &wh = h->second;
+    unsigned mv = wh.orig;
+    unsigned long long mt = 0;
+    for (const Perf &p : wh.w)
+      if (p.t <= T || p.cu == cu) { mv = p.val; mt = p.t; }
+    if (!have || mt > tv) { val = mv; tv = mt; have = true; }
+    if (!wh.w.empty() && wh.w.back().t > tv && wh.w.back().wg != blk->dispatch) stale_l1 = true;
+  }
+  if (!have) memcpy(&val, reinterpret_cast<void *>(a), 4);
+  // 3. hazards: a newer value exists that this read cannot see
+  if (g_unperf.count(a)) newer_elsewhere = true;  // (own-wave stores returned above; another wave's store is still in its queue)
+  for (int x = 0; x < 8 && !newer_elsewhere; x++)
+    if (x != xcd) {
+      auto o = g_dirty[x].find(a);
+      if (o != g_dirty[x].end() && o->second.t > tv) newer_elsewhere = true;
+    }
+  if (newer_elsewhere) g_cnt_unperformed++;
+  if (stale_l1) g_cnt_l1stale++;
+  return val;
+}
+}  // namespace
+
+void mem_init() {
+  const char *e = getenv("DGS_EMU_MEM");
+  g_mem_on = e && !strcmp(e, "relaxed");
+  if (const char *c = getenv("DGS_EMU_CUS")) g_ncu = atoi(c) > 0 && atoi(c) <= 1024 ? atoi(c) : 256;
+}
+bool mem_on() { return g_mem_on && blk != nullptr && !g_watch.empty(); }
+void mem_load(const void *p, void *out, unsigned bytes, int sc1) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  if (!watched(a) || (a & 3) || (bytes & 3)) {
+    memcpy(out, p, bytes);
+    return;
+  }
+  for (unsigned i = 0; i < bytes; i += 4) {
+    const unsigned v = load_word(a + i, sc1);
+    memcpy(static_cast<char *>(out) + i, &v, 4);
+  }
+}
+void mem_store(void *p, const void *src, unsigned bytes, int sc1) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  if (!watched(a) || (a & 3) || (bytes & 3)) {
+    memcpy(p, src, bytes);
+    return;
+  }
+  std::vector<Pending> &q = g_queue[wave_key()];
+  for (unsigned i = 0; i < bytes; i += 4) {
+    unsigned v;
+    memcpy(&v, static_cast<const char *>(src) + i, 4);
+    q.push_back(Pending{a + i, v, sc1});
+    g_unperf[a + i]++;
+    g_cnt_stores++;
+  }
+}
+void mem_drain() {  // s_waitcnt vmcnt(0): a WAVE instruction - every live lane is here (lockstep), then the wave's stores are performed
+  if (!mem_on()) return;
+  wave_sync();
+  drain_queue(blk, me->wave);
+}
+void mem_wave_end(Block *b, int wave) {
+  if (g_mem_on) drain_queue(b, wave);
+}
+void mem_kernel_end() {  // the end of a kernel is a release / the start of the next an acquire: everything lands, every cache is cold
+  if (!g_mem_on) return;
+  for (auto &kv : g_queue) (void)kv;  // (queues are empty: every wave ended)
+  g_queue.clear();
+  g_unperf.clear();
+  for (int x = 0; x < 8; x++) {
+    // dirty lines are written back in the order they were written (two XCDs that wrote one word: the later one wins, as on a
+    // write-back of both)
+    for (auto &kv : g_dirty[x]) {
+      bool newest = true;
+      for (int y = 0; y < 8; y++)
+        if (y != x) {
+          auto o = g_dirty[y].find(kv.first);
+          if (o != g_dirty[y].end() && o->second.t > kv.second.t) newest = false;
+        }
+      auto h = g_hist.find(kv.first);
+      if (h != g_hist.end() && !h->second.w.empty() && h->second.w.back().t > kv.second.t) newest = false;
+      if (newest) memcpy(reinterpret_cast<void *>(kv.first), &kv.second.val, 4);
+    }
+  }
+  for (int x = 0; x < 8; x++) g_dirty[x].clear();
+  g_hist.clear();
+  for (int c = 0; c < g_ncu; c++) g_l1[c].clear();
+}
+}  // namespace emu
+extern "C" void emu_mem_watch(const void *base, size_t bytes) {  // bytes = 0: forget every range
+  if (!bytes) emu::g_watch.clear();
+  else emu::g_watch.push_back(emu::Range{reinterpret_cast<uintptr_t>(base), reinterpret_cast<uintptr_t>(base) + bytes});
+}
+extern "C" void emu_mem_report(unsigned long long *out /* [4]: unperformed, l1_stale, loads, stores */, int clear) {
+  out[0] = emu::g_cnt_unperformed;
+  out[1] = emu::g_cnt_l1stale;
+  out[2] = emu::g_cnt_loads;
+  out[3] = emu::g_cnt_stores;
+  if (clear) emu::g_cnt_unperformed = emu::g_cnt_l1stale = emu::g_cnt_loads = emu::g_cnt_stores = 0;
+}
+namespace emu {
 
 void relax() {  // s_sleep inside a spin-wait: give the turn away (to the other work-items, then to the other workgroups)
   me->relaxed = true;
@@ -450,7 +665,7 @@ void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx) {
     Block b;
     blk = &b;
     for (size_t i = 0; i < nblocks; i++) {
-      init_block(b, bid_of(order[i]), block, grid, nthr);
+      init_block(b, bid_of(order[i]), block, grid, nthr, i);
       run_block();
       if (b.remaining > 0) deadlock("its work-items wait for another workgroup, and workgroups run one at a time (DGS_EMU_BLOCKS)");
     }
@@ -464,7 +679,8 @@ void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx) {
       while (next < nblocks && (int)res.size() < max_resident) {
         Block *b = new Block;
         blk = b;
-        init_block(*b, bid_of(order[next++]), block, grid, nthr);
+        init_block(*b, bid_of(order[next]), block, grid, nthr, next);
+        next++;
         res.push_back(b);
       }
       if (turn >= res.size()) turn = 0;
@@ -498,6 +714,7 @@ void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx) {
       turn++;
     }
   }
+  mem_kernel_end();
   k_fn = saved_fn;
   k_ctx = saved_ctx;
   cur = saved_cur;

@@ -61,6 +61,12 @@ void block_sync();
 void relax();
 void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx);
 void log_launch(const char *kern, dim3 grid);  // tests ask which kernels a call launched (emu_launch_log)
+// relaxed-memory mode (DGS_EMU_MEM=relaxed, emu_rt.cpp): the accesses that go through these see per-wave store queues, per-XCD dirty
+// lines and per-CU L1 snapshots inside the watched address ranges instead of "every access completes at once"
+bool mem_on();
+void mem_load(const void *p, void *out, unsigned bytes, int sc1);
+void mem_store(void *p, const void *src, unsigned bytes, int sc1);
+void mem_drain();
 template <typename F>
 inline void launch(dim3 grid, dim3 block, F &&f) {
   auto tramp = [](void *c) { (*static_cast<typename std::remove_reference<F>::type *>(c))(); };
@@ -97,6 +103,14 @@ static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) {
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+typedef struct emuEvent *hipEvent_t;
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)(uintptr_t)0x51; return hipSuccess; }  // (launches run at once, in call order)
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (hipEvent_t)(uintptr_t)0xe1; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 // 256 CUs like the MI355X, so that every grid-shape decision that depends on cu_count() (hub block caps, panel workgroups) is taken
 // as on the hardware (it used to be 16); DGS_EMU_CUS overrides (read once per process: cu_count() caches it)
@@ -199,7 +213,27 @@ static inline T atomicMin(T *p, T v) { const T o = *p; *p = o < v ? o : v; retur
 #ifndef __HIP_MEMORY_SCOPE_AGENT
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #endif
-// (__hip_atomic_load / _store / _fetch_add are clang builtins on the host as well)
+// __hip_atomic_load / _store at agent scope lower to sc1 accesses on gfx950 (L1 bypass / write-through); a read-modify-write goes
+// to memory at once, ahead of the wave's queued stores (relaxed: no ordering) - one fiber runs at a time, so a plain RMW is atomic
+namespace emu {
+template <typename T>
+static inline T atomic_load_(const T *p, int scope) {
+  T v;
+  if (mem_on()) mem_load(p, &v, sizeof(T), scope >= __HIP_MEMORY_SCOPE_AGENT);
+  else v = *p;
+  return v;
+}
+template <typename T>
+static inline void atomic_store_(T *p, T v, int scope) {
+  if (mem_on()) mem_store(p, &v, sizeof(T), scope >= __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <typename T>
+static inline T atomic_fetch_add_(T *p, T v) { const T o = *p; *p = o + v; return o; }
+}  // namespace emu
+#define __hip_atomic_load(p, order, scope) ::emu::atomic_load_((p), (scope))
+#define __hip_atomic_store(p, v, order, scope) ::emu::atomic_store_((p), (v), (scope))
+#define __hip_atomic_fetch_add(p, v, order, scope) ::emu::atomic_fetch_add_((p), (v))
 
 // raw buffer loads / stores through a descriptor (the in-kernel fold's 16-byte sc1 accesses): base + byte offset, and - where the
 // hardware silently drops an out-of-range access - an abort, because in the product an out-of-range partial-row access is a bug
@@ -215,18 +249,20 @@ static inline void buf_check(const BufRsrc &r, long off, const char *what) {
     abort();
   }
 }
-static inline u4_t buf_load128(const BufRsrc &r, int voff, int soff) {
+static inline u4_t buf_load128(const BufRsrc &r, int voff, int soff, int aux) {
   buf_check(r, (long)(unsigned)voff + soff, "load");
   u4_t v;
-  memcpy(&v, r.base + (unsigned)voff + soff, 16);
+  if (mem_on()) mem_load(r.base + (unsigned)voff + soff, &v, 16, (aux >> 4) & 1);  // aux bit 4 = sc1
+  else memcpy(&v, r.base + (unsigned)voff + soff, 16);
   return v;
 }
-static inline void buf_store128(u4_t v, const BufRsrc &r, int voff, int soff) {
+static inline void buf_store128(u4_t v, const BufRsrc &r, int voff, int soff, int aux) {
   buf_check(r, (long)(unsigned)voff + soff, "store");
-  memcpy(r.base + (unsigned)voff + soff, &v, 16);
+  if (mem_on()) mem_store(r.base + (unsigned)voff + soff, &v, 16, (aux >> 4) & 1);
+  else memcpy(r.base + (unsigned)voff + soff, &v, 16);
 }
 }  // namespace emu
 #define __amdgpu_buffer_rsrc_t ::emu::BufRsrc
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, n, flags) (::emu::BufRsrc{(char *)(p), (unsigned)(n)})
-#define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) ::emu::buf_load128(r, voff, soff)
-#define __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, aux) ::emu::buf_store128(v, r, voff, soff)
+#define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) ::emu::buf_load128(r, voff, soff, aux)
+#define __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, aux) ::emu::buf_store128(v, r, voff, soff, aux)

@@ -1,0 +1,152 @@
+"""TEST INFRASTRUCTURE ONLY: does the emulation's RELAXED-MEMORY mode notice a broken hand-over?  (VERDICT r5 #3.)
+
+The in-kernel fold (dgsparse-lib_amd/csrc/spmm_impl.h: spmm_units_body / fold_row) moves partial rows from the unit wave that wrote
+them to the wave that folds the row - another workgroup, possibly another XCD - with the MI355X guide's R1 form: 16-byte sc1
+(write-through) stores -> `s_waitcnt vmcnt(0)` -> relaxed agent-scope arrival counter; the last arriver: returned counter -> sc1
+(L1-bypassing) loads.  The plain emulation completes every access at once, so it cannot tell that form from a broken one.  Under
+DGS_EMU_MEM=relaxed (tests/emu/emu_rt.cpp: per-wave store queues performed at the wave's drain, plain stores dirty in their XCD's
+L2 until the kernel ends, plain loads through a per-CU L1 that is never refreshed, workgroups interleaved by DGS_EMU_PREEMPT) each
+mutant below is a copy of csrc with ONE element of the protocol removed:
+
+  sc1-store   store_part_coherent -> store_vec            (plain stores: the partial rows stay in the writer's XCD)
+  drain       drain_vmem() removed from count_in          (the counter overtakes the stores)
+  sc1-load    fold_row<..., COH = true> -> false          (plain loads: served by the folding CU's L1)
+  tail        the pipeline drain behind the unit loop removed (the wave's last partial row is never counted in)
+  late        count_in right behind the stores of the SAME unit without the drain (ticket issued while the stores are in flight)
+
+A mutant is KILLED when some schedule gives bits that differ from the oracle's or a non-zero hazard count (reads that missed a
+store still queued / dirty elsewhere, plain loads served stale by L1); the unmutated sources must give the oracle's bits and ZERO
+hazards under every schedule.  python tests/emu/mutation_check_mem.py > profiles/r06_emu_mutants.txt"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, 'dgsparse-lib_amd', 'csrc')
+SCHEDULES = [dict(DGS_EMU_BLOCKS='24', DGS_EMU_BLOCK_ORDER='rand:1', DGS_EMU_PREEMPT='40'),
+             dict(DGS_EMU_BLOCKS='40', DGS_EMU_BLOCK_ORDER='rand:2', DGS_EMU_PREEMPT='16'),
+             dict(DGS_EMU_BLOCKS='8', DGS_EMU_BLOCK_ORDER='rev', DGS_EMU_PREEMPT='24', DGS_EMU_ORDER='rev')]
+
+
+def sub(src, old, new, count=1):
+    assert src.count(old) == count, (old, src.count(old), count)
+    return src.replace(old, new)
+
+
+def m_sc1_store(s):
+    s = sub(s, 'store_part_coherent<V>(part, slot, cbp, acc);', 'store_vec<V>(part + slot, acc);')
+    return sub(s, 'if constexpr (ARG) store_part_coherent<V>(parte, slot, cbe, ei);', 'if constexpr (ARG) store_vec<V>(parte + slot, ei);')
+
+
+def m_drain(s):
+    return sub(s, '    drain_vmem();  // s_waitcnt vmcnt(0), as inline asm:', '    // (mutant: no drain)  // s_waitcnt vmcnt(0), as inline asm:')
+
+
+def m_sc1_load(s):
+    return sub(s, 'fold_row<G, V, OP, ACC, true>(lr, lane, N,', 'fold_row<G, V, OP, ACC, false>(lr, lane, N,')
+
+
+def m_tail(s):
+    return sub(s, '''    settle();
+    if (pend >= 0) count_in(pend);
+    settle();
+  }''', '''    settle();
+  }''')
+
+
+def m_late(s):
+    # the ticket for a partial row is drawn right behind its own stores (no unit in between, no drain in front of the atomic)
+    s = sub(s, '    if (folding && !whole) pend = ut.slot_long[d.w];', '''    if (folding && !whole) {
+      if (lane == 0)
+        tick_old = __hip_atomic_fetch_add(ut.arrive + (int64_t)ut.slot_long[d.w] * gridDim.y + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tick_row = ut.slot_long[d.w];
+    }''')
+    return s
+
+
+MUTANTS = {'none': lambda s: s, 'sc1-store (plain stores)': m_sc1_store, 'drain (no s_waitcnt vmcnt(0) before the counter)': m_drain,
+           'sc1-load (plain loads in the fold)': m_sc1_load, 'tail (last partial row never counted in)': m_tail,
+           'late (ticket drawn right behind the stores, no drain)': m_late}
+
+RUN = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(here)r)
+import oracle
+import emu_lib as E
+rng = np.random.default_rng(int(os.environ.get('MUT_SEED', '3')))
+M, K = 2400, 9000
+deg = rng.integers(0, 5, M)
+deg[100:1150] = 200                                 # single-unit rows (no partial rows): the bulk of the nnz
+deg[1500:1660] = rng.integers(257, 1400, 160)       # 2 .. 6 units
+deg[7] = 5200                                       # 21 units
+deg[2300:2340] = 300                                # 2 units: neighbours in the unit table, often waves of one workgroup
+rp = np.zeros(M + 1, np.int32); rp[1:] = np.cumsum(deg)
+assert rp[-1] > (1 << 18)
+col = np.concatenate([np.sort(rng.choice(K, d, replace=False)) for d in deg]).astype(np.int32)
+val = (rng.random(col.size, dtype=np.float32) - 0.3).astype(np.float32)
+E.set_env(DGS_FOLD=1, DGS_HUB_CHAIN=0, DGS_NBU=16)
+bad = unp = l1 = 0
+plan = E.spmm_plan(rp, col, K)
+for N, cells in ((16, ((E.SUM, None), (E.MAX, plan))), (20, ((E.MIN, None), (E.SUM, plan))), (64, ((E.MAX, None),))):
+    X = rng.random((K, N), dtype=np.float32)
+    for op, pl in cells:
+        E.mem_report()
+        C, Eo = E.spmm(op, rp, col, val, X, plan=pl)
+        r = E.mem_report()
+        unp += r['unperformed']; l1 += r['l1_stale']
+        assert r['stores'] > 0 and r['loads'] > 0, 'the memory model saw no access: is DGS_EMU_MEM=relaxed set?'
+        ref, Er = oracle.spmm({E.SUM: 'sum', E.MAX: 'max', E.MIN: 'min'}[op], rp, col, val, X, fma=True)
+        if op == E.SUM:  # (tree rows: compared with the fold-off bits below; here: nothing unwritten, nothing far off)
+            E.set_env(DGS_FOLD=0)
+            C0, _ = E.spmm(op, rp, col, val, X, plan=pl)
+            E.set_env(DGS_FOLD=1)
+            bad += int((C.view(np.int32) != C0.view(np.int32)).sum())
+        else:
+            bad += int((C.view(np.int32) != ref.view(np.int32)).sum()) + int((Eo != Er).sum())
+print('BAD', bad, 'UNPERFORMED', unp, 'L1STALE', l1)
+'''
+
+
+def main():
+    out = os.path.join(HERE, '_build_mut')
+    src0 = open(os.path.join(CSRC, 'spmm_impl.h')).read()
+    only = sys.argv[1:]
+    rows = []
+    for k, (name, fn) in enumerate(MUTANTS.items()):
+        if only and not any(o in name for o in only):
+            continue
+        d = os.path.join(out, f'mem{k}')
+        shutil.rmtree(d, ignore_errors=True)
+        shutil.copytree(CSRC, os.path.join(d, 'csrc'), ignore=shutil.ignore_patterns('*.so', '*.o', 'build'))
+        open(os.path.join(d, 'csrc', 'spmm_impl.h'), 'w').write(fn(src0))
+        r = subprocess.run(['make', '-C', HERE, '-j8', f'CSRC={d}/csrc', f'B={d}/b'], capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.exit(f'{name}: build failed\n' + r.stderr[-2000:])
+        res = []
+        for sch in SCHEDULES:
+            env = {k_: v for k_, v in os.environ.items() if not k_.startswith('DGS_')}
+            env.update(sch, DGS_EMU_LIB=f'{d}/b/libdgs_emu.so', DGS_EMU_MEM='relaxed')
+            p = subprocess.run([sys.executable, '-c', RUN % dict(root=ROOT, here=HERE)], capture_output=True, text=True, env=env,
+                               timeout=3600)
+            m = re.search(r'BAD (\d+) UNPERFORMED (\d+) L1STALE (\d+)', p.stdout)
+            if p.returncode != 0 or not m:
+                res.append('abort: ' + (p.stderr.strip().splitlines() or ['?'])[-1][:80])
+            else:
+                b, u, l = (int(x) for x in m.groups())
+                res.append('ok' if (b, u, l) == (0, 0, 0) else f'{b} wrong bits, {u} unperformed reads, {l} L1-stale reads')
+        rows.append((name, res))
+        print(f'{name:52s} ' + ' | '.join(res), flush=True)
+    ok = all(x == 'ok' for n, r in rows if n == 'none' for x in r) and all(any(x != 'ok' for x in r) for n, r in rows if n != 'none')
+    print('schedules: ' + ' | '.join(' '.join(f'{k[8:]}={v}' for k, v in s.items()) for s in SCHEDULES))
+    print('unmutated sources: right bits and zero hazards under every schedule; every mutant is killed by at least one' if ok
+          else 'MUTATION CHECK FAILED')
+    shutil.rmtree(out, ignore_errors=True)
+    return 0 if ok else 1
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -605,3 +605,59 @@ def test_strict_order_over_the_cached_plan(graph, N):
     assert _kernels(E.launch_log()) == ['spmm_classify_strict', 'spmm_fused_strict']
     assert_bitexact(C2, oracle.spmm('sum', rp, col, val, X, fma=True)[0], 'override: plan-free strict')
     E.set_env(DGS_STRICT_HUB=None)
+
+
+def _few_valued_case(general, N, seed=8):
+    """Rows of 2 048 / 4 096 / 12 288 / 16 384 nnz, weights AND features drawn like the reference's example drivers fill theirs:
+    (float)(rand() % 3) / 10 (example/util/sp_util.hpp:44-48, what example/ge-spmm/spmm.cu feeds its kernels)."""
+    rng = np.random.default_rng(seed)
+    M, K = (66000, 40000) if general else (48, 40000)
+    deg = rng.integers(0, 3, M)
+    lens = (2048, 4096, 12288, 16384)
+    for i, L in enumerate(lens):
+        deg[5 + 7 * i] = L
+    rp = np.zeros(M + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    col = np.concatenate([np.sort(rng.choice(K, d, replace=False)) for d in deg]).astype(np.int32)
+    val = (rng.integers(0, 3, col.size) / 10).astype(np.float32)
+    X = (rng.integers(0, 3, (K, N)) / 10).astype(np.float32)
+    rows = [5 + 7 * i for i in range(len(lens))]
+    return rp, col, val, X, K, rows
+
+
+@pytest.mark.parametrize('general,N', [(False, 64), (True, 64), (False, 20)])
+def test_few_valued_data_strict_and_low_threshold_match_the_reference_default_does_not(general, N):
+    """VERDICT r5 #4 (north_star: "within 1e-5 rel fp32 for sum on the same CSR inputs"): on operands drawn from {0, .1, .2} the
+    reference's sequential chain carries a SYSTEMATIC rounding bias (~1.1e-5 of the exact sum at 2 048 nnz, ~2.7e-5 at 16 384), which
+    no accurate summation shares.  The contract on such data is therefore met by reproducing the chain: the strict bits (any row
+    length) or DGS_HUB_CHAIN=1024 (rows above 1 024 nnz chained) - 0 elements beyond 1e-5 of the reference's own host loop
+    (spmm_reference_host, example/util/sp_util.hpp:73-83, compiled in place into oracle/_ref when /root/reference is there; else the
+    oracle's restatement, pinned to it bit for bit by test_oracle_pin.py).  The DEFAULT threshold (16 384) keeps the tree on these
+    rows and is documented to miss 1e-5 there (include/dgsparse_hip.h, contract comment): this test pins that too, so
+    the day the default changes the documentation has to."""
+    rp, col, val, X, K, rows = _few_valued_case(general, N)
+    ref = oracle.ref_spmm_sum(rp, col, val, X) if oracle.have_ref() else oracle.spmm('sum', rp, col, val, X, fma=False)[0]
+
+    def rel(C):
+        return np.abs(C[rows].astype(np.float64) - ref[rows]) / np.maximum(np.abs(ref[rows]), 1e-30)
+
+    E.set_env(DGS_HUB_CHAIN=None)  # the library's default threshold (the emulated device passed the hub self-test at load)
+    assert E.lib().dgs_spmm_hub_threshold() == 16384
+    C_nofma, _ = E.spmm(E.SUM, rp, col, val, X, algorithm=E.ALG_STRICT_NOFMA)
+    assert_bitexact(C_nofma, ref, 'strict, product rounded before the add == the reference host loop')
+    C_strict, _ = E.spmm(E.SUM, rp, col, val, X, algorithm=E.ALG_STRICT_SUM)
+    assert rel(C_strict).max() <= 1e-5, rel(C_strict).max(axis=1)
+    E.set_env(DGS_HUB_CHAIN=1024)
+    C_low, _ = E.spmm(E.SUM, rp, col, val, X)
+    assert_bitexact(C_low[rows], C_strict[rows], 'rows above the lowered threshold are the strict chains')
+    assert rel(C_low).max() <= 1e-5
+    E.set_env(DGS_HUB_CHAIN=None)
+    C_def, _ = E.spmm(E.SUM, rp, col, val, X)
+    r = rel(C_def)
+    # rows of 12 288 and 16 384 nnz: (nearly) every element beyond the bar, around 2e-5 / 2.7e-5; 2 048: around the bar
+    assert (r[2] > 1e-5).mean() > 0.9 and (r[3] > 1e-5).mean() > 0.9, (r[2].max(), r[3].max())
+    assert 1.2e-5 < r[3].max() < 5e-5 and 1.0e-5 < r[2].max() < 4e-5, (r[2].max(), r[3].max())
+    assert r[:2].max() < 3e-5
+    # ... and it is the reference's chain that is off, not the tree: the tree is the closer of the two to the exact sum
+    exact = oracle.spmm_sum_f64(rp, col, val, X)
+    assert np.abs(C_def[rows] - exact[rows]).max() < np.abs(ref[rows] - exact[rows]).max()

@@ -1,0 +1,148 @@
+"""What hipcc made of the kernels that SHIP: the gfx950 code objects are taken out of the in-tree
+`dgsparse/libdgsparse_hip.so` (the clang offload bundles of its twelve translation units), their kernel notes are read with
+llvm-readelf, and the headline instantiation is disassembled.  No GPU, no recompilation: ~10 s.
+
+Pinned here, so that a source edit that changes any of it fails on the CPU and not as a silent slowdown / wrong result on the box:
+  * `spmm_fused<16, 4, SUM, values, !ACC, HUB>` (the kernel bench.py times): no scratch, <= 96 VGPRs (five waves per SIMD),
+    <= 28 032 B of LDS (five workgroups per CU);
+  * the in-kernel fold's hand-over in that kernel (MI355X guide, R1 form): an `s_waitcnt vmcnt(0)` directly in front of every
+    `global_atomic_add`, `sc1` on every partial-row buffer store / load, no `buffer_wbl2` / `buffer_inv` anywhere;
+  * every `spmm_fused` / `spmm_small` / `spmm_small_hub` / `spmm_combine` instantiation of the library within its spill budget
+    (0 except for the documented ones below).
+The figures DESIGN.md quotes from the code object come from `bench/isa_report.sh` (same extraction, human-readable)."""
+import os
+import re
+import struct
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, 'dgsparse-lib_amd', 'dgsparse', 'libdgsparse_hip.so')
+LLVM = '/opt/rocm/lib/llvm/bin'
+HEADLINE = 'spmm_fused<16, 4, 0, true, false, true>'
+
+# spilled VGPRs allowed per instantiation (regex on the demangled name -> budget); everything else: 0
+SPILL_BUDGET = [
+    (r'spmm_fused<(8|16|32), 4, 4, (true|false), false, false>', 40),  # masked sum (backward of max / min w.r.t. the dense operand): gradient AND arg-id gather windows at 5 waves per SIMD
+    (r'spmm_fused<64, 4, 4, (true|false), false, false>', 24),
+    (r'spmm_fused<(4|8), 4, (0|3), (true|false), false, true>', 2),    # narrow tiles with the hub role
+]
+
+
+def _code_objects(tmp):
+    """[path of each gfx950 ELF image bundled into the shared library]"""
+    blob = open(LIB, 'rb').read()
+    magic = b'__CLANG_OFFLOAD_BUNDLE__'
+    out, i = [], 0
+    while True:
+        i = blob.find(magic, i)
+        if i < 0:
+            break
+        n = struct.unpack_from('<Q', blob, i + 24)[0]
+        o = i + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from('<QQQ', blob, o)
+            o += 24
+            triple = blob[o:o + tl].decode()
+            o += tl
+            if 'gfx950' in triple and size:
+                p = os.path.join(tmp, f'co{len(out)}.elf')
+                open(p, 'wb').write(blob[i + off:i + off + size])
+                out.append(p)
+        i += len(magic)
+    return out
+
+
+@pytest.fixture(scope='module')
+def kernels(tmp_path_factory):
+    if not os.path.exists(LIB):
+        pytest.fail('libdgsparse_hip.so is not built (python -c "import __graft_entry__ as g; g.build()")')
+    tmp = str(tmp_path_factory.mktemp('isa'))
+    table = {}
+    for co in _code_objects(tmp):
+        notes = subprocess.run([f'{LLVM}/llvm-readelf', '--notes', co], capture_output=True, text=True, check=True).stdout
+        for k in re.split(r'\n\s+- \.agpr_count', notes)[1:]:
+            name = re.search(r'\.name:\s+(\S+)', k).group(1)
+            g = lambda f: int(re.search(r'\.' + f + r':\s+(\d+)', k).group(1))
+            table[name] = dict(co=co, vgpr=g('vgpr_count'), spilled=g('vgpr_spill_count'), sgpr=g('sgpr_count'),
+                               lds=g('group_segment_fixed_size'), scratch=g('private_segment_fixed_size'))
+    names = list(table)
+    dem = subprocess.run(['c++filt'], input='\n'.join(names), capture_output=True, text=True, check=True).stdout.splitlines()
+    for n, d in zip(names, dem):
+        table[n]['demangled'] = re.sub(r'\(.*', '', d).replace('void dgs::', '')
+    assert len(table) > 300, f'only {len(table)} kernels found in {LIB}'
+    return table
+
+
+def test_the_library_ships_gfx950_code_only(kernels):
+    blob = open(LIB, 'rb').read()
+    triples = set(re.findall(rb'hipv4-amdgcn-amd-amdhsa--(gfx[0-9a-z]+)', blob))
+    assert triples == {b'gfx950'}, triples
+
+
+def test_headline_kernel_registers_lds_scratch(kernels):
+    k = [v for v in kernels.values() if v['demangled'] == HEADLINE]
+    assert len(k) == 1, [v['demangled'] for v in kernels.values() if 'spmm_fused<16, 4, 0' in v['demangled']]
+    k = k[0]
+    assert k['scratch'] == 0 and k['spilled'] == 0, k
+    assert k['vgpr'] <= 96, k           # five waves per SIMD (512 / 96)
+    assert k['lds'] <= 28032, k         # five workgroups per CU (160 KB / 28 KB)
+    assert k['sgpr'] <= 96, k           # residency: <= 80 -> 8 workgroups of 256 per CU by SGPRs, 82 - 96 -> 7 (guide); five is what LDS allows
+
+
+def test_spill_budget_of_every_row_stream_instantiation(kernels):
+    over, seen = [], 0
+    for v in kernels.values():
+        d = v['demangled']
+        if not re.match(r'(spmm_fused|spmm_small|spmm_small_hub|spmm_combine|spmm_fused_strict)<', d):
+            continue
+        seen += 1
+        budget = 0
+        for pat, b in SPILL_BUDGET:
+            if re.fullmatch(pat, d):
+                budget = b
+        if v['spilled'] > budget:
+            over.append((d, v['spilled'], budget, v['scratch']))
+    assert seen > 150, seen
+    assert not over, 'instantiations over their spill budget (name, spilled VGPRs, budget, scratch bytes): ' + repr(sorted(over))
+
+
+def test_fold_hand_over_in_the_headline_kernel(kernels, tmp_path):
+    k = [(n, v) for n, v in kernels.items() if v['demangled'] == HEADLINE][0]
+    dis = subprocess.run([f'{LLVM}/llvm-objdump', '-d', '--no-show-raw-insn', f'--disassemble-symbols={k[0]}', k[1]['co']],
+                         capture_output=True, text=True, check=True).stdout
+    ins = [re.sub(r'//.*', '', ln).strip() for ln in dis.splitlines()]
+    ins = [x for x in ins if x and not x.endswith(':') and not x.startswith(('Disassembly', '/'))]
+    assert len(ins) > 1000, len(ins)
+    # no L2 write-back / invalidate: the hand-over is sc1 payload + drain + relaxed counter, not a fence pair
+    assert not [x for x in ins if x.startswith(('buffer_wbl2', 'buffer_inv'))]
+    # every arrival ticket is drawn directly behind a full drain of the wave's vector-memory queue
+    atom = [i for i, x in enumerate(ins) if x.startswith('global_atomic_add')]
+    assert atom, 'no arrival counter in the headline kernel?'
+    vmem = ('global_store', 'buffer_store', 'global_load', 'buffer_load', 'global_atomic', 'buffer_atomic')
+    for i in atom:
+        j = i - 1
+        while j >= 0 and not (ins[j].startswith('s_waitcnt') and 'vmcnt(0)' in ins[j]):
+            assert not ins[j].startswith(vmem), f'a vector-memory instruction between the drain and the counter: {ins[j - 3:i + 1]}'
+            assert i - j < 12, f'no s_waitcnt vmcnt(0) within 12 instructions in front of the counter: {ins[i - 12:i + 1]}'
+            j -= 1
+        assert j >= 0
+    # partial rows: 16-byte buffer accesses, every one of them sc1 (write-through stores, L1-bypassing loads)
+    bst = [x for x in ins if x.startswith('buffer_store_dwordx4')]
+    bld = [x for x in ins if x.startswith('buffer_load_dwordx4')]
+    assert bst and bld, (len(bst), len(bld))
+    assert all(' sc1' in x for x in bst + bld), [x for x in bst + bld if ' sc1' not in x][:3]
+    assert len(bld) >= 8, len(bld)  # the fold keeps eight partial rows in flight per lane
+
+
+def test_masked_sum_units_body_carries_no_fold_state(kernels):
+    """The masked sum never folds in the kernel (spmm_units_body: CAN_FOLD): no arrival counter, no sc1 partial-row traffic in its
+    instantiations - that state was what took their spill from 40 to 61 VGPRs in round 5."""
+    for n, v in kernels.items():
+        if re.fullmatch(r'spmm_fused<16, 4, 4, true, false, false>', v['demangled']):
+            dis = subprocess.run([f'{LLVM}/llvm-objdump', '-d', '--no-show-raw-insn', f'--disassemble-symbols={n}', v['co']],
+                                 capture_output=True, text=True, check=True).stdout
+            assert 'global_atomic_add' not in dis and 'buffer_load_dwordx4' not in dis
+            return
+    pytest.fail('masked-sum instantiation not found')
