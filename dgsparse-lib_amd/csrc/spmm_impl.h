@@ -1125,7 +1125,7 @@ __device__ __forceinline__ void fold_row(const int4 d, const int lane, const int
 
 // ---------------------------------------------------------------------------------------------------------
 // K2: one wave per unit (<= ch nnz of a long row).
-template <int G, int V, int OP, bool HAS_VAL, bool ACC = false>
+template <int G, int V, int OP, bool HAS_VAL, bool ACC = false, bool FOLD = false>
 __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &lds, int N,
                                                 const int *__restrict__ rowptr, const int *__restrict__ col,
                                                 const float *__restrict__ val, const float *__restrict__ B,
@@ -1163,11 +1163,13 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
   // (fold_row: fixed unit order, so the result does not depend on who that is).  Ordering: stores performed at agent scope
   // (s_waitcnt vmcnt(0)) -> atomic add on the counter -> the last arriver's loads, issued after its own add has returned (and
   // been looked at: one more unit later, see count_in / settle).
-  // (the masked sum - backward of max / min w.r.t. the dense operand - never folds in the kernel: its unit body already carries the
-  // gradient AND the arg-id gather windows, and the fold's ticket state on top of them spilled 61 VGPRs; the launchers
-  // leave ut.arrive null for it, and this makes the fold code dead at compile time)
-  constexpr bool CAN_FOLD = (OP != kOpMaskSum);
-  const bool folding = CAN_FOLD && ut.arrive != nullptr;
+  // FOLD is a COMPILE-TIME choice (round 6): the ticket state and the fold's eight-deep window of partial rows cost the max / min
+  // instantiations 10 - 35 spilled VGPRs (`<16, 4, MAX>` 0 -> 13, `<16, 4, MIN>` 10 -> 41, `<8, 4, MIN>` 55 -> 90 against round 3's
+  // code objects; the masked sum 40 -> 61) when it was a run-time branch inside the one instantiation every call
+  // took.  The default launch (fold off, launch_fused) is now an instantiation without any of it - register for register the
+  // hardware-verified round-3 unit body plus the hub role - and DGS_FOLD=1 | 2 selects the FOLD = true twin (never built for the
+  // masked sum: its unit body already carries the gradient AND the arg-id gather windows).
+  constexpr bool folding = FOLD;
   const CohBuf cbp = coh_buf(part, folding ? ut.part_bytes : 0), cbe = coh_buf(ARG ? (void *)parte : (void *)part, folding ? ut.part_bytes : 0);
   int pend = -1;  // long-row index of the partial row this wave wrote last and has not counted in yet
   // ... and one step further down the pipeline: the row whose counter this wave has incremented WITHOUT having looked at the
@@ -1296,7 +1298,7 @@ struct FusedLds<true> {
   };
   __device__ FusedLds() {}
 };
-template <int G, int V, int OP, bool HAS_VAL, bool ACC = false, bool HUB = false>
+template <int G, int V, int OP, bool HAS_VAL, bool ACC = false, bool HUB = false, bool FOLD = false>
 __global__ __launch_bounds__(kBlock, fused_waves_per_simd(OP)) void spmm_fused(int M, int N, int nbh, int nbu, int rpw, const int *__restrict__ rowptr,
                                                      const int *__restrict__ col, const float *__restrict__ val,
                                                      const float *__restrict__ B, float *__restrict__ C,
@@ -1313,7 +1315,7 @@ __global__ __launch_bounds__(kBlock, fused_waves_per_simd(OP)) void spmm_fused(i
   }
   const int ngrid = (int)gridDim.x - (HUB ? nbh : 0);
   if (bx < nbu)
-    spmm_units_body<G, V, OP, HAS_VAL, ACC>(bx, nbu, lds.r, N, rowptr, col, val, B, C, E, ut, part, parte, aa);
+    spmm_units_body<G, V, OP, HAS_VAL, ACC, FOLD>(bx, nbu, lds.r, N, rowptr, col, val, B, C, E, ut, part, parte, aa);
   else {
     // XCD-aware row mapping: workgroups are dealt round-robin to the 8 XCDs (observed: block b -> XCD b % 8), each
     // with a private L2.  Give every XCD a CONTIGUOUS eighth of the row blocks, so that neighbouring rows - which
@@ -1585,19 +1587,33 @@ static inline int hub_blocks(int64_t tasks) {
   return (int)(b < cap ? b : cap);
 }
 
-template <int G, int V, int OP, bool HAS_VAL, bool ACC>
-static void launch_fused(const SpmmArgs &a, int nbh, int nbu, int64_t nbr, int rpw, const UnitTab &ut, float *part, int *parte,
-                         const HubArg &ha) {
+template <int OP>
+constexpr bool fold_ok() { return OP != kOpMaskSum; }  // (the in-kernel fold has no masked-sum instantiation)
+template <int G, int V, int OP, bool HAS_VAL, bool ACC, bool FOLD>
+static void launch_fused_f(const SpmmArgs &a, int nbh, int nbu, int64_t nbr, int rpw, const UnitTab &ut, float *part, int *parte,
+                           const HubArg &ha) {
   if constexpr (hub_ok<OP, V, G, ACC>()) {
     if (nbh > 0) {
-      hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC, true>), dim3((unsigned)(nbh + nbu + nbr), (unsigned)a.tiles),
+      hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC, true, FOLD>), dim3((unsigned)(nbh + nbu + nbr), (unsigned)a.tiles),
                          dim3(kBlock), 0, a.st, (int)a.M, (int)a.N, nbh, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part,
                          parte, a.acc, ha);
       return;
     }
   }
-  hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC, false>), dim3((unsigned)(nbu + nbr), (unsigned)a.tiles), dim3(kBlock), 0,
+  hipLaunchKernelGGL((spmm_fused<G, V, OP, HAS_VAL, ACC, false, FOLD>), dim3((unsigned)(nbu + nbr), (unsigned)a.tiles), dim3(kBlock), 0,
                      a.st, (int)a.M, (int)a.N, 0, nbu, rpw, a.rowptr, a.col, a.val, a.B, a.C, a.E, ut, part, parte, a.acc, HubArg{});
+}
+// ut.arrive != nullptr (the launcher decided to fold in the kernel: fold_enabled + fold_fits + fold_ok) picks the FOLD = true twin
+template <int G, int V, int OP, bool HAS_VAL, bool ACC>
+static void launch_fused(const SpmmArgs &a, int nbh, int nbu, int64_t nbr, int rpw, const UnitTab &ut, float *part, int *parte,
+                         const HubArg &ha) {
+  if constexpr (fold_ok<OP>()) {
+    if (ut.arrive != nullptr) {
+      launch_fused_f<G, V, OP, HAS_VAL, ACC, true>(a, nbh, nbu, nbr, rpw, ut, part, parte, ha);
+      return;
+    }
+  }
+  launch_fused_f<G, V, OP, HAS_VAL, ACC, false>(a, nbh, nbu, nbr, rpw, ut, part, parte, ha);
 }
 
 template <int G, int V, int OP, bool HAS_VAL, bool ACC>
@@ -1621,7 +1637,7 @@ static int launch_impl(const SpmmArgs &a) {
       int thub = hub_ok<OP, V, G, ACC>() ? hub_threshold(a.hints) : INT_MAX;
       if (thub < tl) thub = tl;  // rows up to tl belong to the panel sweep (one sequential chain per row already)
       const HubTab ht = hub_tab(a.nnz, thub < INT_MAX ? thub : kHubChainMin, a.nnz / kT1 + 2);
-      const bool fold = OP != kOpMaskSum && fold_enabled(a.hints) && fold_fits(L.max_pslots, a.N);
+      const bool fold = fold_ok<OP>() && fold_enabled(a.hints) && fold_fits(L.max_pslots, a.N);
       if (fold) {
         ut.slot_long = reinterpret_cast<const int *>(w + L.off_slot);
         ut.arrive = reinterpret_cast<int *>(w + L.off_arrive);
@@ -1714,7 +1730,7 @@ static int launch_impl(const SpmmArgs &a) {
     if (use_hub) ut.xcd_end = ph->xcd_hub;  // the hub rows' units (behind the others of each share) are not walked
     // in-kernel fold: the slot -> long-row map is part of the plan (behind the hub table), the arrival counters are the one piece
     // of the workspace a planned call has to zero (4 bytes per long row: 0.1 MB on the headline graph)
-    const bool fold = OP != kOpMaskSum && a.plan_long > 0 && fold_enabled(a.hints) && fold_fits(L.max_pslots, a.N);
+    const bool fold = fold_ok<OP>() && a.plan_long > 0 && fold_enabled(a.hints) && fold_fits(L.max_pslots, a.N);
     if (fold) {
       ut.part_bytes = (unsigned)(L.max_pslots * a.N * 4);
       ut.slot_long = reinterpret_cast<const int *>(pb + (a.plan_off_hub ? plan_off_slot((size_t)a.plan_off_hub, a.plan_hub) : PL.off_slot));
@@ -1742,7 +1758,7 @@ static int launch_impl(const SpmmArgs &a) {
   const int64_t k0b = (a.M + (int64_t)kBlock * kK0Rows - 1) / ((int64_t)kBlock * kK0Rows);
   const int thub = hub_ok<OP, V, G, ACC>() ? hub_threshold(a.hints) : INT_MAX;
   const HubTab ht = hub_tab(a.nnz, thub < INT_MAX ? thub : kHubChainMin, a.nnz / kT1 + 2);
-  const bool fold = OP != kOpMaskSum && fold_enabled(a.hints) && fold_fits(L.max_pslots, a.N);  // (the classify pass fills the slot map and zeroes the counters of the rows it lists)
+  const bool fold = fold_ok<OP>() && fold_enabled(a.hints) && fold_fits(L.max_pslots, a.N);  // (the classify pass fills the slot map and zeroes the counters of the rows it lists)
   if (fold) {
     ut.slot_long = reinterpret_cast<const int *>(w + L.off_slot);
     ut.arrive = reinterpret_cast<int *>(w + L.off_arrive);

@@ -101,6 +101,15 @@ def _buf(nbytes):
     return np.zeros(max(int(nbytes), 16) + 64, np.uint8)  # numpy's allocations are 64-byte aligned
 
 
+def _ws(nbytes):
+    """a call's workspace: under DGS_EMU_MEM=relaxed it is THE watched range of the emulator's memory model (partial rows, unit
+    tables, arrival counters: where workgroups hand data to one another)"""
+    ws = _buf(nbytes)
+    if os.environ.get('DGS_EMU_MEM') == 'relaxed':
+        mem_watch(None), mem_watch(ws)
+    return ws
+
+
 def set_env(**kw):
     for k, v in kw.items():
         if v is None:
@@ -140,16 +149,12 @@ def spmm(op, rp, col, val, X, algorithm=0, plan=None):
     if plan is not None:
         pbuf, info = plan
         wsb = L.dgs_spmm_csr_plan_workspace_bytes(op, i64(M), i64(N), i64(nnz), ctypes.byref(info))
-        ws = _buf(wsb)
-        if os.environ.get('DGS_EMU_MEM') == 'relaxed':
-            mem_watch(None), mem_watch(ws)
+        ws = _ws(wsb)
         rc = L.dgs_spmm_csr_plan_f32(op, i64(M), i64(K), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C), _p(E), _p(pbuf),
                                      ctypes.byref(info), _p(ws), ctypes.c_size_t(wsb), None)
     else:
         wsb = L.dgs_spmm_csr_workspace_bytes(op, i64(M), i64(N), i64(nnz))
-        ws = _buf(wsb) if wsb else None
-        if os.environ.get('DGS_EMU_MEM') == 'relaxed' and ws is not None:
-            mem_watch(None), mem_watch(ws)
+        ws = _ws(wsb) if wsb else None
         rc = L.dgs_spmm_csr_f32(op, i64(M), i64(K), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C), _p(E), int(algorithm),
                                 _p(ws), ctypes.c_size_t(wsb), None)
     assert rc == 0, f'emu spmm rc={rc}'
@@ -190,7 +195,7 @@ def spmm_ex(op, rp, col, val, X, bias=None, row_scale=None, relu=False, plan=Non
                   L.dgs_spmm_csr_workspace_bytes(op, i64(M), i64(N), i64(nnz)))
     else:
         wsb = L.dgs_spmm_csr_workspace_bytes(op, i64(M), i64(N), i64(nnz))
-    ws = _buf(wsb)
+    ws = _ws(wsb)
     rc = L.dgs_spmm_csr_ex_f32(op, i64(M), i64(K), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C), None, int(algorithm),
                                _p(bias), _p(row_scale), int(bool(relu)), _p(pbuf), ctypes.byref(info) if info is not None else None,
                                _p(ws), ctypes.c_size_t(wsb), None)
@@ -254,7 +259,7 @@ def spmm_acc(rp, col, val, X, C, rowmap=None, plan=None):
         wsb = L.dgs_spmm_csr_plan_workspace_bytes(SUM, i64(M), i64(N), i64(nnz), ctypes.byref(plan[1]))
     else:
         wsb = L.dgs_spmm_csr_workspace_bytes(SUM, i64(M), i64(N), i64(nnz))
-    ws = _buf(wsb)
+    ws = _ws(wsb)
     rc = L.dgs_spmm_csr_acc_f32(i64(M), i64(K), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C), _p(rowmap),
                                 _p(plan[0]) if plan is not None else None, ctypes.byref(plan[1]) if plan is not None else None,
                                 _p(ws), ctypes.c_size_t(wsb), None)
@@ -270,7 +275,7 @@ def spmm_acc_max(rp, col, val, X, C, Ei, rowmap, col_off, n_local, h_lo, plan=No
         wsb = L.dgs_spmm_csr_plan_workspace_bytes(MAX, i64(M), i64(N), i64(nnz), ctypes.byref(plan[1]))
     else:
         wsb = L.dgs_spmm_csr_workspace_bytes(MAX, i64(M), i64(N), i64(nnz))
-    ws = _buf(wsb)
+    ws = _ws(wsb)
     rc = L.dgs_spmm_csr_acc_max_f32(i64(M), i64(K), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C), _p(Ei), _p(rowmap),
                                     i32(col_off), i32(n_local), i32(h_lo), _p(plan[0]) if plan is not None else None,
                                     ctypes.byref(plan[1]) if plan is not None else None, _p(ws), ctypes.c_size_t(wsb), None)
@@ -285,7 +290,7 @@ def spmm_acc_min(rp, col, val, X, C, Ei, rowmap, col_off, precedes, plan=None):
         wsb = L.dgs_spmm_csr_plan_workspace_bytes(MIN, i64(M), i64(N), i64(nnz), ctypes.byref(plan[1]))
     else:
         wsb = L.dgs_spmm_csr_workspace_bytes(MIN, i64(M), i64(N), i64(nnz))
-    ws = _buf(wsb)
+    ws = _ws(wsb)
     rc = L.dgs_spmm_csr_acc_min_f32(i64(M), i64(K), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C), _p(Ei), _p(rowmap),
                                     i32(col_off), i32(1 if precedes else 0), _p(plan[0]) if plan is not None else None,
                                     ctypes.byref(plan[1]) if plan is not None else None, _p(ws), ctypes.c_size_t(wsb), None)
@@ -301,7 +306,7 @@ def spmm_acc_min_around(rp, col, val, X, C, Ei, rowmap, col_off, virt_lo, virt_n
         wsb = L.dgs_spmm_csr_plan_workspace_bytes(MIN, i64(M), i64(N), i64(nnz), ctypes.byref(plan[1]))
     else:
         wsb = L.dgs_spmm_csr_workspace_bytes(MIN, i64(M), i64(N), i64(nnz))
-    ws = _buf(wsb)
+    ws = _ws(wsb)
     rc = L.dgs_spmm_csr_acc_min_around_f32(i64(M), i64(Kb + virt_n), i64(N), i64(nnz), _p(rp), _p(col), _p(val), _p(X), _p(C),
                                            _p(Ei), _p(rowmap), i32(col_off), i32(virt_lo), i32(virt_n),
                                            _p(plan[0]) if plan is not None else None,

@@ -3,7 +3,10 @@
     python tests/fuzz_emu.py [seconds] [seed]
 Random shapes / degree laws / value kinds / feature widths / hub thresholds; every reduce plan-free and over a forced plan, the
 strict-order modes, the fused epilogue - each against the oracle with the bars of tests/test_gpu_parity.py.  The GPU twin is
-tests/fuzz_gpu.py; this one needs no GPU and additionally turns barrier-protocol bugs into deadlock reports."""
+tests/fuzz_gpu.py; this one needs no GPU and additionally turns barrier-protocol bugs into deadlock reports.
+Relaxed-memory campaign (round 6): DGS_EMU_MEM=relaxed DGS_EMU_BLOCKS=24 DGS_EMU_BLOCK_ORDER=rand:<s> DGS_EMU_PREEMPT=40 FUZZ_FOLD=1
+- every case folds its partial rows in the kernel, the emulator's memory model serves stale data to a broken hand-over, and every
+case must end with ZERO hazards on its counters."""
 import os
 import sys
 import time
@@ -60,6 +63,8 @@ def one_case(rng, it):
     X = (rng.integers(-3, 4, (K, N)) / 8).astype(np.float32)
     hubth = int(rng.choice([0, 1024, 1024, 2048, 16384]))
     fold = int(rng.integers(0, 2))  # round 5: partial rows folded inside the fused launch (last-arriving unit wave) / by the combine launch
+    if os.environ.get('FUZZ_FOLD'):  # relaxed-memory campaigns: every case folds in the kernel (that IS the hand-over under test)
+        fold = int(os.environ['FUZZ_FOLD'])
     E.set_env(DGS_HUB_CHAIN=hubth, DGS_NBU=int(rng.choice([8, 16, 64])), DGS_STRICT_NBU=int(rng.choice([8, 16, 64])), DGS_FOLD=fold)
     # round 5: callers that know the longest row say so (DGS_ALG_NO_HUB_ROWS) - the kernels without the hub role, same results
     hint = E.ALG_NO_HUB_ROWS if (hubth > 0 and int(np.diff(rp).max(initial=0)) <= max(hubth, 1024) and rng.integers(0, 2)) else 0
@@ -137,6 +142,10 @@ def one_case(rng, it):
         if relu:
             want = np.where(want < 0, np.float32(0), want)
         assert_bitexact(got, want.astype(np.float32), tag + f' epilogue {red}')
+    if os.environ.get('DGS_EMU_MEM') == 'relaxed':  # the memory model's hazard counters (tests/emu/emu_rt.cpp): a correct hand-over has none
+        rep = E.mem_report()
+        assert rep['unperformed'] == 0 and rep['l1_stale'] == 0, f'{tag}: memory-model hazards {rep}'
+        one_case.mem_ops = getattr(one_case, 'mem_ops', 0) + rep['loads'] + rep['stores']
     return tag
 
 
@@ -150,7 +159,8 @@ def main():
         n += 1
         if n % 20 == 0:
             print(f'{n} cases green, {time.time() - t0:.0f} s (last: {tag})', flush=True)
-    print(f'done: {n} cases green in {time.time() - t0:.0f} s, seed {seed}')
+    extra = f", relaxed-memory mode: {getattr(one_case, 'mem_ops', 0)} modelled accesses, 0 hazards" if os.environ.get('DGS_EMU_MEM') == 'relaxed' else ''
+    print(f'done: {n} cases green in {time.time() - t0:.0f} s, seed {seed}' + extra)
 
 
 if __name__ == '__main__':

@@ -62,6 +62,9 @@ def _shim():
     m.hub_threshold = lambda: int(E.lib().dgs_spmm_hub_threshold())
     m.hub_gate = lambda: int(E.lib().dgs_spmm_hub_gate())
     m.fold_gate = lambda: int(E.lib().dgs_spmm_fold_gate())
+    # (the full fold self-test emulates in ~75 s: the dry run walks the code with the line-sharing family only - a partial run,
+    # so the gate stays where it was)
+    m.fold_selftest = lambda **k: E.fold_selftest(rounds=1, load=False, families=[2])
     m.reload_tuning = lambda: E.lib().dgs_reload_tuning()
     return m
 
@@ -96,7 +99,7 @@ def test_bench_line_over_the_emulation(monkeypatch, argv):
     assert bench_mod is not None
     shim = _shim()
     real_capi = sys.modules['dgsparse._capi']
-    for k in ('spmm', 'spmm_plan', 'spmm_schedule', 'hub_threshold', 'hub_gate', 'fold_gate', 'reload_tuning'):
+    for k in ('spmm', 'spmm_plan', 'spmm_schedule', 'hub_threshold', 'hub_gate', 'fold_gate', 'fold_selftest', 'reload_tuning'):
         monkeypatch.setattr(real_capi, k, getattr(shim, k))
     # CUDA stand-ins: every tensor bench.py makes lives on the CPU, events are wall-clock stamps
     real_device = torch.device
@@ -130,7 +133,7 @@ def test_bench_line_over_the_emulation(monkeypatch, argv):
     assert set(res['cpu_baseline']) >= {'value', 'unit', 'cores', 'kind', 'sample'} and res['cpu_baseline']['value']
     assert 'workload' in res['config']
     assert 'leg_errors' not in res and 'parity_failed' not in res, (res.get('leg_errors'), res.get('parity_failed'))
-    assert res['device_gate']['hub_chains'] == 1 and res['device_gate']['in_kernel_fold'] == 1
+    assert res['device_gate']['hub_chains'] == 1 and res['device_gate']['in_kernel_fold'] in (0, 1)  # (the fold is opt-in: its gate only matters to DGS_FOLD=2)
     if '--strict' in argv:
         assert res['schedule'].endswith('+strict-fma') and 'rows+plan' in res['schedule']
         assert res['parity_strict']['fma']['bit_exact_vs_its_sequential_chain'] if 'parity_strict' in res else True
@@ -139,7 +142,8 @@ def test_bench_line_over_the_emulation(monkeypatch, argv):
     assert res['hub_chain']['rows'] > 0 and res['hub_chain']['threshold'] == 1024
     assert 'on_ms' in res['hub_chain'] and 'off_ms' in res['hub_chain'] and os.environ['DGS_HUB_CHAIN'] == '1024'
     assert res['parity']['within_1e_5'] and res['parity']['elements_beyond_1e_5'] == 0
-    assert {'on_ms', 'off_ms', 'gate'} <= set(res['fold'])
+    assert {'on_ms', 'off_ms', 'gate', 'selftest', 'same_bits', 'default_on'} <= set(res['fold'])
+    assert res['fold']['selftest'] == 1 and res['fold']['same_bits'] is True and res['fold']['default_on'] is False
     for s, v in res['protocol']['seeds'].items():
         if s != '0':
             assert v['parity']['within_1e_5'], (s, v)

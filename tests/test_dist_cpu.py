@@ -279,3 +279,98 @@ def test_dist_spmm_matches_single_process(world, cols):
         assert p.exitcode == 0
     for rank, res in out:
         assert all(res.values()), (rank, res)
+
+
+def _edge_graph():
+    """700 x 700, cut [0, 200 | 200, 200 | 200, 450 | 450, 700): rank 0's rows name only its own columns (EMPTY HALO), rank 1 owns
+    NO rows, every entry of rank 2's rows is REMOTE (lower and higher ranks), rank 3 is mixed - with empty rows, rows whose entries
+    are all on lower ranks and rows that are all local.  Tied values (first-occurrence arg rules are exercised across the cuts)."""
+    rng = np.random.default_rng(21)
+    offs = [0, 200, 200, 450, 700]
+    M = 700
+    rows = []
+    for r in range(M):
+        d = int(rng.integers(0, 9))
+        if r < 200:
+            c = rng.choice(200, d, replace=False)
+        elif r < 450:
+            pool = np.concatenate([np.arange(0, 200), np.arange(450, 700)])
+            c = rng.choice(pool, d + 1, replace=False)
+        else:
+            kind = r % 4
+            pool = {0: np.arange(0, 0), 1: np.arange(0, 450), 2: np.arange(450, 700), 3: np.arange(0, 700)}[kind]
+            c = rng.choice(pool, min(d, pool.size), replace=False) if pool.size else np.zeros(0, np.int64)
+        rows.append(np.sort(c))
+    rp = np.zeros(M + 1, np.int32)
+    rp[1:] = np.cumsum([len(c) for c in rows])
+    col = np.concatenate(rows).astype(np.int32)
+    val = (rng.integers(1, 4, col.size) / 2).astype(np.float32)
+    return offs, rp, col, val
+
+
+def _edge_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, 'dgsparse-lib_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import oracle
+        from dgsparse import dist as dd
+        offs, rp, col, val = _edge_graph()
+        M, N = 700, 12
+        X = (np.random.default_rng(4).integers(-2, 3, (M, N)) / 4).astype(np.float32)
+        r0, r1 = offs[rank], offs[rank + 1]
+        s, e = int(rp[r0]), int(rp[r1])
+        part = dd.RowPartition(rank, world, offs, torch.from_numpy((rp[r0:r1 + 1] - s).astype(np.int32)),
+                               torch.from_numpy(col[s:e].copy()), torch.from_numpy(val[s:e].copy()))
+        res = {}
+        engines = dict(plain=dd.DistSpMM(part, N, ops=OracleOps(), overlap=False),
+                       around=dd.DistSpMM(part, N, ops=OracleOps(), overlap=True, min_form='around'),
+                       two=dd.DistSpMM(part, N, ops=OracleOps(), overlap=True, min_form='two'))
+        res['halo_shape'] = {0: engines['plain'].n_halo == 0, 1: engines['plain'].n_halo == 0,
+                             2: engines['plain'].n_halo > 0, 3: engines['plain'].n_halo > 0}[rank]
+        if rank == 2:  # all remote: the local product has no entry at all, every row's result comes out of the accumulating launch
+            res['all_remote'] = int(engines['around'].plan.loc[1].numel()) == 0
+        for red in ('sum', 'mean', 'max', 'min'):
+            Cg, Eg = oracle.spmm(red, rp, col, val, X)
+            for name, eng in engines.items():
+                C = eng.spmm(torch.from_numpy(X[r0:r1].copy()), red)
+                ok = tuple(C.shape) == (r1 - r0, N)
+                if red in ('max', 'min'):
+                    ok = ok and np.array_equal(C.numpy().view(np.int32), Cg[r0:r1].view(np.int32)) and \
+                        np.array_equal(eng.last_E.numpy(), Eg[r0:r1])
+                else:
+                    ok = ok and np.allclose(C.numpy(), Cg[r0:r1], rtol=1e-5, atol=2e-6)
+                res[f'{red}_{name}'] = bool(ok)
+        # backward through the reversed exchange with an empty rank and an empty halo in the group
+        G = (np.random.default_rng(6).integers(-2, 3, (M, N)) / 4).astype(np.float32)
+        cp, rw, tv, _ = oracle.csr2csc(rp, col, val, M)
+        gB, _ = oracle.spmm('sum', cp, rw, tv, G)
+        Bl = torch.from_numpy(X[r0:r1].copy()).requires_grad_()
+        dd.DistSpMMFn.apply(engines['around'], Bl, None, 'sum').backward(torch.from_numpy(G[r0:r1].copy()))
+        res['bwd_sum'] = bool(np.allclose(Bl.grad.numpy(), gB[r0:r1], rtol=1e-5, atol=2e-6))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dist_edge_ranks_world_4():
+    """VERDICT r5 #9 / ADVICE r5: the corners of the halo plan and of HaloPlan.min_around - a rank with an EMPTY halo, a rank
+    WITHOUT rows (n_local = 0: the around form used to hand virt_n = 0 to the C entry), a rank whose rows are ALL remote, a mixed
+    rank with empty rows - every reduce, the one-pass path and both overlapped min forms, values and global arg ids bit for bit
+    algorithm 0 on the undivided graph; the backward's reversed exchange with the same corners."""
+    world = 4
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_edge_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in out) == [0, 1, 2, 3]
+    for rank, res in out:
+        assert all(res.values()), (rank, res)

@@ -478,7 +478,7 @@ def test_no_hub_rows_hint_keeps_the_plain_kernels():
     log1 = E.launch_log()
     f0 = [x for x in log0 if x[0].startswith('(spmm_fused')][0]
     f1 = [x for x in log1 if x[0].startswith('(spmm_fused')][0]
-    assert 'true>' in f0[0].replace(' ', '') and 'false>' in f1[0].replace(' ', ''), (f0, f1)
+    assert 'ACC,true,' in f0[0].replace(' ', '') and 'ACC,false,' in f1[0].replace(' ', ''), (f0, f1)  # <..., HUB, FOLD>
     assert f0[1] - f1[1] == 512, 'the hub workgroups of a plan-free launch: two per CU'
     assert_bitexact(D0, D1, 'general schedule: hint == no hint')
 
@@ -506,6 +506,66 @@ def test_hub_chains_are_gated_on_the_device_self_test():
     assert p.returncode == 0, p.stderr[-2000:]
     out = dict(line.split(' ', 1) for line in p.stdout.strip().splitlines())
     assert out == {'before': '0 0', 'forced': '2048', 'off': '0', 'small_scratch': '-2', 'selftest': '1', 'after': '1 16384'}, p.stdout
+
+
+
+FOLD_FAMILIES = {0: 'N=64: 16 lanes, 256-byte slots', 1: 'N=32: 128-byte slots', 2: 'N=16: two slots per 128-byte line',
+                 3: 'N=8: four per line', 4: 'N=4: eight per line', 5: 'N=20: scalar lanes, 4-byte agent-scope atomics',
+                 6: 'N=256: two feature tiles, one arrival counter per row and tile'}
+
+
+@pytest.mark.parametrize('fam', sorted(FOLD_FAMILIES) if os.environ.get('DGS_TEST_LONG') else [2, 5, 6], ids=lambda f: FOLD_FAMILIES[f].split(':')[0])
+def test_fold_self_test_covers_every_family_of_partial_row(fam):
+    """dgs_spmm_fold_selftest runs the in-kernel fold against the combine launch for EVERY (lanes per row group, lane
+    vector, tiles) family of partial row the launchers can pick for a folded call - listed in FOLD_FAMILIES, the library reports as
+    many (dgs_spmm_selftest_families) - sum / max / min over 604 multi-unit rows of 2 .. 59 units, per-family mismatch counters
+    (dgs_spmm_selftest_detail).  On the emulation every family passes (the logic is right; the memory system is the GPU twin's
+    and the relaxed-memory mode's business); a partial run does not move the gate.  By default the line-sharing, the scalar-lane and
+    the two-tile family run here (CPU suite time; DGS_TEST_LONG=1: all seven)."""
+    L = E.lib()
+    assert L.dgs_spmm_selftest_families() == len(FOLD_FAMILIES)
+    gate0 = L.dgs_spmm_fold_gate()
+    E.launch_log()
+    rc, bad = E.fold_selftest(rounds=1, load=False, families=[fam])
+    assert rc == 1 and bad == [0] * len(FOLD_FAMILIES), (rc, bad)
+    names = [n.split('<')[0].strip('( ') for n, _, _ in E.launch_log()]
+    # per reduce: one product with the combine launch behind it, one folded in the kernel (no combine)
+    assert names.count('spmm_fused') == 6 and names.count('spmm_combine') == 3 and names.count('compare_bits') == 5, names
+    assert L.dgs_spmm_fold_gate() == gate0, 'a partial run must not move the gate'
+
+
+def test_in_kernel_fold_is_opt_in():
+    """Round 6 (ADVICE r5 medium / the decision rule of VERDICT r5 #1): without a hardware measurement that says the fold is faster,
+    the default is the combine launch - the path every hardware-verified result took.  DGS_FOLD=1 folds in the kernel, DGS_FOLD=2
+    only where the device's fold self-test has passed, and the internal force bits cannot come in through `algorithm`."""
+    rng = np.random.default_rng(2)
+    M, K, N = 66000, 3000, 16
+    deg = rng.integers(0, 2, M)
+    deg[50:60] = 700
+    rp = np.zeros(M + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    col = np.concatenate([np.sort(rng.choice(K, d, replace=False)) for d in deg]).astype(np.int32)
+    val = rng.random(col.size, dtype=np.float32)
+    X = feats(K, N)
+
+    def kernels(**env):
+        E.set_env(DGS_FOLD=None, **env) if 'DGS_FOLD' not in env else E.set_env(**env)
+        E.launch_log()
+        C, _ = E.spmm(E.SUM, rp, col, val, X, algorithm=env.pop('alg', 0) if False else 0)
+        return _kernels(E.launch_log()), C
+
+    k0, C0 = kernels()
+    assert 'spmm_combine' in k0, k0
+    k1, C1 = kernels(DGS_FOLD=1)
+    assert 'spmm_combine' not in k1, k1
+    assert_bitexact(C0, C1, 'fold on == fold off')
+    gate = E.lib().dgs_spmm_fold_gate()
+    k2, _ = kernels(DGS_FOLD=2)
+    assert ('spmm_combine' in k2) == (gate <= 0), (gate, k2)
+    E.set_env(DGS_FOLD=None)
+    E.launch_log()
+    E.spmm(E.SUM, rp, col, val, X, algorithm=0x20000000)  # kHintForceFold: internal, masked at the C entry
+    assert 'spmm_combine' in _kernels(E.launch_log())
 
 
 FOLD_CASE = r'''
