@@ -459,8 +459,9 @@ def main():
     }
     res.update(extra)
     res['device_gate'] = dict(hub_chains=_capi.hub_gate(), in_kernel_fold=_capi.fold_gate(), hub_threshold=_capi.hub_threshold(),
-                              note='1 = dgs_spmm_hub_selftest passed on this device (the feature is on by default), -1 = failed (off), '
-                                   '0 = not run; DGS_HUB_CHAIN / DGS_FOLD override')
+                              note='hub_chains: 1 = dgs_spmm_hub_selftest passed on this device (chains on by default), -1 = failed (off), '
+                                   '0 = not run; DGS_HUB_CHAIN overrides.  in_kernel_fold: verdict of dgs_spmm_fold_selftest (run by the '
+                                   '`fold` leg below, after this snapshot unless DGS_FOLD=2); the fold itself is OFF unless DGS_FOLD=1 | 2')
     # roofline.traffic is NOT measured by this process (PMC passes cannot run beside the timed region): it is the
     # figure of the committed rocprofv3 counter passes for this very configuration, with its provenance next to it
     tf = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')

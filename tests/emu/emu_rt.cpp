@@ -100,7 +100,8 @@ struct Wave {
 struct Block {
   std::vector<Fiber> fibers;
   std::vector<Wave> waves;
-  std::vector<char> lds;  // the section's contents while another workgroup owns it
+  std::vector<char> lds;  // the section's contents while another workgroup owns it (full copy: sanitizer builds)
+  std::vector<std::pair<unsigned, std::vector<char>>> lds_pages;  // ... or just the pages the launch has written (dirty tracking)
   dim3 bid;
   size_t dispatch = 0;    // position in the launch's dispatch order: CU = dispatch % CUs, XCD = dispatch % 8 (memory model)
   int live = 0, arrived = 0, remaining = 0;
@@ -638,6 +639,100 @@ extern "C" size_t emu_launch_log(char *buf, size_t cap, int clear) {
   return n;
 }
 namespace emu {
+// Dirty-page tracking of the LDS section while several workgroups are resident.  Every __shared__ object of every template
+// instantiation is a distinct static, ~21 MB in all, of which one launch touches a few pages; copying the whole section at every
+// workgroup switch made pre-emptive schedules (DGS_EMU_PREEMPT) 20x slower than the kernels themselves.  The section is
+// write-protected at the start of a multi-resident launch; the first write to a page faults once, the handler notes the page and
+// unprotects it; a workgroup switch saves / restores only the noted pages.  (Not under ASAN / UBSAN builds: the sanitizers own SIGSEGV.)
+}  // namespace emu
+#include <signal.h>
+#include <unistd.h>
+namespace emu {
+namespace {
+constexpr size_t kPage = 4096;
+bool lds_track = false;
+unsigned lds_dirty[8192];
+volatile unsigned lds_ndirty = 0;
+struct sigaction lds_old_sa;
+char *lds_lo() { return reinterpret_cast<char *>(reinterpret_cast<uintptr_t>(__start_emu_lds) & ~(uintptr_t)(kPage - 1)); }
+char *lds_hi() { return reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(__stop_emu_lds) + kPage - 1) & ~(uintptr_t)(kPage - 1)); }
+void lds_segv(int sig, siginfo_t *si, void *uc) {
+  char *a = static_cast<char *>(si->si_addr);
+  if (lds_track && a >= __start_emu_lds && a < __stop_emu_lds && lds_ndirty < 8192) {
+    const unsigned pg = (unsigned)((a - lds_lo()) / kPage);
+    lds_dirty[lds_ndirty] = pg;
+    lds_ndirty = lds_ndirty + 1;
+    // a page that straddles the section's ends holds other data too: it simply becomes writable like before
+    mprotect(lds_lo() + (size_t)pg * kPage, kPage, PROT_READ | PROT_WRITE);
+    return;
+  }
+  sigaction(SIGSEGV, &lds_old_sa, nullptr);  // not ours: let the default / previous handler have it on the retry
+  (void)sig;
+  (void)uc;
+}
+bool lds_track_begin() {
+#if EMU_ASAN
+  return false;
+#else
+  if (getenv("DGS_EMU_UBSAN") || getenv("DGS_EMU_NO_LDS_TRACK")) return false;
+  // only whole pages strictly inside the section are protected (its first / last partial pages are shared with other data and
+  // are treated as always dirty)
+  char *lo = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(__start_emu_lds) + kPage - 1) & ~(uintptr_t)(kPage - 1));
+  char *hi = reinterpret_cast<char *>(reinterpret_cast<uintptr_t>(__stop_emu_lds) & ~(uintptr_t)(kPage - 1));
+  if (hi <= lo) return false;
+  struct sigaction sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sa_sigaction = lds_segv;
+  sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+  sigemptyset(&sa.sa_mask);
+  if (sigaction(SIGSEGV, &sa, &lds_old_sa) != 0) return false;
+  lds_ndirty = 0;
+  // the partial first / last pages: always saved
+  if (lo > __start_emu_lds) lds_dirty[lds_ndirty++] = 0;
+  if (hi < __stop_emu_lds) lds_dirty[lds_ndirty++] = (unsigned)((hi - lds_lo()) / kPage);
+  lds_track = true;
+  if (mprotect(lo, (size_t)(hi - lo), PROT_READ) != 0) {
+    lds_track = false;
+    sigaction(SIGSEGV, &lds_old_sa, nullptr);
+    return false;
+  }
+  return true;
+#endif
+}
+void lds_track_end() {
+  if (!lds_track) return;
+  lds_track = false;
+  mprotect(lds_lo(), (size_t)(lds_hi() - lds_lo()), PROT_READ | PROT_WRITE);
+  sigaction(SIGSEGV, &lds_old_sa, nullptr);
+}
+// the bytes of page pg that belong to the section
+void lds_page_span(unsigned pg, char *&p, size_t &n) {
+  char *a = lds_lo() + (size_t)pg * kPage, *b = a + kPage;
+  if (a < __start_emu_lds) a = __start_emu_lds;
+  if (b > __stop_emu_lds) b = __stop_emu_lds;
+  p = a;
+  n = (size_t)(b - a);
+}
+void lds_save(Block *b) {
+  b->lds_pages.clear();
+  const unsigned n = lds_ndirty;
+  for (unsigned i = 0; i < n; i++) {
+    char *p;
+    size_t len;
+    lds_page_span(lds_dirty[i], p, len);
+    b->lds_pages.emplace_back(lds_dirty[i], std::vector<char>(p, p + len));
+  }
+}
+void lds_restore(const Block *b) {
+  for (const auto &pg : b->lds_pages) {
+    char *p;
+    size_t len;
+    lds_page_span(pg.first, p, len);
+    memcpy(p, pg.second.data(), len);  // (a page that was dirty when b was saved is writable by now)
+  }
+}
+}  // namespace
+
 void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx) {
   const unsigned nthr = block.x * block.y * block.z;
   if (block.y != 1 || block.z != 1 || nthr == 0 || nthr > 1024) {
@@ -674,6 +769,7 @@ void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx) {
     std::vector<Block *> res;
     size_t next = 0, turn = 0;
     Block *owner = nullptr;  // whose LDS is in the section
+    const bool tracking = lds_track_begin();
     int idle_rounds = 0;
     while (next < nblocks || !res.empty()) {
       while (next < nblocks && (int)res.size() < max_resident) {
@@ -686,11 +782,16 @@ void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx) {
       if (turn >= res.size()) turn = 0;
       Block *b = res[turn];
       if (owner != b) {
-        if (owner) {
-          owner->lds.resize(lds_bytes);
-          memcpy(owner->lds.data(), __start_emu_lds, lds_bytes);
+        if (tracking) {
+          if (owner) lds_save(owner);
+          if (!b->fresh) lds_restore(b);
+        } else {
+          if (owner) {
+            owner->lds.resize(lds_bytes);
+            memcpy(owner->lds.data(), __start_emu_lds, lds_bytes);
+          }
+          if (!b->fresh) memcpy(__start_emu_lds, b->lds.data(), lds_bytes);
         }
-        if (!b->fresh) memcpy(__start_emu_lds, b->lds.data(), lds_bytes);
         owner = b;
       }
       b->fresh = false;
@@ -713,6 +814,7 @@ void launch_impl(dim3 grid, dim3 block, void (*fn)(void *), void *ctx) {
         deadlock("every resident workgroup spins and there is no room to dispatch the one they wait for (DGS_EMU_BLOCKS)");
       turn++;
     }
+    if (tracking) lds_track_end();
   }
   mem_kernel_end();
   k_fn = saved_fn;

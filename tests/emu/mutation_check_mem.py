@@ -26,8 +26,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'dgsparse-lib_amd', 'csrc')
-SCHEDULES = [dict(DGS_EMU_BLOCKS='24', DGS_EMU_BLOCK_ORDER='rand:1', DGS_EMU_PREEMPT='40'),
-             dict(DGS_EMU_BLOCKS='40', DGS_EMU_BLOCK_ORDER='rand:2', DGS_EMU_PREEMPT='16'),
+SCHEDULES = [dict(DGS_EMU_BLOCKS='24', DGS_EMU_BLOCK_ORDER='rand:1', DGS_EMU_PREEMPT='8'),
+             dict(DGS_EMU_BLOCKS='40', DGS_EMU_BLOCK_ORDER='rand:2', DGS_EMU_PREEMPT='3'),
              dict(DGS_EMU_BLOCKS='8', DGS_EMU_BLOCK_ORDER='rev', DGS_EMU_PREEMPT='24', DGS_EMU_ORDER='rev')]
 
 
