@@ -70,6 +70,10 @@ def parse():
     ap.add_argument('--force-dist', action='store_true', help='run the partitioned code path even with one rank (testing)')
     ap.add_argument('--sweep', action='store_true', help='also time feat=32/128 and max (extra keys)')
     ap.add_argument('--no-dense', action='store_true', help='skip the Reddit-shaped side measurement (extra key)')
+    ap.add_argument('--fold-inprocess', action='store_true', help='run the in-kernel-fold leg inside this process (default: a child '
+                    'process - the leg forces an opt-in schedule that has never met the hardware, and a GPU fault there must not '
+                    'cost the line)')
+    ap.add_argument('--only-fold-leg', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -320,6 +324,45 @@ def main():
         nnz_total = st['nnz']
         step, planned = make_step(rp, col, val, X)
 
+        def fold_leg():
+            """The in-kernel fold of partial rows (opt-in: DGS_FOLD=1 | 2) next to the combine launch it replaces, on the same
+            tensors: first the device's own verdict on the hand-over (dgs_spmm_fold_selftest: every family of partial row, 3
+            rounds, the last under a streaming load), then DGS_FOLD = 1 / 0 for one measurement each and a bit compare of the
+            two results, then back to the process's own setting.  Decision rule: the fold becomes a default
+            only with on_ms < off_ms on hardware."""
+            had = os.environ.get('DGS_FOLD')
+            try:
+                verdict, fam = _capi.fold_selftest(rounds=3, load=True)
+            except Exception as e:
+                verdict, fam = -2, str(e)
+            fd = dict(selftest=verdict, selftest_mismatches_per_family=fam, gate=_capi.fold_gate(),
+                      default_on=bool(had == '1' or (had == '2' and _capi.fold_gate() > 0)))
+            outs = {}
+            for name, v in (('on_ms', '1'), ('off_ms', '0')):
+                if v == '1' and verdict != 1:
+                    fd[name] = None  # a hand-over the device got wrong is not timed
+                    continue
+                os.environ['DGS_FOLD'] = v
+                _capi.reload_tuning()
+                stepf, _ = make_step(rp, col, val, X)
+                outs[v] = stepf()[0].clone()
+                fd[name] = round(sorted(event_ms(stepf, max(10, a.steps // 5)) for _ in range(3))[1], 5)
+                del stepf
+            if len(outs) == 2:
+                fd['same_bits'] = bool(torch.equal(outs['1'].view(torch.int32), outs['0'].view(torch.int32)))
+            del outs
+            if had is None:
+                os.environ.pop('DGS_FOLD')
+            else:
+                os.environ['DGS_FOLD'] = had
+            _capi.reload_tuning()
+            fd['note'] = 'fold on: one kernel launch per planned call (+ a memset of 4 B per long row); off (the default): fused + combine'
+            return fd
+
+        if a.only_fold_leg:  # (the child process of the `fold` leg below: same graph, same plan, nothing else)
+            print(json.dumps(fold_leg() if planned else dict(skipped='no plan for this shape')))
+            return
+
         # parity spot-check on the exact tensors being timed: sampled rows (always including the longest) against an
         # fp64 torch gather-sum; every row is checked against the sequential reference in the cpu_baseline leg below,
         # and the full parity suite is tests/ -m gpu
@@ -515,39 +558,23 @@ def main():
             prot['seeds'] = seeds
             res['protocol'] = prot
             if planned:
-                # the in-kernel fold of partial rows (opt-in: DGS_FOLD=1 | 2) next to the combine launch it replaces, on the same
-                # tensors: first the device's own verdict on the hand-over (dgs_spmm_fold_selftest: every family of partial row,
-                # 3 rounds, the last under a streaming load), then DGS_FOLD = 1 / 0 for one measurement each and a bit compare
-                # of the two results, then back to the process's own setting.  Decision rule: the fold becomes a
-                # default only with on_ms < off_ms on hardware
-                had = os.environ.get('DGS_FOLD')
-                try:
-                    verdict, fam = _capi.fold_selftest(rounds=3, load=True)
-                except Exception as e:
-                    verdict, fam = -2, str(e)
-                fd = dict(selftest=verdict, selftest_mismatches_per_family=fam, gate=_capi.fold_gate(),
-                          default_on=bool(had == '1' or (had == '2' and _capi.fold_gate() > 0)))
-                outs = {}
-                for name, v in (('on_ms', '1'), ('off_ms', '0')):
-                    if v == '1' and verdict != 1:
-                        fd[name] = None  # a hand-over the device got wrong is not timed
-                        continue
-                    os.environ['DGS_FOLD'] = v
-                    _capi.reload_tuning()
-                    stepf, _ = make_step(rp, col, val, X)
-                    outs[v] = stepf()[0].clone()
-                    fd[name] = round(sorted(event_ms(stepf, max(10, a.steps // 5)) for _ in range(3))[1], 5)
-                    del stepf
-                if len(outs) == 2:
-                    fd['same_bits'] = bool(torch.equal(outs['1'].view(torch.int32), outs['0'].view(torch.int32)))
-                del outs
-                if had is None:
-                    os.environ.pop('DGS_FOLD')
+                # the in-kernel fold leg (fold_leg above).  In a CHILD process by default: it forces an opt-in schedule that has
+                # never met the hardware, and whatever happens to it - a wrong bit, a hang cut by the timeout, a GPU fault that
+                # kills the process - the line of the default schedule survives
+                if a.fold_inprocess:
+                    res['fold'] = fold_leg()
                 else:
-                    os.environ['DGS_FOLD'] = had
-                _capi.reload_tuning()
-                fd['note'] = 'fold on: one kernel launch per planned call (+ a memset of 4 B per long row); off (the default): fused + combine'
-                res['fold'] = fd
+                    import subprocess
+                    argv = [x for x in sys.argv[1:] if x not in ('--sweep',)] + ['--only-fold-leg', '--no-cpu-baseline', '--no-dense', '--no-protocol']
+                    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+                    try:
+                        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, timeout=600, env=env)
+                        lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+                        res['fold'] = json.loads(lines[-1]) if lines else dict(error='the fold leg printed no line', rc=p.returncode,
+                                                                                stderr_tail=p.stderr[-400:])
+                    except subprocess.TimeoutExpired:
+                        res['fold'] = dict(error='the fold leg did not finish within 600 s (killed)')
+                    res['fold']['process'] = 'child'
             if '+hub' in res.get('schedule', ''):
                 # what the hub chains cost next to the tree on the same tensors (the decision rule needs both numbers
                 # in every line): DGS_HUB_CHAIN=0 for one measurement, then back to what this process was started with

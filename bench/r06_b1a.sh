@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6, GPU batch 1a: first hardware contact of everything written since round 3, in the order VERDICT r5 #1 asks for:
-# device self-tests (hub: 8 shapes; fold: 7 families x 3 rounds, loaded) -> hub smoke (stop on hang) -> the default bench line and the
+# device self-tests (hub: 14 shapes; fold: 9 families x 3 rounds, loaded) -> hub smoke (stop on hang) -> the default bench line and the
 # kernel stats of the same command -> all -m gpu tests (--durations) -> sweep line, steps-20 line, hub off, fold on.
 set -x
 cd "$(dirname "$0")/.."
@@ -12,7 +12,7 @@ import torch, time
 from dgsparse import _capi
 t = time.time()
 _capi.ensure_hub_selftest(torch.device('cuda', 0))
-print('hub gate', _capi.hub_gate(), 'threshold', _capi.hub_threshold(), 'per shape', _capi.selftest_detail()[16:24], round(time.time() - t, 2), 's')
+print('hub gate', _capi.hub_gate(), 'threshold', _capi.hub_threshold(), 'per shape', _capi.selftest_detail()[16:30], round(time.time() - t, 2), 's')
 for rounds, load in ((1, False), (3, True), (10, True)):
     t = time.time()
     print('fold selftest rounds', rounds, 'load', load, _capi.fold_selftest(rounds=rounds, load=load), 'gate', _capi.fold_gate(), round(time.time() - t, 2), 's')

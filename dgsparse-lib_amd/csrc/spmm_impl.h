@@ -120,6 +120,7 @@ struct UnitTab {
   const int *slot_long = nullptr;
   int *arrive = nullptr;
   unsigned part_bytes = 0;  // bytes of the partial-row region (what the fold's buffer descriptors cover; < 2^31, fold_fits)
+  int pstride = 0;          // FOLD twin: floats between two partial rows (fold_stride: whole 128-byte lines); else the rows are N apart
 };
 
 struct WsLayout {
@@ -135,6 +136,16 @@ static inline int unit_len(int64_t nnz) {
   return ch;
 }
 
+// Row stride of the partial rows when they are folded INSIDE the fused launch: whole 128-byte lines per slot, on a 128-byte aligned
+// base, so that no two partial rows ever share a cache line.  The hand-over is write-through sc1 stores -> drain -> counter -> sc1
+// loads (MI355X guide, R1 form); what that form does not spell out is what an sc1 load returns for a line its own XCD still holds
+// from an EARLIER read - which is exactly what slots narrower than a line would make it do (the folder of row A reads the line that
+// also holds the first slot of row B, and folds B later).  With one slot per line(s) every line of a row is read by its folder for
+// the first time in the launch, after every writer has drained: the question never arises.  Costs address space only (N = 16: 64 ->
+// 128 bytes per slot; the bytes written and read are the same).  The combine launch (fold off) keeps the dense layout.
+static inline int64_t fold_stride(int64_t N) { return (N + 31) / 32 * 32; }
+template <typename T>
+static inline T *align128(T *p) { return reinterpret_cast<T *>((reinterpret_cast<uintptr_t>(p) + 127) & ~uintptr_t(127)); }
 // feature tiles a launch over N floats can have (16-byte lanes: 256- or, narrowed, 64-float tiles; scalar lanes: 64-float tiles)
 static inline int64_t max_tiles(int64_t N) { return (N + 63) / 64 + 1; }
 static inline WsLayout ws_layout(int reduce_op, int64_t N, int64_t nnz) {
@@ -150,7 +161,7 @@ static inline WsLayout ws_layout(int reduce_op, int64_t N, int64_t nnz) {
   L.off_units = up(sizeof(SpmmWs));
   L.off_long = L.off_units + up((size_t)L.max_units * sizeof(int4));
   L.off_part = L.off_long + up((size_t)L.max_long * sizeof(int4));
-  const size_t prow = up((size_t)L.max_pslots * N * sizeof(float));  // one partial row per unit of a multi-unit row
+  const size_t prow = up((size_t)L.max_pslots * fold_stride(N) * sizeof(float) + 128);  // one partial row per unit of a multi-unit row (fold_stride + alignment slack: either layout fits)
   L.off_parte = L.off_part + prow;
   const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
   L.off_slot = L.off_parte + (arg ? prow : 0);                         // long-row index of every partial slot
@@ -167,7 +178,7 @@ static inline WsLayout ws_layout_plan(int reduce_op, int64_t N, int64_t pslots, 
   L.max_pslots = pslots;
   L.max_long = n_long;
   L.off_part = 0;
-  const size_t prow = up((size_t)(pslots > 0 ? pslots : 1) * N * sizeof(float));
+  const size_t prow = up((size_t)(pslots > 0 ? pslots : 1) * fold_stride(N) * sizeof(float) + 128);
   L.off_parte = prow;
   const bool arg = (reduce_op == DGS_MAX || reduce_op == DGS_MIN);
   L.off_arrive = prow + (arg ? prow : 0);
@@ -1024,8 +1035,9 @@ __device__ __forceinline__ void fold_row(const int4 d, const int lane, const int
                                          const int *__restrict__ col, const float *__restrict__ val,
                                          const float *__restrict__ B, float *__restrict__ C, int *__restrict__ E,
                                          const float *__restrict__ part, const int *__restrict__ parte, const AccArg &aa,
-                                         const unsigned part_bytes = 0) {
+                                         const unsigned part_bytes = 0, const int pstride = 0) {
   constexpr int NG = kWave / G;
+  const int ps = COH ? pstride : N;  // floats between two partial rows (COH: whole lines per slot, fold_stride)
   constexpr bool ARG = (OP == DGS_MAX || OP == DGS_MIN);
   const CohBuf cbp = coh_buf(part, COH ? part_bytes : 0), cbe = coh_buf(ARG ? (const void *)parte : (const void *)part, COH ? part_bytes : 0);
   // max: a partial row that never improved on the identity carries the identity as its value, so the fold needs values and
@@ -1053,7 +1065,7 @@ __device__ __forceinline__ void fold_row(const int4 d, const int lane, const int
     // one (ISA read, late round 3: combine of max 54.8 us for 10.4 us of sum on the headline graph)
 #pragma unroll
     for (int q = 0; q < UP; q++) {
-      const int64_t slot = (int64_t)(d.y + min(k + q * NG, d.z - 1)) * N + (fl ? f0 : 0);
+      const int64_t slot = (int64_t)(d.y + min(k + q * NG, d.z - 1)) * ps + (fl ? f0 : 0);
       load_part<V, COH>(part, slot, cbp, x[q]);
       if constexpr (ARG && !LATE_ARG) load_part<V, COH>(parte, slot, cbe, xe[q]);
     }
@@ -1094,7 +1106,7 @@ __device__ __forceinline__ void fold_row(const int4 d, const int lane, const int
 #pragma unroll
       for (int v = 0; v < V; v++) {
         if (ep[v] != INT_MAX) {
-          const int *q = parte + (int64_t)(d.y + ep[v]) * N + f0 + v;
+          const int *q = parte + (int64_t)(d.y + ep[v]) * ps + f0 + v;
           ei[v] = COH ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
         } else {
           ei[v] = -1;
@@ -1192,7 +1204,7 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
     tick_row = -1;
     if (old == lr.z - 1) {  // this wave brought the count to the row's number of units: every partial row has been written through
       __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      fold_row<G, V, OP, ACC, true>(lr, lane, N, rowptr, col, HAS_VAL ? val : nullptr, B, C, E, part, parte, aa, ut.part_bytes);
+      fold_row<G, V, OP, ACC, true>(lr, lane, N, rowptr, col, HAS_VAL ? val : nullptr, B, C, E, part, parte, aa, ut.part_bytes, ut.pstride);
     }
   };
   for (; u < uend; u += wstride) {
@@ -1245,7 +1257,7 @@ __device__ __forceinline__ void spmm_units_body(int bid, int nblocks, RowsLds &l
           if constexpr (ARG) store_vec_stream<V>(E + (int64_t)d.x * N + f0, ei);
         }
       } else {
-        const int64_t slot = (int64_t)d.w * N + f0;
+        const int64_t slot = (int64_t)d.w * (FOLD ? ut.pstride : N) + f0;
         if (folding) {
           store_part_coherent<V>(part, slot, cbp, acc);
           if constexpr (ARG) store_part_coherent<V>(parte, slot, cbe, ei);
@@ -1553,7 +1565,7 @@ void fold_gate_set(int state);
 // cannot see (tests/emu's relaxed-memory mode models it: sc1 write-through, per-wave store queues, per-XCD dirty lines, per-CU L1).
 // The fold's buffer descriptors reach a partial row through a 32-bit byte offset: in-kernel fold only below 2^31 bytes of partial
 // rows (20 MB on the headline graph; beyond, the combine launch folds - nothing else changes).
-static inline bool fold_fits(int64_t pslots, int64_t N) { return pslots * N * 4 < (int64_t(1) << 31); }
+static inline bool fold_fits(int64_t pslots, int64_t N) { return pslots * fold_stride(N) * 4 + 128 < (int64_t(1) << 31); }
 static inline bool fold_enabled(int hints) {
   if (hints & kHintNoFold) return false;
   if (hints & kHintForceFold) return true;
@@ -1641,7 +1653,9 @@ static int launch_impl(const SpmmArgs &a) {
       if (fold) {
         ut.slot_long = reinterpret_cast<const int *>(w + L.off_slot);
         ut.arrive = reinterpret_cast<int *>(w + L.off_arrive);
-        ut.part_bytes = (unsigned)(L.max_pslots * a.N * 4);
+        ut.pstride = (int)fold_stride(a.N);
+        part = align128(part), parte = align128(parte);
+        ut.part_bytes = (unsigned)(L.max_pslots * ut.pstride * 4);
       }
       hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, tl, thub, ht, a.rowptr, hdr,
                          units, longrows, const_cast<int *>(ut.slot_long), ut.arrive, (int)a.tiles);
@@ -1732,7 +1746,9 @@ static int launch_impl(const SpmmArgs &a) {
     // of the workspace a planned call has to zero (4 bytes per long row: 0.1 MB on the headline graph)
     const bool fold = fold_ok<OP>() && a.plan_long > 0 && fold_enabled(a.hints) && fold_fits(L.max_pslots, a.N);
     if (fold) {
-      ut.part_bytes = (unsigned)(L.max_pslots * a.N * 4);
+      ut.pstride = (int)fold_stride(a.N);
+      part = align128(part), parte = align128(parte);
+      ut.part_bytes = (unsigned)(L.max_pslots * ut.pstride * 4);
       ut.slot_long = reinterpret_cast<const int *>(pb + (a.plan_off_hub ? plan_off_slot((size_t)a.plan_off_hub, a.plan_hub) : PL.off_slot));
       ut.arrive = reinterpret_cast<int *>(w + L.off_arrive);
       if (hipMemsetAsync(ut.arrive, 0, (size_t)a.plan_long * a.tiles * sizeof(int), a.st) != hipSuccess) return DGS_ELAUNCH;
@@ -1762,7 +1778,9 @@ static int launch_impl(const SpmmArgs &a) {
   if (fold) {
     ut.slot_long = reinterpret_cast<const int *>(w + L.off_slot);
     ut.arrive = reinterpret_cast<int *>(w + L.off_arrive);
-    ut.part_bytes = (unsigned)(L.max_pslots * a.N * 4);
+    ut.pstride = (int)fold_stride(a.N);
+    part = align128(part), parte = align128(parte);
+    ut.part_bytes = (unsigned)(L.max_pslots * ut.pstride * 4);
   }
   hipLaunchKernelGGL(spmm_classify, dim3((unsigned)k0b), dim3(kBlock), 0, a.st, (int)a.M, L.ch, kT2, thub, ht, a.rowptr, hdr,
                      units, longrows, const_cast<int *>(ut.slot_long), ut.arrive, (int)a.tiles);

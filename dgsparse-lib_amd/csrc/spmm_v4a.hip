@@ -56,8 +56,7 @@ extern "C" int dgs_spmm_hub_threshold(void) {
 // ---- device self-tests: the hub chains, and the in-kernel fold (include/dgsparse_hip.h "Device gate") ---------------------------
 // Generated inputs (no host buffers: everything is a hash of the index).  Hub test: the default sum with the chains forced on
 // against a reference kernel that is beyond suspicion - one thread per (row, feature), one fmaf chain in CSR order - on every
-// family of hub workgroup the launchers can pick (16-byte lanes with 16 / 8 / 4 / 2-lane feature tiles, scalar lanes; the general and
-// the single-launch schedule).  Fold test (its own entry point, round 6): sum, max and min over matrices with hundreds of multi-unit
+// family of hub workgroup the launchers can pick (kHubShapes below; the general and the single-launch schedule).  Fold test (its own entry point, round 6): sum, max and min over matrices with hundreds of multi-unit
 // rows (2 .. 59 units each), folded inside the fused launch, against the SAME launches with the combine kernel behind them
 // (identical trees: identical bits, values and arg ids) - for every family of PARTIAL ROW the launchers can pick (whole-line slots,
 // slots that share a 128-byte line two / four / eight to a line, scalar-lane slots written with 4-byte agent-scope atomics, two
@@ -77,11 +76,17 @@ struct Shape {
 constexpr Shape general(int M, int N, int nmid, int midlen) { return Shape{M, 8192, N, {20000, kHubChain + 1, kHubChain, 5000}, nmid, midlen, midlen, 2}; }
 constexpr Shape single(int N) { return Shape{40, 8192, N, {20000, 17000, 70, 3}, 0, 0, 0, 3}; }
 // hub test.  General schedule: two hub rows (one of them threshold + 1), a row of exactly the threshold and tree rows; the
-// production-sized one first (> 2^16 rows), then one per lane family on a few thousand rows (> 2^18 nnz: still the general schedule).
-// Single-launch schedule (spmm_small_hub): 16-lane, 2-lane and scalar-lane feature tiles.
-constexpr Shape kHubShapes[] = {general(66000, 64, 0, 0), general(4096, 32, 1000, 240), general(4096, 16, 1000, 240),
-                                general(4096, 8, 1000, 240), general(4096, 20, 1000, 240), single(64), single(20), single(8)};
+// production-sized one first (> 2^16 rows), then one per FAMILY of hub workgroup on a few thousand rows (> 2^18 nnz: still the general
+// schedule).  A family is strict_hub_coop<V, GP>, GP = strict_hub_gp(G, V) the lanes of a feature slice: 16-byte lanes with 16 / 8 / 4 /
+// 2 / 1 lanes per slice (N = 256 / 128 / 64, 32, 16 / 8 / 4) and scalar lanes with 16 / 8 / 4 / 1 (N = 20 / 7 / 3 / 1).  Single-launch
+// schedule (spmm_small_hub: the same workgroup behind the row stream): 4-lane, 2-lane and scalar 16-lane slices.
+constexpr Shape kHubShapes[] = {general(66000, 64, 0, 0),       general(4096, 128, 1000, 240), general(4096, 256, 1000, 240),
+                                general(4096, 32, 1000, 240),   general(4096, 16, 1000, 240),  general(4096, 8, 1000, 240),
+                                general(4096, 4, 1000, 240),    general(4096, 20, 1000, 240),  general(4096, 7, 1000, 240),
+                                general(4096, 3, 1000, 240),    general(4096, 1, 1000, 240),   single(64),
+                                single(20),                     single(8)};
 constexpr int kNumHubShapes = sizeof(kHubShapes) / sizeof(kHubShapes[0]);
+static_assert(kNumHubShapes <= 32, "per-shape counters sit at [16, 48) of the scratch header");
 // fold test: per family 604 multi-unit rows - 59, 36, 12 and 3 units, 300 of 2 (the minimum) and 300 of 6 - whose ~2 500 partial
 // rows are written and folded by workgroups all over the chip.  Family = feature width = (lanes per row group, lane vector, tiles).
 constexpr Shape fold_shape_of(int N) { return Shape{2048, 8192, N, {15000, 9000, 3000, 700}, 600, 300, 1500, 2}; }
@@ -91,8 +96,11 @@ constexpr int kFoldWidths[] = {64,    // G 16, 16-byte lanes: 256-byte slots (wh
                                8,     // G 2: four to a line
                                4,     // G 1: eight to a line
                                20,    // scalar lanes (N % 4 != 0): 4-byte agent-scope atomic stores / loads, 80-byte slots
-                               256};  // two feature tiles of 32 lanes (narrowed): one arrival counter per row AND tile
+                               256,   // two feature tiles of 32 lanes (narrowed): one arrival counter per row AND tile
+                               128,   // G 32: 512-byte slots
+                               3};    // scalar lanes, 12-byte slots: ten to a line, every word its own fabric write
 constexpr int kNumFoldFamilies = sizeof(kFoldWidths) / sizeof(kFoldWidths[0]);
+static_assert(kNumFoldFamilies <= 14, "per-family counters sit at [2, 16) of the scratch header");
 __device__ __forceinline__ unsigned hash32(unsigned x) {
   x ^= x >> 16;
   x *= 0x7feb352du;
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void gen(Shape sh, int nnz, int *__restrict
   if (i < (int64_t)sh.K * sh.N) B[i] = unit_float(hash32((unsigned)i + 0x9e3779b9u));
 }
 // one workgroup per row, one thread per feature: algorithm 0 as written (include/cuda/spmm_cuda.cuh:27-47), fmaf-contracted
-__global__ __launch_bounds__(kWave) void reference(int N, const int *__restrict__ rowptr, const int *__restrict__ col,
+__global__ __launch_bounds__(kBlock) void reference(int N, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                    const float *__restrict__ val, const float *__restrict__ B,
                                                    float *__restrict__ C) {
   const int r = blockIdx.x, f = threadIdx.x;
@@ -224,7 +232,8 @@ static int hub_shape(const Shape &sh, int idx, char *base, hipStream_t st) {
   generate(sh, L, base, st);
   const int rc = product(sh, L, base, DGS_SUM, kHintForceHub | kHintNoFold, C, nullptr, st);
   if (rc != DGS_OK) return rc;
-  hipLaunchKernelGGL(reference, dim3((unsigned)sh.M), dim3(kWave), 0, st, sh.N, reinterpret_cast<int *>(base + L.rowptr),
+  static_assert(kBlock >= 256, "one thread per feature, N <= 256");
+  hipLaunchKernelGGL(reference, dim3((unsigned)sh.M), dim3((unsigned)(sh.N <= kWave ? kWave : kBlock)), 0, st, sh.N, reinterpret_cast<int *>(base + L.rowptr),
                      reinterpret_cast<int *>(base + L.col), reinterpret_cast<float *>(base + L.val),
                      reinterpret_cast<float *>(base + L.B), R);
   hipLaunchKernelGGL(compare, dim3((unsigned)(((int64_t)sh.M * sh.N + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sh.M, sh.N,
@@ -280,6 +289,7 @@ extern "C" size_t dgs_spmm_hub_selftest_bytes(void) {
 extern "C" int dgs_spmm_hub_gate(void) { return hub_gate(); }
 extern "C" int dgs_spmm_fold_gate(void) { return fold_gate(); }
 extern "C" int dgs_spmm_selftest_families(void) { return selftest::kNumFoldFamilies; }
+extern "C" int dgs_spmm_selftest_hub_shapes(void) { return selftest::kNumHubShapes; }
 extern "C" int dgs_spmm_selftest_detail(int32_t *out, int n) {
   for (int i = 0; i < n && i < 64; i++) out[i] = selftest::g_detail[i];
   return n < 64 ? n : 64;

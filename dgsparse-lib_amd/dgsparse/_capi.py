@@ -48,6 +48,8 @@ _lib.dgs_spmm_fold_selftest.restype = _int
 _lib.dgs_spmm_fold_selftest.argtypes = [_vp, _sz, _int, _int, _vp]
 _lib.dgs_spmm_selftest_families.restype = _int
 _lib.dgs_spmm_selftest_families.argtypes = []
+_lib.dgs_spmm_selftest_hub_shapes.restype = _int
+_lib.dgs_spmm_selftest_hub_shapes.argtypes = []
 _lib.dgs_spmm_selftest_detail.restype = _int
 _lib.dgs_spmm_selftest_detail.argtypes = [_vp, _int]
 _lib.dgs_reload_tuning.restype = None
@@ -139,7 +141,7 @@ _lib.dgs_scatter_add_rows_f32.restype = _int
 _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
 EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_reload_tuning', 'dgs_spmm_hub_threshold', 'dgs_spmm_hub_gate', 'dgs_spmm_fold_gate',
-           'dgs_spmm_hub_selftest_bytes', 'dgs_spmm_hub_selftest', 'dgs_spmm_fold_selftest', 'dgs_spmm_selftest_families', 'dgs_spmm_selftest_detail', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
+           'dgs_spmm_hub_selftest_bytes', 'dgs_spmm_hub_selftest', 'dgs_spmm_fold_selftest', 'dgs_spmm_selftest_families', 'dgs_spmm_selftest_hub_shapes', 'dgs_spmm_selftest_detail', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
            'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes', 'dgs_spmm_plan_build', 'dgs_spmm_plan_build2',
            'dgs_spmm_plan_compact_bytes', 'dgs_spmm_plan_compact', 'dgs_spmm_plan_info_from_header',
            'dgs_spmm_plan_thresholds', 'dgs_spmm_plan_provisional_info', 'dgs_spmm_csr_ex_f32', 'dgs_spmm_csr_plan_workspace_bytes',
@@ -214,7 +216,7 @@ _selftested = set()  # device indices whose hub self-test has run in this proces
 def ensure_hub_selftest(dev) -> None:
     """Runs the library's device self-test of the hub chains once per device and process (include/dgsparse_hip.h, "Device
     gate": the default sum / mean chain their hub rows only on a device where that chain has been compared, bit for bit, with a
-    one-thread-per-element sequential kernel - eight shapes, every lane family).  ~38 MB of scratch for a few milliseconds and ONE
+    one-thread-per-element sequential kernel - fourteen shapes: every family of hub workgroup, both schedules).  ~38 MB of scratch for a few milliseconds and ONE
     stream synchronisation, at the first use of the device; skipped (and retried later) while a stream capture is in progress;
     skipped for good - no scratch, no launch, no sync - in a process that pins DGS_HUB_CHAIN (and does not ask for DGS_FOLD=2: the
     in-kernel fold is off unless asked for, and only "2" leaves the decision to the device)."""

@@ -125,8 +125,9 @@ int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_
  * Device gate.  The hub workgroup keeps two register sets of gathers in flight across workgroup barriers while one wave chains
  * out of LDS - behaviour of the compiler's wait counts and of the memory system that only the hardware can confirm.  So without
  * an explicit DGS_HUB_CHAIN the chains are ON only on a device where dgs_spmm_hub_selftest() has passed in this process: it runs
- * the default sum on generated matrices with hub rows - every lane family of the hub workgroup (feature tiles of 16 / 8 / 4 / 2
- * 16-byte lanes, scalar lanes), the general and the single-launch schedule, eight shapes - against a one-thread-per-element
+ * the default sum on generated matrices with hub rows - every family of the hub workgroup (feature slices of 16 / 8 / 4 / 2 / 1
+ * 16-byte lanes = N 256 / 128 / 64, 32, 16 / 8 / 4, and of 16 / 8 / 4 / 1 scalar lanes = N 20 / 7 / 3 / 1), the general and the
+ * single-launch schedule, fourteen shapes (dgs_spmm_selftest_hub_shapes()) - against a one-thread-per-element
  * sequential fmaf kernel and demands identical bits on the hub rows (and 1e-5 elsewhere).  It is one of the TWO entry points of
  * this library that synchronise (`stream`, once) - call it once per device at start-up (dgsparse's Python layer and torch binding
  * do, at the first use of a device); until it has passed, rows above 64 nnz take the fixed tree on that device (the round-3
@@ -145,13 +146,13 @@ int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_
  * fixed unit order in both.  It is not a default because no hardware measurement says it is faster (round 6), and because only the
  * hardware can confirm the hand-over: dgs_spmm_fold_selftest() runs sum, max and min over generated matrices with ~600 multi-unit
  * rows (2 .. 59 units) both ways - for every family of partial row the launchers can pick (whole-line slots; slots that share a
- * 128-byte line two, four, eight to a line; scalar-lane slots; two feature tiles), `rounds` times each, the last round with a
+ * 128-byte line two, four, eight, ten to a line; scalar-lane slots; two feature tiles - nine families), `rounds` times each, the last round with a
  * streaming kernel loading the fabric from a second stream (flags bit 0) - and demands identical bits (values and arg ids).
  * flags bits 8 .. : run only these families (diagnosis; only a full run raises the gate).  Returns 1 / 0 / < 0 like the hub test;
  * synchronises `stream` once; same scratch.  DGS_FOLD=2 ("auto") makes dgs_spmm_hub_selftest() run it (3 rounds, loaded) and
  * folds in the kernel exactly where it passed (dgs_spmm_fold_gate(): 1 / 0 / -1).
  * dgs_spmm_selftest_detail(out, n): the mismatch counters of the last tests of this process - [0] hub total, [1] fold total,
- * [2 + f] fold family f (dgs_spmm_selftest_families() of them), [16 + h] hub shape h.
+ * [2 + f] fold family f (dgs_spmm_selftest_families() of them), [16 + h] hub shape h (dgs_spmm_selftest_hub_shapes() of them).
  * No reference counterpart (the reference has one kernel per algorithm id and no self-checks).
  */
 int dgs_spmm_hub_threshold(void);
@@ -161,6 +162,7 @@ int dgs_spmm_hub_gate(void);
 int dgs_spmm_fold_gate(void);
 int dgs_spmm_fold_selftest(void *scratch, size_t scratch_bytes, int rounds, int flags, dgsStream_t stream);
 int dgs_spmm_selftest_families(void);
+int dgs_spmm_selftest_hub_shapes(void);
 int dgs_spmm_selftest_detail(int32_t *out, int n);
 
 /*

@@ -116,7 +116,7 @@ def test_bench_line_over_the_emulation(monkeypatch, argv):
     # legs - schedule tag, hub_chain.on_ms / off_ms - are walked as they are on the headline graph)
     monkeypatch.setenv('DGS_HUB_CHAIN', '1024')
     E.lib().dgs_reload_tuning()
-    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '1', '--steps', '2', '--warmup', '1', '--settle', '0', '--no-dense', '--protocol-seeds', '2'] + argv)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '1', '--steps', '2', '--warmup', '1', '--settle', '0', '--no-dense', '--protocol-seeds', '2', '--fold-inprocess'] + argv)
     # the protocol's repeat counts are for a GPU: one emulated launch per measurement is enough to walk the code
     monkeypatch.setattr(B, 'event_ms', lambda fn, steps: (fn(), 1.0)[1])
     out = io.StringIO()

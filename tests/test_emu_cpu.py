@@ -511,10 +511,11 @@ def test_hub_chains_are_gated_on_the_device_self_test():
 
 FOLD_FAMILIES = {0: 'N=64: 16 lanes, 256-byte slots', 1: 'N=32: 128-byte slots', 2: 'N=16: two slots per 128-byte line',
                  3: 'N=8: four per line', 4: 'N=4: eight per line', 5: 'N=20: scalar lanes, 4-byte agent-scope atomics',
-                 6: 'N=256: two feature tiles, one arrival counter per row and tile'}
+                 6: 'N=256: two feature tiles, one arrival counter per row and tile', 7: 'N=128: 32 lanes, 512-byte slots',
+                 8: 'N=3: scalar lanes, 12-byte slots'}
 
 
-@pytest.mark.parametrize('fam', sorted(FOLD_FAMILIES) if os.environ.get('DGS_TEST_LONG') else [2, 5, 6], ids=lambda f: FOLD_FAMILIES[f].split(':')[0])
+@pytest.mark.parametrize('fam', sorted(FOLD_FAMILIES) if os.environ.get('DGS_TEST_LONG') else [2, 5, 6, 8], ids=lambda f: FOLD_FAMILIES[f].split(':')[0])
 def test_fold_self_test_covers_every_family_of_partial_row(fam):
     """dgs_spmm_fold_selftest runs the in-kernel fold against the combine launch for EVERY (lanes per row group, lane
     vector, tiles) family of partial row the launchers can pick for a folded call - listed in FOLD_FAMILIES, the library reports as

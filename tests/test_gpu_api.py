@@ -661,8 +661,10 @@ def test_hub_self_test_passes_on_this_device_and_gates_the_default(monkeypatch):
     from dgsparse import _capi
     monkeypatch.delenv('DGS_HUB_CHAIN', raising=False)
     _capi.ensure_hub_selftest(torch.device('cuda', torch.cuda.current_device()))
-    assert _capi.hub_gate() == 1, f'the hub-chain self-test FAILED on this device (per shape: {_capi.selftest_detail()[16:24]})'
-    assert _capi.selftest_detail()[16:24] == [0] * 8, 'every hub shape (lane family x schedule) bit-exact'
+    nsh = int(_capi._lib.dgs_spmm_selftest_hub_shapes())
+    assert nsh == 14
+    assert _capi.hub_gate() == 1, f'the hub-chain self-test FAILED on this device (per shape: {_capi.selftest_detail()[16:16 + nsh]})'
+    assert _capi.selftest_detail()[16:16 + nsh] == [0] * nsh, 'every hub shape (hub-workgroup family x schedule) bit-exact'
     assert _capi.hub_threshold() == 16384
     monkeypatch.setenv('DGS_HUB_CHAIN', '0')
     assert _capi.hub_threshold() == 0
@@ -687,19 +689,19 @@ def test_hub_self_test_passes_on_this_device_and_gates_the_default(monkeypatch):
 def test_fold_self_test_passes_for_every_family_of_partial_row(monkeypatch):
     """the in-kernel fold's hand-over (sc1 stores -> drain -> agent-scope counter -> sc1 loads) checked by the device
     for EVERY family of partial row the launchers can pick - whole-line slots (N = 64, 32), slots sharing a 128-byte line two / four
-    / eight to a line (N = 16, 8, 4), scalar-lane slots written with 4-byte atomics (N = 20), two feature tiles with their own
-    arrival counters (N = 256) - sum / max / min, rows of 2 .. 59 units, three rounds each, the last one with a streaming kernel
+    / eight to a line (N = 16, 8, 4), scalar-lane slots written with 4-byte atomics (N = 20, 3), two feature tiles with their own
+    arrival counters (N = 256), 512-byte slots (N = 128) - sum / max / min, rows of 2 .. 59 units, three rounds each, the last one with a streaming kernel
     loading the fabric from a second stream; then ten more loaded rounds of the line-sharing and scalar families.  The fold is
     opt-in (DGS_FOLD=1 | 2): the gate only matters to DGS_FOLD=2, and this test is what says whether opting in is safe here."""
     from dgsparse import _capi
     monkeypatch.delenv('DGS_FOLD', raising=False)
     _capi.reload_tuning()
-    assert _capi._lib.dgs_spmm_selftest_families() == 7
+    assert _capi._lib.dgs_spmm_selftest_families() == 9
     verdict, fam = _capi.fold_selftest(rounds=3, load=True)
-    assert verdict == 1 and fam == [0] * 7, f'in-kernel fold self-test FAILED: mismatches per family {fam}'
+    assert verdict == 1 and fam == [0] * 9, f'in-kernel fold self-test FAILED: mismatches per family {fam}'
     assert _capi.fold_gate() == 1
-    verdict, fam = _capi.fold_selftest(rounds=10, load=True, families=[2, 3, 4, 5])
-    assert verdict == 1 and fam == [0] * 7, f'in-kernel fold self-test FAILED under repetition: mismatches per family {fam}'
+    verdict, fam = _capi.fold_selftest(rounds=10, load=True, families=[2, 3, 4, 5, 8])
+    assert verdict == 1 and fam == [0] * 9, f'in-kernel fold self-test FAILED under repetition: mismatches per family {fam}'
     # the default does not fold in the kernel whatever the gate says; DGS_FOLD=2 does where the gate is up
     torch.cuda.synchronize()
 

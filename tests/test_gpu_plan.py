@@ -444,7 +444,7 @@ def test_in_kernel_fold_equals_the_combine_launch(capi, N, monkeypatch):
     row); and the device's fold self-test (every family of partial row) has passed here.  The fold is opt-in since round 6."""
     if capi.fold_gate() == 0:
         capi.fold_selftest(rounds=3, load=True)
-    assert capi.fold_gate() == 1, f'the in-kernel fold self-test FAILED on this device: {capi.selftest_detail()[2:9]}'
+    assert capi.fold_gate() == 1, f'the in-kernel fold self-test FAILED on this device: {capi.selftest_detail()[2:11]}'
     rp, col, st = graphgen.powerlaw_csr(300000, 3000000, alpha=2.0, dmax=20000, seed=31)
     val = graphgen.weights(col.shape[0], 'signed', 3)
     X = graphgen.features(st['K'], N, 4)
