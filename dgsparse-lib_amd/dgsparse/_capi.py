@@ -216,7 +216,7 @@ _selftested = set()  # device indices whose hub self-test has run in this proces
 def ensure_hub_selftest(dev) -> None:
     """Runs the library's device self-test of the hub chains once per device and process (include/dgsparse_hip.h, "Device
     gate": the default sum / mean chain their hub rows only on a device where that chain has been compared, bit for bit, with a
-    one-thread-per-element sequential kernel - fourteen shapes: every family of hub workgroup, both schedules).  ~38 MB of scratch for a few milliseconds and ONE
+    one-thread-per-element sequential kernel - fourteen shapes: every family of hub workgroup, both schedules).  ~38 MB of scratch for some tens of milliseconds and ONE
     stream synchronisation, at the first use of the device; skipped (and retried later) while a stream capture is in progress;
     skipped for good - no scratch, no launch, no sync - in a process that pins DGS_HUB_CHAIN (and does not ask for DGS_FOLD=2: the
     in-kernel fold is off unless asked for, and only "2" leaves the decision to the device)."""

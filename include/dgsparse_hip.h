@@ -142,8 +142,8 @@ int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_
  * behind the fused launch folds them.  With DGS_FOLD=1 the unit wave that completes a row (an arrival counter per row and feature
  * tile, zeroed per call) folds it inside the fused launch - one launch less per call, the fold overlapping the rest of the launch.
  * The partial rows then cross from one workgroup to another - possibly on another XCD, behind another L2 - through agent-scope
- * (sc1, write-through) stores and sc1 loads ordered around the counter's atomic.  Same results either way: the fold order is the
- * fixed unit order in both.  It is not a default because no hardware measurement says it is faster (round 6), and because only the
+ * (sc1, write-through) stores and sc1 loads ordered around the counter's atomic, every partial row on 128-byte lines of its own
+ * (no line is shared between two rows' slots).  Same results either way: the fold order is the fixed unit order in both.  It is not a default because no hardware measurement says it is faster (round 6), and because only the
  * hardware can confirm the hand-over: dgs_spmm_fold_selftest() runs sum, max and min over generated matrices with ~600 multi-unit
  * rows (2 .. 59 units) both ways - for every family of partial row the launchers can pick (whole-line slots; slots that share a
  * 128-byte line two, four, eight, ten to a line; scalar-lane slots; two feature tiles - nine families), `rounds` times each, the last round with a

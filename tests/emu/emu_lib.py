@@ -40,7 +40,8 @@ def lib():
         for f in ('dgs_spmm_csr_workspace_bytes', 'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes',
                   'dgs_spmm_csr_plan_workspace_bytes', 'dgs_spmm_plan_compact_bytes', 'dgs_spmm_hub_selftest_bytes'):
             getattr(_lib, f).restype = ctypes.c_size_t
-        assert hub_selftest() == 1, 'the hub-chain self-test fails on the emulation'
+        if os.environ.get('DGS_EMU_NO_SELFTEST') != '1':  # (tests of the gate itself load the library as a C caller would: unverified)
+            assert hub_selftest() == 1, 'the hub-chain self-test fails on the emulation'
     return _lib
 
 

@@ -509,6 +509,53 @@ def test_hub_chains_are_gated_on_the_device_self_test():
 
 
 
+def test_a_plan_built_before_the_gate_chains_its_hub_rows_once_the_gate_is_up():
+    """the plan's hub table used to be cut with the threshold in force at BUILD time - INT_MAX until the device self-test
+    has passed - so a plan built by a C caller that had not run the test yet (or during a stream capture) carried n_hub = 0 for
+    good: its planned sums kept the tree on rows the plan-free calls chained once the gate was up.  Now the table is cut with the
+    compiled-in threshold whatever the gate says, and each LAUNCH decides whether to use it."""
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, os, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import emu_lib as E, oracle
+rng = np.random.default_rng(4)
+M, K, N = 66000, 30000, 16
+deg = rng.integers(0, 2, M)
+deg[11], deg[500] = 17000, 900
+rp = np.zeros(M + 1, np.int32); rp[1:] = np.cumsum(deg)
+col = np.concatenate([np.sort(rng.choice(K, d, replace=False)) for d in deg]).astype(np.int32)
+val = rng.random(col.size, dtype=np.float32)
+X = rng.random((K, N), dtype=np.float32)
+L = E.lib()                                    # DGS_EMU_NO_SELFTEST=1: as a C caller that has not run the self-test
+print('gate_before', L.dgs_spmm_hub_gate(), L.dgs_spmm_hub_threshold())
+plan = E.spmm_plan(rp, col, K)
+print('n_hub', plan[1].n_hub)
+chain, _ = oracle.spmm('sum', rp, col, val, X, fma=True)
+E.launch_log()
+C0, _ = E.spmm(E.SUM, rp, col, val, X, plan=plan)
+g0 = [g for n, g, _ in E.launch_log() if 'spmm_fused' in n]
+print('before_tree_within_1e5', bool(np.allclose(C0, chain, rtol=1e-5, atol=1e-6)), 'hub_row_is_chain', bool(np.array_equal(C0[11].view(np.int32), chain[11].view(np.int32))))
+print('selftest', E.hub_selftest(), 'gate_after', L.dgs_spmm_hub_gate(), L.dgs_spmm_hub_threshold())
+E.launch_log()
+C1, _ = E.spmm(E.SUM, rp, col, val, X, plan=plan)   # the SAME plan
+g1 = [g for n, g, _ in E.launch_log() if 'spmm_fused' in n]
+print('after_hub_row_is_chain', bool(np.array_equal(C1[11].view(np.int32), chain[11].view(np.int32))), 'more_blocks', g1[0] > g0[0])
+""" % (root, here)
+    E.lib()
+    env = {k: v for k, v in os.environ.items() if not k.startswith('DGS_')}
+    env['DGS_EMU_NO_SELFTEST'] = '1'
+    p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = dict(line.split(' ', 1) for line in p.stdout.strip().splitlines())
+    assert out['gate_before'] == '0 0' and out['n_hub'] == '1', out
+    assert out['before_tree_within_1e5'] == 'True hub_row_is_chain False', out
+    assert out['selftest'] == '1 gate_after 1 16384', out
+    assert out['after_hub_row_is_chain'] == 'True more_blocks True', out
+
+
 FOLD_FAMILIES = {0: 'N=64: 16 lanes, 256-byte slots', 1: 'N=32: 128-byte slots', 2: 'N=16: two slots per 128-byte line',
                  3: 'N=8: four per line', 4: 'N=4: eight per line', 5: 'N=20: scalar lanes, 4-byte agent-scope atomics',
                  6: 'N=256: two feature tiles, one arrival counter per row and tile', 7: 'N=128: 32 lanes, 512-byte slots',
