@@ -143,7 +143,10 @@ static inline int unit_len(int64_t nnz) {
 // also holds the first slot of row B, and folds B later).  With one slot per line(s) every line of a row is read by its folder for
 // the first time in the launch, after every writer has drained: the question never arises.  Costs address space only (N = 16: 64 ->
 // 128 bytes per slot; the bytes written and read are the same).  The combine launch (fold off) keeps the dense layout.
-static inline int64_t fold_stride(int64_t N) { return (N + 31) / 32 * 32; }
+#ifndef DGS_FOLD_DENSE
+#define DGS_FOLD_DENSE 0  // 1 (tests/emu/mutation_check_mem.py only): the twin keeps the combine launch's dense layout - slots narrower than a line share lines
+#endif
+static inline int64_t fold_stride(int64_t N) { return DGS_FOLD_DENSE ? N : (N + 31) / 32 * 32; }
 template <typename T>
 static inline T *align128(T *p) { return reinterpret_cast<T *>((reinterpret_cast<uintptr_t>(p) + 127) & ~uintptr_t(127)); }
 // feature tiles a launch over N floats can have (16-byte lanes: 256- or, narrowed, 64-float tiles; scalar lanes: 64-float tiles)

@@ -539,10 +539,17 @@ void mem_store(void *p, const void *src, unsigned bytes, int sc1) {
     g_cnt_stores++;
   }
 }
-void mem_drain() {  // s_waitcnt vmcnt(0): a WAVE instruction - every live lane is here (lockstep), then the wave's stores are performed
-  if (!mem_on()) return;
-  wave_sync();
-  drain_queue(blk, me->wave);
+// s_waitcnt vmcnt(0) is a WAVE instruction: when it retires, every lane's earlier stores have been issued AND performed.  The fibers
+// of a wave are not in lockstep, so "every lane's earlier stores have been issued" has to be said explicitly - in BOTH memory modes: a
+// lane that draws an arrival ticket behind the drain must not do so while its wave-mates' fibers have not reached their stores yet
+// (found by the round-6 campaign with resident workgroups in random fiber order: a unit wave with no ticket in flight counted its
+// last partial row in before lanes 1 .. 63 had written theirs, and a wave of the SAME workgroup folded the row - one arg id wrong.
+// An artefact of the emulation: on the hardware the wave's stores precede the wait in program order).  Then the queue is performed.
+void mem_drain() {
+  if (blk == nullptr) return;
+  static const bool nosync = getenv("DGS_EMU_DRAIN_NOSYNC") != nullptr;  // (the pre-fix behaviour, to reproduce the artefact)
+  if (!nosync || mem_on()) wave_sync();
+  if (mem_on()) drain_queue(blk, me->wave);
 }
 void mem_wave_end(Block *b, int wave) {
   if (g_mem_on) drain_queue(b, wave);

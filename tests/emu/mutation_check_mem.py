@@ -10,7 +10,7 @@ mutant below is a copy of csrc with ONE element of the protocol removed:
 
   sc1-store   store_part_coherent -> store_vec            (plain stores: the partial rows stay in the writer's XCD)
   drain       drain_vmem() removed from count_in          (the counter overtakes the stores)
-  sc1-load    fold_row<..., COH = true> -> false          (plain loads: served by the folding CU's L1)
+  sc1-load    load_part<V, COH> -> load_part<V, false> in fold_row (plain loads: served by the folding CU's L1)
   tail        the pipeline drain behind the unit loop removed (the wave's last partial row is never counted in)
   late        count_in right behind the stores of the SAME unit without the drain (ticket issued while the stores are in flight)
 
@@ -46,7 +46,10 @@ def m_drain(s):
 
 
 def m_sc1_load(s):
-    return sub(s, 'fold_row<G, V, OP, ACC, true>(lr, lane, N,', 'fold_row<G, V, OP, ACC, false>(lr, lane, N,')
+    # (only the FLAVOUR of the fold's loads: COH also selects the row stride, which must stay the writers')
+    s = sub(s, 'load_part<V, COH>(part, slot, cbp, x[q]);', 'load_part<V, false>(part, slot, cbp, x[q]);')
+    return sub(s, 'if constexpr (ARG && !LATE_ARG) load_part<V, COH>(parte, slot, cbe, xe[q]);',
+               'if constexpr (ARG && !LATE_ARG) load_part<V, false>(parte, slot, cbe, xe[q]);')
 
 
 def m_tail(s):
@@ -67,9 +70,21 @@ def m_late(s):
     return s
 
 
+def dense(s):
+    # the fold twin with the combine launch's dense partial-row layout (slots narrower than 128 bytes share lines) instead of one
+    # slot per line(s): what the twin was before the padding, and what makes an L1-served load of a neighbour's line possible
+    return '#define DGS_FOLD_DENSE 1\n' + s
+
+
 MUTANTS = {'none': lambda s: s, 'sc1-store (plain stores)': m_sc1_store, 'drain (no s_waitcnt vmcnt(0) before the counter)': m_drain,
            'sc1-load (plain loads in the fold)': m_sc1_load, 'tail (last partial row never counted in)': m_tail,
-           'late (ticket drawn right behind the stores, no drain)': m_late}
+           'late (ticket drawn right behind the stores, no drain)': m_late,
+           'none, dense layout (slots share lines)': dense,
+           'sc1-load, dense layout': lambda s: dense(m_sc1_load(s))}
+# With every partial row on lines of its own (fold_stride) a folder reads each line of its row for the first time in the launch, so
+# even PLAIN loads cannot be served stale by L1 under this model: the sc1-load mutant may survive there (sc1 on the loads is then
+# defence in depth) - it must be killed in the dense layout, which is what shows that the model sees L1-served loads at all.
+MAY_SURVIVE = {'sc1-load (plain loads in the fold)'}
 
 RUN = r'''
 import os, sys
@@ -140,7 +155,12 @@ def main():
                 res.append('ok' if (b, u, l) == (0, 0, 0) else f'{b} wrong bits, {u} unperformed reads, {l} L1-stale reads')
         rows.append((name, res))
         print(f'{name:52s} ' + ' | '.join(res), flush=True)
-    ok = all(x == 'ok' for n, r in rows if n == 'none' for x in r) and all(any(x != 'ok' for x in r) for n, r in rows if n != 'none')
+    clean = [n for n, _ in rows if n.startswith('none')]
+    ok = all(x == 'ok' for n, r in rows if n in clean for x in r) and \
+        all(any(x != 'ok' for x in r) for n, r in rows if n not in clean and n not in MAY_SURVIVE)
+    for n, r in rows:
+        if n in MAY_SURVIVE and all(x == 'ok' for x in r):
+            print(f'({n}: survives with one slot per line - no line is read twice, so L1 has nothing stale to serve; killed in the dense layout below)')
     print('schedules: ' + ' | '.join(' '.join(f'{k[8:]}={v}' for k, v in s.items()) for s in SCHEDULES))
     print('unmutated sources: right bits and zero hazards under every schedule; every mutant is killed by at least one' if ok
           else 'MUTATION CHECK FAILED')
