@@ -287,6 +287,15 @@ extern "C" size_t dgs_spmm_hub_selftest_bytes(void) {
   return m;
 }
 extern "C" int dgs_spmm_hub_gate(void) { return hub_gate(); }
+// For hosts that keep the verdict of an IDENTICAL (library binary, device model, runtime) triple across processes - DataLoader workers,
+// the ranks of a job - instead of paying the self-test in each: sets the hub gate of the current device (1 passed / -1 failed / 0 not
+// run), returns the previous state.  As much a bypass as DGS_HUB_CHAIN=16384 is; dgsparse's Python layer uses it only with
+// DGS_GATE_CACHE set, and only for verdicts this library wrote itself (dgsparse/_capi.py: _gate_cache_*).
+extern "C" int dgs_spmm_hub_gate_assume(int verdict) {
+  const int prev = hub_gate();
+  hub_gate_set(verdict > 0 ? 1 : (verdict < 0 ? -1 : 0));
+  return prev;
+}
 extern "C" int dgs_spmm_fold_gate(void) { return fold_gate(); }
 extern "C" int dgs_spmm_selftest_families(void) { return selftest::kNumFoldFamilies; }
 extern "C" int dgs_spmm_selftest_hub_shapes(void) { return selftest::kNumHubShapes; }

@@ -38,6 +38,8 @@ _lib.dgs_spmm_hub_threshold.restype = _int
 _lib.dgs_spmm_hub_threshold.argtypes = []
 _lib.dgs_spmm_hub_gate.restype = _int
 _lib.dgs_spmm_hub_gate.argtypes = []
+_lib.dgs_spmm_hub_gate_assume.restype = _int
+_lib.dgs_spmm_hub_gate_assume.argtypes = [_int]
 _lib.dgs_spmm_fold_gate.restype = _int
 _lib.dgs_spmm_fold_gate.argtypes = []
 _lib.dgs_spmm_hub_selftest_bytes.restype = _sz
@@ -140,7 +142,7 @@ _lib.dgs_spmm_min_merge_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp, ctypes.c
 _lib.dgs_scatter_add_rows_f32.restype = _int
 _lib.dgs_scatter_add_rows_f32.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp]
 
-EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_reload_tuning', 'dgs_spmm_hub_threshold', 'dgs_spmm_hub_gate', 'dgs_spmm_fold_gate',
+EXPORTS = ['dgs_version', 'dgs_arch', 'dgs_strerror', 'dgs_reload_tuning', 'dgs_spmm_hub_threshold', 'dgs_spmm_hub_gate', 'dgs_spmm_hub_gate_assume', 'dgs_spmm_fold_gate',
            'dgs_spmm_hub_selftest_bytes', 'dgs_spmm_hub_selftest', 'dgs_spmm_fold_selftest', 'dgs_spmm_selftest_families', 'dgs_spmm_selftest_hub_shapes', 'dgs_spmm_selftest_detail', 'dgs_spmm_csr_workspace_bytes', 'dgs_spmm_csr_f32',
            'dgs_spmm_plan_bytes', 'dgs_spmm_plan_workspace_bytes', 'dgs_spmm_plan_build', 'dgs_spmm_plan_build2',
            'dgs_spmm_plan_compact_bytes', 'dgs_spmm_plan_compact', 'dgs_spmm_plan_info_from_header',
@@ -213,6 +215,52 @@ def hub_threshold() -> int:
 _selftested = set()  # device indices whose hub self-test has run in this process
 
 
+# ---- optional verdict cache (DGS_GATE_CACHE=<directory>) -------------------------------------------------------------------------------
+# The device gate is per process: every DataLoader worker and every rank of a job pays ~38 MB of scratch, some tens of milliseconds
+# and a stream synchronisation for a verdict that is a property of (this library binary, the device model, the HIP runtime).  With
+# DGS_GATE_CACHE set, a PASS is written to <dir>/dgs_gate_<key>.json and the next process with the same key adopts it
+# (dgs_spmm_hub_gate_assume) instead of running the test.  Failures are never cached (they are re-tested and reported every time),
+# a cache entry never turns the chains OFF, and an explicit DGS_HUB_CHAIN wins over everything as before.
+def _gate_key(props: dict) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    with open(LIB_PATH, 'rb') as f:
+        for chunk in iter(lambda: f.read(1 << 20), b''):
+            h.update(chunk)
+    for k in sorted(props):
+        h.update(f'|{k}={props[k]}'.encode())
+    return h.hexdigest()[:32]
+
+
+def _gate_props(idx: int) -> dict:
+    p = torch.cuda.get_device_properties(idx)
+    return dict(name=p.name, arch=getattr(p, 'gcnArchName', ''), cus=p.multi_processor_count, mem=p.total_memory,
+                hip=str(torch.version.hip), abi=int(_lib.dgs_version()))
+
+
+def _gate_cache_read(directory: str, key: str):
+    import json
+    try:
+        with open(os.path.join(directory, f'dgs_gate_{key}.json')) as f:
+            d = json.load(f)
+        return 1 if (d.get('key') == key and d.get('hub_chains') == 1) else None
+    except (OSError, ValueError):
+        return None
+
+
+def _gate_cache_write(directory: str, key: str, props: dict) -> None:
+    import json
+    import tempfile
+    try:
+        os.makedirs(directory, exist_ok=True)
+        fd, tmp = tempfile.mkstemp(dir=directory, prefix='.dgs_gate_')
+        with os.fdopen(fd, 'w') as f:
+            json.dump(dict(key=key, hub_chains=1, device=props, library=LIB_PATH), f)
+        os.replace(tmp, os.path.join(directory, f'dgs_gate_{key}.json'))  # atomic: concurrent workers write the same content
+    except OSError:
+        pass  # a cache that cannot be written is no cache
+
+
 def ensure_hub_selftest(dev) -> None:
     """Runs the library's device self-test of the hub chains once per device and process (include/dgsparse_hip.h, "Device
     gate": the default sum / mean chain their hub rows only on a device where that chain has been compared, bit for bit, with a
@@ -226,6 +274,15 @@ def ensure_hub_selftest(dev) -> None:
     if os.environ.get('DGS_HUB_CHAIN', '') != '' and os.environ.get('DGS_FOLD', '') != '2':
         _selftested.add(idx)  # the library would return at once as well (dgs_spmm_hub_selftest): spare the allocation
         return
+    cache_dir, key, props = os.environ.get('DGS_GATE_CACHE', ''), None, None
+    if cache_dir and os.environ.get('DGS_HUB_CHAIN', '') == '' and os.environ.get('DGS_FOLD', '') != '2':
+        props = _gate_props(idx)
+        key = _gate_key(props)
+        if _gate_cache_read(cache_dir, key) == 1:  # an identical library passed on an identical device + runtime
+            with _on_device(torch.device('cuda', idx)):
+                _lib.dgs_spmm_hub_gate_assume(1)
+            _selftested.add(idx)
+            return
     if torch.cuda.is_current_stream_capturing():
         return
     _selftested.add(idx)
@@ -234,9 +291,12 @@ def ensure_hub_selftest(dev) -> None:
         nb = int(_lib.dgs_spmm_hub_selftest_bytes())
         scratch = torch.empty(nb, dtype=torch.uint8, device=d)
         rc = int(_lib.dgs_spmm_hub_selftest(_p(scratch), nb, _stream(d)))
+        gate_now = int(_lib.dgs_spmm_hub_gate())  # (of device idx: still the current device here)
     if rc < 0:
         _selftested.discard(idx)
         _check(rc, 'spmm_hub_selftest')
+    if rc == 1 and key is not None and gate_now == 1:
+        _gate_cache_write(cache_dir, key, props)
     if fold_gate() < 0:
         import warnings
         warnings.warn(f'dgsparse: the in-kernel fold self-test FAILED on cuda:{idx} (DGS_FOLD=2): multi-unit rows are folded by the '

@@ -136,7 +136,9 @@ int dgs_spmm_csr_schedule(int reduce_op, int64_t M, int64_t K, int64_t N, int64_
  * environment bypasses the gate both ways (n = 0: off, n > 0: on at that threshold) and the test is then skipped (returns 1, no
  * launch, no synchronisation).
  *   scratch: dgs_spmm_hub_selftest_bytes() bytes of device memory (~38 MB), 256-B aligned, contents undefined on entry and exit.
- * dgs_spmm_hub_gate(): 1 / 0 / -1 = passed / not run / failed on the current device.
+ * dgs_spmm_hub_gate(): 1 / 0 / -1 = passed / not run / failed on the current device.  dgs_spmm_hub_gate_assume(v) sets it (returns the
+ * previous state): for hosts that cache the verdict of an identical (library binary, device model, runtime) triple across processes
+ * - every DataLoader worker and rank pays the test otherwise.  A bypass like DGS_HUB_CHAIN; dgsparse uses it only under DGS_GATE_CACHE.
  *
  * The IN-KERNEL FOLD (off by default).  Rows that are cut into several units leave partial rows in the workspace; a combine launch
  * behind the fused launch folds them.  With DGS_FOLD=1 the unit wave that completes a row (an arrival counter per row and feature
@@ -159,6 +161,7 @@ int dgs_spmm_hub_threshold(void);
 size_t dgs_spmm_hub_selftest_bytes(void);
 int dgs_spmm_hub_selftest(void *scratch, size_t scratch_bytes, dgsStream_t stream);
 int dgs_spmm_hub_gate(void);
+int dgs_spmm_hub_gate_assume(int verdict);
 int dgs_spmm_fold_gate(void);
 int dgs_spmm_fold_selftest(void *scratch, size_t scratch_bytes, int rounds, int flags, dgsStream_t stream);
 int dgs_spmm_selftest_families(void);

@@ -556,6 +556,61 @@ print('after_hub_row_is_chain', bool(np.array_equal(C1[11].view(np.int32), chain
     assert out['after_hub_row_is_chain'] == 'True more_blocks True', out
 
 
+RELAXED_CASE = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(here)r)
+import oracle
+import emu_lib as E
+rng = np.random.default_rng(6)
+M, K = 2400, 9000
+deg = rng.integers(0, 5, M)
+deg[100:1150] = 200
+deg[1500:1600] = rng.integers(257, 1400, 100)
+deg[7] = 5200
+deg[2300:2340] = 300
+rp = np.zeros(M + 1, np.int32); rp[1:] = np.cumsum(deg)
+assert rp[-1] > (1 << 18)
+col = np.concatenate([np.sort(rng.choice(K, d, replace=False)) for d in deg]).astype(np.int32)
+val = (rng.random(col.size, dtype=np.float32) - 0.3).astype(np.float32)
+E.set_env(DGS_FOLD=1, DGS_HUB_CHAIN=0, DGS_NBU=16)
+plan = E.spmm_plan(rp, col, K)
+bad = haz = acc = 0
+for N, cells in ((16, ((E.MAX, None), (E.MIN, plan))), (20, ((E.SUM, plan),))):
+    X = rng.random((K, N), dtype=np.float32)
+    for op, pl in cells:
+        E.mem_report()
+        C, Eo = E.spmm(op, rp, col, val, X, plan=pl)
+        r = E.mem_report()
+        haz += r['unperformed'] + r['l1_stale']; acc += r['loads'] + r['stores']
+        if op == E.SUM:
+            E.set_env(DGS_FOLD=0); C0, _ = E.spmm(op, rp, col, val, X, plan=pl); E.set_env(DGS_FOLD=1)
+            bad += int((C.view(np.int32) != C0.view(np.int32)).sum())
+        else:
+            ref, Er = oracle.spmm({E.MAX: 'max', E.MIN: 'min'}[op], rp, col, val, X, fma=True)
+            bad += int((C.view(np.int32) != ref.view(np.int32)).sum()) + int((Eo != Er).sum())
+print('BAD', bad, 'HAZARDS', haz, 'ACCESSES', acc)
+"""
+
+
+def test_fold_hand_over_under_the_relaxed_memory_mode():
+    """VERDICT r5 #3, the standing part: the in-kernel fold (DGS_FOLD=1) with the emulator's relaxed-memory mode on - per-wave store
+    queues performed at the drain, plain stores dirty in their XCD's L2, plain loads through a never-refreshed per-CU L1 - and 24
+    resident workgroups pre-empting one another at rendezvous points: the oracle's bits and ZERO reads that missed a newer value
+    (16-byte sc1 lanes, max plan-free and min over a plan; scalar lanes, sum over a plan).  That the mode NOTICES a broken hand-over
+    is shown by tests/emu/mutation_check_mem.py (five mutants, profiles/r06_emu_mutants.txt; ~25 min, not part of this suite)."""
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    E.lib()
+    env = {k: v for k, v in os.environ.items() if not k.startswith('DGS_')}
+    env.update(DGS_EMU_MEM='relaxed', DGS_EMU_BLOCKS='24', DGS_EMU_BLOCK_ORDER='rand:4', DGS_EMU_PREEMPT='8')
+    p = subprocess.run([sys.executable, '-c', RELAXED_CASE % dict(root=root, here=here)], capture_output=True, text=True, env=env, timeout=1200)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = p.stdout.strip().splitlines()[-1].split()
+    assert out[0] == 'BAD' and out[1] == '0' and out[3] == '0' and int(out[5]) > 100000, p.stdout[-500:]
+
+
 FOLD_FAMILIES = {0: 'N=64: 16 lanes, 256-byte slots', 1: 'N=32: 128-byte slots', 2: 'N=16: two slots per 128-byte line',
                  3: 'N=8: four per line', 4: 'N=4: eight per line', 5: 'N=20: scalar lanes, 4-byte agent-scope atomics',
                  6: 'N=256: two feature tiles, one arrival counter per row and tile', 7: 'N=128: 32 lanes, 512-byte slots',

@@ -1,6 +1,8 @@
 """GPU tests of the drop-in Python surface (dgsparse.spmm_* / SparseTensor / torch.ops.dgsparse_spmm.*),
 written the way the reference's own tests are (test/test_spmm.py: forward_check / backward_check against
 torch.sparse.mm, here via the committed golden vectors generated from exactly that call)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -683,6 +685,31 @@ def test_hub_self_test_passes_on_this_device_and_gates_the_default(monkeypatch):
     assert _capi._lib.dgs_spmm_hub_selftest(None, 0, torch.cuda.current_stream().cuda_stream) == 1
     monkeypatch.delenv('DGS_HUB_CHAIN')
     _capi.reload_tuning()
+
+
+@pytest.mark.first_contact
+def test_gate_verdict_cache_spares_the_second_process_the_self_test(monkeypatch, tmp_path):
+    """DGS_GATE_CACHE: a PASS of the hub self-test is kept per (library binary, device model, runtime); a later process - here: the
+    same one with its per-process state wiped - adopts it through dgs_spmm_hub_gate_assume instead of running the test again."""
+    from dgsparse import _capi
+    monkeypatch.delenv('DGS_HUB_CHAIN', raising=False)
+    monkeypatch.setenv('DGS_GATE_CACHE', str(tmp_path))
+    dev = torch.device('cuda', torch.cuda.current_device())
+    _capi._selftested.discard(dev.index)
+    _capi._lib.dgs_spmm_hub_gate_assume(0)
+    _capi.ensure_hub_selftest(dev)                      # runs the test, writes the verdict
+    assert _capi.hub_gate() == 1
+    files = [f for f in os.listdir(tmp_path) if f.startswith('dgs_gate_')]
+    assert len(files) == 1
+    _capi._selftested.discard(dev.index)
+    _capi._lib.dgs_spmm_hub_gate_assume(0)
+    assert _capi.hub_gate() == 0
+
+    def boom(*a):
+        raise AssertionError('the self-test ran although a cached verdict exists')
+    monkeypatch.setattr(_capi._lib, 'dgs_spmm_hub_selftest', boom)
+    _capi.ensure_hub_selftest(dev)                      # adopts it
+    assert _capi.hub_gate() == 1 and _capi.hub_threshold() == 16384
 
 
 @pytest.mark.first_contact

@@ -263,3 +263,26 @@ def test_counter_based_sampler_matches_its_definition():
     for cols in ('uniform', 'local'):
         rp, col, st = graphgen.powerlaw_csr(3000, 30000, alpha=2.2, dmax=300, cols=cols, seed=1, sampler='hash')
         assert 0 <= col.min() and col.max() < 3000 and rp[-1] == col.shape[0]
+
+
+def test_gate_verdict_cache_key_read_write(tmp_path, monkeypatch):
+    """DGS_GATE_CACHE (the device gate is per process - every DataLoader worker and rank pays it): a PASS is kept
+    per (library binary, device model, runtime) key; a different device model or library is a different key; failures are never
+    written; a damaged or foreign file is no verdict."""
+    from dgsparse import _capi
+    props = dict(name='AMD Instinct MI355X', arch='gfx950:sramecc+:xnack-', cus=256, mem=309220868096, hip='7.0.0', abi=_capi.version())
+    k1 = _capi._gate_key(props)
+    assert len(k1) == 32 and k1 == _capi._gate_key(dict(props))
+    assert _capi._gate_key(dict(props, cus=304)) != k1 and _capi._gate_key(dict(props, hip='7.2.0')) != k1
+    d = str(tmp_path / 'gate')
+    assert _capi._gate_cache_read(d, k1) is None            # no directory yet
+    _capi._gate_cache_write(d, k1, props)
+    assert _capi._gate_cache_read(d, k1) == 1
+    assert _capi._gate_cache_read(d, _capi._gate_key(dict(props, cus=304))) is None
+    with open(f'{d}/dgs_gate_{k1}.json', 'w') as f:
+        f.write('{"key": "someone else", "hub_chains": 1}')
+    assert _capi._gate_cache_read(d, k1) is None            # a file that does not carry its own key
+    with open(f'{d}/dgs_gate_{k1}.json', 'w') as f:
+        f.write('not json')
+    assert _capi._gate_cache_read(d, k1) is None
+    _capi._gate_cache_write('/proc/definitely/not/writable', k1, props)  # must not raise
