@@ -81,7 +81,7 @@ def fold_selftest(rounds=1, load=False, families=None):
     full run moves the fold gate)."""
     L = lib()
     nb = L.dgs_spmm_hub_selftest_bytes()
-    scratch = _buf(nb)
+    scratch = _ws(nb)  # (under DGS_EMU_MEM=relaxed the scratch - the products' workspaces live inside it - is the watched range)
     flags = (1 if load else 0) | (sum(1 << (8 + f) for f in families) if families is not None else 0)
     rc = L.dgs_spmm_fold_selftest(_p(scratch), ctypes.c_size_t(nb), int(rounds), int(flags), None)
     return rc, selftest_detail()[2:2 + L.dgs_spmm_selftest_families()]
