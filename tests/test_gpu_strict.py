@@ -168,7 +168,7 @@ def test_default_sum_chains_the_hub_rows(capi, monkeypatch, N, plan):
     rp, col, st = graphgen.powerlaw_csr(70000, 900000, alpha=1.9, dmax=20000, seed=21)
     lens = np.diff(rp)
     hub = lens > 1024
-    assert hub.sum() >= 8 and lens.max() > 8000
+    assert hub.sum() >= 8 and lens.max() > 5000  # (the generator rescales its degrees to the nnz budget: the longest row is ~7 500)
     val = graphgen.weights(col.shape[0], 'uniform', 5)
     X = graphgen.features(st['K'], N, 6)
     ref, _ = oracle.spmm('sum', rp, col, val, X, fma=True, threads=oracle.max_threads())
