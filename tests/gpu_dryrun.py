@@ -126,7 +126,8 @@ NO_DRY_RUN = (('dgsparse.', 'goes through the torch operator binding (_spmm_hip.
               ('CUDAGraph', 'CUDA graph capture'), ('torch.cuda.graph', 'CUDA graph capture'),
               ('subprocess', 'spawns worker processes (RCCL / torchrun)'), ('torch.distributed', 'needs a process group'),
               ('dgsparse import dist', 'dgsparse.dist drives HIP streams and collectives'), ('_spmm_hip', 'torch binding'),
-              ('from dgsparse import nn', 'dgsparse.nn goes through the torch operator binding'))
+              ('from dgsparse import nn', 'dgsparse.nn goes through the torch operator binding'),
+              ('fuzz cases in', 'asserts a number of cases per minute of GPU time'))
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X')
@@ -167,7 +168,10 @@ def _dgs_tuning_follows_env(monkeypatch):
 
 
 def transform(src):
-    src = src.replace("'cuda'", "'cpu'").replace('"cuda"', '"cpu"').replace('.cuda()', '.cpu()').replace('cuda:0', 'cpu')
+    # (.cuda() / .to(d) COPY on the GPU box - host -> device; here they must copy too, or an accumulating launch would write through
+    # to the numpy array the expected value is computed from)
+    src = src.replace("'cuda'", "'cpu'").replace('"cuda"', '"cpu"').replace('.cuda()', '.clone()').replace('cuda:0', 'cpu')
+    src = re.sub(r"\.to\((d|dev|'cpu')\)", '.clone()', src)
     src = re.sub(r"torch\.device\('cpu', [^)]*\)", "torch.device('cpu')", src)
     return src
 
@@ -187,6 +191,7 @@ def main():
     os.makedirs(OUT)
     open(os.path.join(OUT, 'conftest.py'), 'w').write(CONFTEST % dict(root=ROOT))
     open(os.path.join(OUT, 'util.py'), 'w').write(transform(open(os.path.join(HERE, 'util.py')).read()))
+    open(os.path.join(OUT, 'fuzz_gpu.py'), 'w').write(transform(open(os.path.join(HERE, 'fuzz_gpu.py')).read()))
     os.symlink(os.path.join(HERE, 'golden'), os.path.join(OUT, 'golden'))
     names = []
     for f in files.split(','):

@@ -353,8 +353,12 @@ def test_cabi_error_codes(capi):
     E = torch.empty(M, N, dtype=torch.int32, device='cuda')
     nnz = col.shape[0]
     need = lib.dgs_spmm_csr_workspace_bytes(0, M, N, nnz)
-    assert need > 0
-    ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+    need_max = lib.dgs_spmm_csr_workspace_bytes(1, M, N, nnz)
+    assert 0 < need <= need_max
+    # (the buffer is as large as the LARGEST size claimed below: until round 6 it had the sum's size while the max call claimed the
+    # max's - the kernels then wrote their arg partial rows past its end, which the GPU's caching allocator happened to absorb and the
+    # CPU dry run of this test, tests/gpu_dryrun.py, did not)
+    ws = torch.empty(need_max, dtype=torch.uint8, device='cuda')
     args = lambda op, Eptr, wsptr, wsb: lib.dgs_spmm_csr_f32(op, M, K, N, nnz, drp.data_ptr(), dcol.data_ptr(), None,  # noqa: E731
                                                              dX.data_ptr(), C.data_ptr(), Eptr, 0, wsptr, wsb, None)
     assert args(7, None, ws.data_ptr(), need) == -1  # DGS_EINVAL: bad reduce op
@@ -363,7 +367,7 @@ def test_cabi_error_codes(capi):
     assert args(0, None, None, 0) == -2
     assert lib.dgs_spmm_csr_f32(0, 2**31, K, N, nnz, drp.data_ptr(), dcol.data_ptr(), None, dX.data_ptr(), C.data_ptr(),
                                 None, 0, ws.data_ptr(), need, None) == -4  # DGS_ERANGE
-    assert args(1, E.data_ptr(), ws.data_ptr(), lib.dgs_spmm_csr_workspace_bytes(1, M, N, nnz)) in (0, -2)
+    assert args(1, E.data_ptr(), ws.data_ptr(), need_max) == 0
     assert args(0, None, ws.data_ptr(), need) == 0
     torch.cuda.synchronize()
     Co, _ = oracle.spmm('sum', rp, col, None, dX.cpu().numpy(), fma=True)
