@@ -9,6 +9,9 @@ for p in (ROOT, os.path.join(ROOT, 'dgsparse-lib_amd')):
         sys.path.insert(0, p)
 
 
+collect_ignore_glob = ['_dryrun/*', '_dryrun']  # tests/gpu_dryrun.py's scratch copies (same module names): never collected from here
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
     config.addinivalue_line('markers', 'first_contact: written in rounds 4 / 5 while the GPU pool was closed - never run on hardware: '

@@ -205,7 +205,9 @@ def main():
     env = {k: v for k, v in os.environ.items() if not k.startswith('DGS_')}
     cmd = [sys.executable, '-m', 'pytest', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', '--rootdir', OUT, '-c', os.devnull] + names + args
     print(' '.join(cmd), flush=True)
-    return subprocess.call(cmd, env=env, cwd=OUT)
+    rc = subprocess.call(cmd, env=env, cwd=OUT)
+    shutil.rmtree(OUT, ignore_errors=True)  # (its modules carry the names of the real test files: leave nothing for a plain `pytest tests` to trip over)
+    return rc
 
 
 if __name__ == '__main__':
